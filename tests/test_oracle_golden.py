@@ -1,0 +1,128 @@
+"""Pin the CPU oracle (oracle/ppnet_oracle.py) to golden vectors produced by the
+reference's own classes (oracle/gen_golden.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ppnet_oracle as O
+
+PROTO_CASES = ["proto_ms_small", "proto_ms_city", "proto_s3", "proto_floor", "proto_s1_wide"]
+
+
+def _t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def _ranges(g):
+    return {s: (int(lo), int(hi)) for s, (lo, hi) in enumerate(g["scale_ranges"])}
+
+
+@pytest.mark.parametrize("name", PROTO_CASES)
+def test_forward_matches_reference(golden, name):
+    g = golden(name)
+    S = int(g["num_scales"])
+    logits, d, act = O.forward_from_conv_features(
+        _t(g["conv"]), _t(g["prototype_vectors"]), _ranges(g), S, _t(g["last_layer_weight"])
+    )
+    # same op order as the reference -> agreement to fp32 rounding
+    np.testing.assert_allclose(d.numpy(), g["distances"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(act.numpy(), g["activations"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(logits.numpy(), g["logits"], rtol=1e-5, atol=1e-5)
+    # tuple quirk, model_multiscale.py:378-385: default -> distances, return_activations alone -> activations
+    np.testing.assert_array_equal(g["default_1"], g["distances"])
+    np.testing.assert_array_equal(g["act_1"], g["activations"])
+
+
+@pytest.mark.parametrize("name", PROTO_CASES)
+def test_backward_matches_reference(golden, name):
+    g = golden(name)
+    S = int(g["num_scales"])
+    _, _, _, dx, dp, dw = O.fwd_bwd_reference(
+        _t(g["conv"]), _t(g["prototype_vectors"]), _ranges(g), S, _t(g["last_layer_weight"]),
+        _t(g["g_logits"]), _t(g["g_dist"]), _t(g["g_act"]),
+    )
+    for got, key in ((dx, "d_conv"), (dp, "d_prototypes"), (dw, "d_last_layer")):
+        ref = g[key]
+        scale = np.abs(ref).max() + 1e-30
+        assert np.abs(got.numpy() - ref).max() <= 1e-5 * scale, key
+
+
+@pytest.mark.parametrize("name", PROTO_CASES)
+def test_default_layouts(golden, name):
+    g = golden(name)
+    S = int(g["num_scales"])
+    P, K = g["class_identity"].shape
+    np.testing.assert_array_equal(O.default_class_identity(P, K, S).numpy(), g["class_identity"])
+    r = O.default_scale_ranges(P, S)
+    np.testing.assert_array_equal(np.array([r[s] for s in range(S)]), g["scale_ranges"])
+    assert list(g["state_keys"]) == ["prototype_vectors", "ones", "last_layer.weight"]
+
+
+def test_group_head(golden):
+    g = golden("group_ms_small")
+    S = int(g["num_scales"])
+    G = int(g["num_groups"])
+    ident = _t(g["class_identity"])
+    n_cls = len(O.class_prototype_index(ident))
+    gw = [_t(g[f"group_w_{i}"]) for i in range(n_cls)]
+    logits, d, act = O.forward_from_conv_features(
+        _t(g["conv"]), _t(g["prototype_vectors"]), _ranges(g), S, None,
+        class_identity=ident, group_weights=gw, last_layer_group_weight=_t(g["last_layer_group_weight"]),
+    )
+    np.testing.assert_allclose(d.numpy(), g["distances"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(logits.numpy(), g["logits"], rtol=2e-5, atol=2e-5)
+    cat = torch.cat(O.compute_group(act, ident, gw), dim=-1)
+    np.testing.assert_allclose(cat.numpy(), g["group_cat"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_array_equal(O.group_class_identity(ident, G).numpy(), g["group_class_identity"])
+    keys = list(g["state_keys"])
+    assert "last_layer.weight" not in keys and "last_layer_group.weight" in keys
+    assert keys[:2] == ["prototype_vectors", "ones"]
+    # phase-1 -> phase-2 load_state_dict(strict=False): finetune_wandb_group.py:76
+    assert list(g["unexpected_keys"]) == ["last_layer.weight"]
+    # rows of every group projection live on the simplex after init
+    for w in gw:
+        np.testing.assert_allclose(w.sum(1).numpy(), 1.0, atol=1e-5)
+        assert (w >= 0).all()
+
+
+def test_single_scale_is_s1(golden):
+    g = golden("ppnet_single")
+    P = g["prototype_vectors"].shape[0]
+    logits, d, act = O.forward_from_conv_features(
+        _t(g["conv"]), _t(g["prototype_vectors"]), {0: (0, P)}, 1, _t(g["last_layer_weight"])
+    )
+    np.testing.assert_allclose(d.numpy(), g["distances"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(logits.numpy(), g["logits"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(act.numpy(), g["activations"], rtol=1e-6, atol=1e-6)
+
+
+def test_push_argmin(golden):
+    g = golden("push_argmin")
+    idx, val = O.push_masked_argmin(
+        _t(g["distances"]), _t(g["target"])[None], _t(g["class_identity"]), int(g["num_classes"]), void_class=0
+    )
+    np.testing.assert_array_equal(idx.numpy(), g["indices"])
+    np.testing.assert_array_equal(val.numpy(), g["values"])
+    # the fixture holds an absent class (-> index 0, value 1e10) and an exact tie (-> lowest flat index)
+    assert (g["values"] == np.float32(1e10)).any()
+    assert (g["indices"][g["values"] == np.float32(1e10)] == 0).all()
+    W = g["distances"].shape[-1]
+    assert g["indices"][0, 4] == 2 * W + 3 and g["values"][0, 4] == np.float32(0.125)
+
+
+def test_resize_label(golden):
+    g = golden("push_argmin")
+    for w, h in g["resize_sizes"]:
+        out = O.resize_label(g["label_full"], (int(w), int(h)))
+        np.testing.assert_array_equal(out.numpy(), g[f"resized_{w}x{h}"])
+
+
+def test_simplex_and_prune(golden):
+    g = golden("misc")
+    np.testing.assert_allclose(O.projection_simplex_sort(_t(g["simplex_in"])).numpy(), g["simplex_out"], atol=1e-6)
+    P, S = int(g["prune_P"]), int(g["prune_S"])
+    keep, ranges = O.prune_state(list(g["prune_drop"]), O.default_scale_ranges(P, S), S, P)
+    np.testing.assert_array_equal(np.array([ranges[s] for s in range(S)]), g["prune_after_ranges"])
+    np.testing.assert_array_equal(g["prune_before_protos"][keep], g["prune_after_protos"])
+    np.testing.assert_array_equal(g["prune_before_last"][:, keep], g["prune_after_last"])
+    assert tuple(g["prune_after_ones_shape"]) == g["prune_after_protos"].shape
