@@ -1,0 +1,134 @@
+/*
+ * spx_hip.h — C ABI of libspx_hip.so: the MI355X (gfx950) implementation of
+ * ScaleProtoSeg's prototype-distance hot path.
+ *
+ * The reference has no FFI: its boundary for this path is the Python surface of
+ * the PPNetMultiScale nn.Module.  The entry points below are the
+ * device-side operators that surface needs; the Python package
+ * `scaleprotoseg_amd` binds them with ctypes and mirrors the reference's
+ * module/function names above them.  Each entry point cites the reference
+ * code it replaces (paths relative to the reference checkout).
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer unless named host_*; the caller owns and
+ *    allocates every buffer (torch.empty); nothing is retained after return;
+ *  - `stream` is a hipStream_t passed as void* (0 = default stream); calls only
+ *    enqueue work, they never synchronise;
+ *  - return 0 on success, non-zero on error; spx_last_error() gives the message
+ *    of the last failing call of the calling thread;
+ *  - tensors are dense, row-major, in the reference's layouts:
+ *      features X   [B, C, H*W]      bf16 (x_dtype 0) or fp32 (x_dtype 1), C = S*Cs
+ *      bank         [P, Cs]          fp32   (prototype_vectors.view(P, Cs))
+ *      distances    [B, P, H*W]      fp32
+ *      activations  [B*H*W, P]       fp32   (NHWC pixel order)
+ *      logits       [B*H*W, K]       fp32
+ *      last layer W [K, P]           fp32
+ */
+#ifndef SPX_HIP_H
+#define SPX_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPX_MAX_PANELS 64   /* (scale, <=192-prototype block) work units per pixel tile */
+#define SPX_ABI_VERSION 1
+
+/* How the prototype bank is cut into MFMA panels.  Filled by spx_make_plan(). */
+typedef struct spx_plan {
+    int32_t num_prototypes;        /* P */
+    int32_t num_classes;           /* K */
+    int32_t num_scales;            /* S */
+    int32_t channels_per_scale;    /* Cs (multiple of 16) */
+    int32_t kc;                    /* channels staged per LDS step (16 or 32) */
+    int32_t npb;                   /* 32-prototype blocks per panel (1..6) */
+    int32_t ncb;                   /* 32-class blocks of the head (1..5) */
+    int32_t npanels;
+    int32_t panel_ch0[SPX_MAX_PANELS];  /* first feature channel of the panel's scale */
+    int32_t panel_p0[SPX_MAX_PANELS];   /* first prototype row of the panel */
+    int32_t panel_np[SPX_MAX_PANELS];   /* prototypes in the panel (<= 32*npb) */
+} spx_plan;
+
+int spx_version(void);
+const char* spx_last_error(void);
+
+/* Build the panel plan from the module's scale table
+ * (scale_num_prototypes, segmentation/model/model_multiscale.py:146-149, re-packed by
+ * prune_prototypes :408-423).  host_scale_lo/hi: S entries each, HOST memory. */
+int spx_make_plan(int32_t P, int32_t K, int32_t S, int32_t Cs,
+                  const int32_t* host_scale_lo, const int32_t* host_scale_hi, spx_plan* out);
+
+/* Sizes (bytes) of the packed operand buffers for a plan. */
+size_t spx_packed_bank_bytes(const spx_plan* plan);   /* bf16 MFMA A-fragments of the bank          */
+size_t spx_packed_bankT_bytes(const spx_plan* plan);  /* bf16 A-fragments of bank^T (backward dX)   */
+size_t spx_packed_p2_bytes(const spx_plan* plan);     /* fp32 |p|^2 per padded prototype            */
+size_t spx_packed_head_bytes(const spx_plan* plan);   /* split-bf16 (hi,lo) fragments of W          */
+size_t spx_packed_headT_bytes(const spx_plan* plan);  /* split-bf16 fragments of W^T (backward)     */
+
+/* Re-pack the fp32 bank into bf16 MFMA fragment order and compute |p|^2
+ * (replaces the per-forward p**2 / sum of model_multiscale.py:270-274).
+ * packed_bankT may be NULL when no backward is needed. */
+int spx_pack_bank(const spx_plan* plan, const float* bank, void* packed_bank, void* packed_bankT,
+                  float* packed_p2, void* stream);
+
+/* Re-pack a dense [K, P] head matrix (last_layer.weight, model_multiscale.py:225; or the dense
+ * form of the grouping projections) into split-bf16 fragments.  packed_headT may be NULL. */
+int spx_pack_head(const spx_plan* plan, const float* W, void* packed_head, void* packed_headT, void* stream);
+
+/* Fused forward: distances -> similarity -> linear head.
+ * Replaces _scale_l2_convolution + _l2_convolution (model_multiscale.py:255-317),
+ * distance_2_similarity (:324-330), the permute/contiguous/reshape (:369-370) and
+ * run_last_layer (:243-244).  Any of distances/activations/logits may be NULL (not written).
+ * act_fn: 0 = "log" (log((d+1)/(d+eps))), 1 = "linear" (-d). */
+int spx_dist_fwd(const spx_plan* plan, const void* x, int32_t x_dtype, int32_t B, int32_t HW,
+                 const void* packed_bank, const float* packed_p2, const void* packed_head,
+                 float* distances, float* activations, float* logits,
+                 float epsilon, int32_t act_fn, void* stream);
+
+/* Backward, pixel side: recomputes the distance tile, forms
+ *   G = (dDist + (dAct + dLogits.W) * act'(d)) * [d > 0]
+ * and writes dX = 2 (rowsum_s(G) x - G.P) in X's dtype, plus bf16 copies of G and of the
+ * activations (both [P_pad, B*HW], prototype-major) for spx_bank_bwd.  Replaces autograd through
+ * model_multiscale.py:255-281,324-330,243-244.  d_dist / d_act / d_logits may be NULL (treated as 0);
+ * dx may be NULL (X frozen); g_out / a_out may be NULL when the bank / head are frozen. */
+int spx_dist_bwd(const spx_plan* plan, const void* x, int32_t x_dtype, int32_t B, int32_t HW,
+                 const void* packed_bank, const void* packed_bankT, const float* packed_p2,
+                 const void* packed_headT,
+                 const float* d_dist, const float* d_act, const float* d_logits,
+                 void* dx, void* g_out, void* a_out,
+                 float epsilon, int32_t act_fn, void* stream);
+
+/* Rows of the g_out / a_out scratch of spx_dist_bwd (= padded prototype count). */
+int32_t spx_gpad_rows(const spx_plan* plan);
+
+/* Backward, parameter side: d_bank [P, Cs] = 2 (p colsum(G) - G^T X) and d_W [K, P] = dLogits^T A,
+ * as a pixel-split MFMA reduction with per-workgroup fp32 partial slabs summed in a fixed order
+ * (no float atomics: replicas stay bit-identical).  workspace: spx_bank_bwd_workspace_bytes().
+ * d_bank / d_W may be NULL. */
+size_t spx_bank_bwd_workspace_bytes(const spx_plan* plan, int32_t B, int32_t HW);
+int spx_bank_bwd(const spx_plan* plan, const void* x, int32_t x_dtype, int32_t B, int32_t HW,
+                 const float* bank, const void* g_in, const void* a_in, const float* d_logits,
+                 float* d_bank, float* d_W, void* workspace, void* stream);
+
+/* Class-masked per-prototype argmin over the latent grid (prototype push).
+ * Replaces the one_hot / matmul / masked add / two min() reductions of
+ * segmentation/push_multiscale_optimization.py:74-91.  labels: int32 [B, HW], already resized with
+ * resize_label (dataset.py:22-30); label == void_class (or outside 0..K) matches no prototype;
+ * void_class < 0 means labels are 0..K-1 with no void.  class_identity: fp32 [P, K].
+ * Outputs: indices int64 [B, P] (flat i*W+j, lowest index on ties), values fp32 [B, P].
+ * scratch: uint64 [B*P]. */
+int spx_push_argmin(const float* distances, const int32_t* labels, const float* class_identity,
+                    int32_t B, int32_t P, int32_t K, int32_t HW, int32_t void_class, float max_dist,
+                    int64_t* indices, float* values, uint64_t* scratch, void* stream);
+
+/* Lexicographic (value, image) argmin over images per prototype: tot_dist.argmin(dim=0),
+ * push_multiscale_optimization.py:135-137.  values fp32 [N, P] -> best int64 [P]. */
+int spx_argmin_images(const float* values, int32_t N, int32_t P, int64_t* best, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPX_HIP_H */

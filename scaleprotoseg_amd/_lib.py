@@ -1,0 +1,121 @@
+"""ctypes binding of libspx_hip.so (include/spx_hip.h).
+
+The HIP extension is the only compute path of this package: loading fails
+loudly when the shared library is missing, and every operator raises when its
+tensors are not on an AMD GPU.  There is no CPU or eager-PyTorch fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libspx_hip.so")
+SPX_MAX_PANELS = 64
+ABI_VERSION = 1
+
+
+class SpxError(RuntimeError):
+    """A libspx_hip.so entry point returned a non-zero status."""
+
+
+class SpxPlan(C.Structure):
+    _fields_ = [
+        ("num_prototypes", C.c_int32),
+        ("num_classes", C.c_int32),
+        ("num_scales", C.c_int32),
+        ("channels_per_scale", C.c_int32),
+        ("kc", C.c_int32),
+        ("npb", C.c_int32),
+        ("ncb", C.c_int32),
+        ("npanels", C.c_int32),
+        ("panel_ch0", C.c_int32 * SPX_MAX_PANELS),
+        ("panel_p0", C.c_int32 * SPX_MAX_PANELS),
+        ("panel_np", C.c_int32 * SPX_MAX_PANELS),
+    ]
+
+
+_PP = C.POINTER(SpxPlan)
+_V = C.c_void_p
+_I = C.c_int32
+_F = C.c_float
+
+# name -> (restype, argtypes); must list every symbol include/spx_hip.h declares
+SIGNATURES = {
+    "spx_version": (C.c_int, []),
+    "spx_last_error": (C.c_char_p, []),
+    "spx_make_plan": (C.c_int, [_I, _I, _I, _I, C.POINTER(_I), C.POINTER(_I), _PP]),
+    "spx_packed_bank_bytes": (C.c_size_t, [_PP]),
+    "spx_packed_bankT_bytes": (C.c_size_t, [_PP]),
+    "spx_packed_p2_bytes": (C.c_size_t, [_PP]),
+    "spx_packed_head_bytes": (C.c_size_t, [_PP]),
+    "spx_packed_headT_bytes": (C.c_size_t, [_PP]),
+    "spx_pack_bank": (C.c_int, [_PP, _V, _V, _V, _V, _V]),
+    "spx_pack_head": (C.c_int, [_PP, _V, _V, _V, _V]),
+    "spx_dist_fwd": (C.c_int, [_PP, _V, _I, _I, _I, _V, _V, _V, _V, _V, _V, _F, _I, _V]),
+    "spx_dist_bwd": (C.c_int, [_PP, _V, _I, _I, _I, _V, _V, _V, _V, _V, _V, _V, _V, _V, _V, _F, _I, _V]),
+    "spx_gpad_rows": (_I, [_PP]),
+    "spx_bank_bwd_workspace_bytes": (C.c_size_t, [_PP, _I, _I]),
+    "spx_bank_bwd": (C.c_int, [_PP, _V, _I, _I, _I, _V, _V, _V, _V, _V, _V, _V, _V]),
+    "spx_push_argmin": (C.c_int, [_V, _V, _V, _I, _I, _I, _I, _I, _F, _V, _V, _V, _V]),
+    "spx_argmin_images": (C.c_int, [_V, _I, _I, _V, _V]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """Load libspx_hip.so (built by scaleprotoseg_amd.build / __graft_entry__.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SpxError(
+            f"{LIB_PATH} is missing: build it with `python -m scaleprotoseg_amd.build` "
+            "(hipcc --offload-arch=gfx950).  scaleprotoseg_amd has no CPU fallback."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.spx_version() != ABI_VERSION:
+        raise SpxError(f"libspx_hip.so ABI {lib.spx_version()} != binding ABI {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(status: int) -> None:
+    if status != 0:
+        raise SpxError(load().spx_last_error().decode("utf-8", "replace"))
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    """Raw device pointer of a dense GPU tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise SpxError(
+            "scaleprotoseg_amd operators run on an AMD GPU only (tensor is on "
+            f"{t.device}); there is no CPU fallback"
+        )
+    if not t.is_contiguous():
+        raise SpxError("tensor must be contiguous")
+    return t.data_ptr()
+
+
+def stream_ptr() -> int:
+    """hipStream_t of torch's current stream."""
+    return torch.cuda.current_stream().cuda_stream
+
+
+def make_plan(P: int, K: int, S: int, Cs: int, scale_lo, scale_hi) -> SpxPlan:
+    lib = load()
+    plan = SpxPlan()
+    lo = (C.c_int32 * S)(*[int(v) for v in scale_lo])
+    hi = (C.c_int32 * S)(*[int(v) for v in scale_hi])
+    check(lib.spx_make_plan(P, K, S, Cs, lo, hi, C.byref(plan)))
+    return plan

@@ -1,0 +1,220 @@
+// C ABI of libspx_hip.so (see include/spx_hip.h).  Host-side validation + kernel launches; no torch types,
+// no allocation, no synchronisation (graph-capturable).
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "spx_args.h"
+
+static thread_local char g_err[512] = "";
+
+static int fail(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return 1;
+}
+static int hip_status(hipError_t e, const char* what) {
+    if (e == hipSuccess) return 0;
+    return fail("%s: %s", what, hipGetErrorString(e));
+}
+static int check_plan(const spx_plan* pl) {
+    if (!pl) return fail("plan is NULL");
+    if (pl->npanels < 1 || pl->npanels > SPX_MAX_PANELS) return fail("plan: npanels %d out of range", pl->npanels);
+    if (pl->npb < 1 || pl->npb > 6) return fail("plan: npb %d out of range", pl->npb);
+    if (pl->ncb < 1 || pl->ncb > 5) return fail("plan: ncb %d out of range", pl->ncb);
+    if (pl->kc != 16 && pl->kc != 32) return fail("plan: kc %d", pl->kc);
+    if (pl->channels_per_scale % pl->kc) return fail("plan: Cs %d not a multiple of kc", pl->channels_per_scale);
+    return 0;
+}
+static int x_vec_ok(const void* x, int x_dtype, int HW) {
+    const uintptr_t p = (uintptr_t)x;
+    if (p & 15) return 0;
+    return x_dtype == 1 ? (HW % 4 == 0) : (HW % 8 == 0);
+}
+
+extern "C" {
+
+int spx_version(void) { return SPX_ABI_VERSION; }
+const char* spx_last_error(void) { return g_err; }
+
+int spx_make_plan(int32_t P, int32_t K, int32_t S, int32_t Cs, const int32_t* lo, const int32_t* hi, spx_plan* out) {
+    if (!out || !lo || !hi) return fail("spx_make_plan: NULL argument");
+    if (P < 1 || K < 1 || S < 1 || Cs < 1) return fail("spx_make_plan: non-positive size (P=%d K=%d S=%d Cs=%d)", P, K, S, Cs);
+    if (Cs % 16) return fail("spx_make_plan: channels per scale (%d) must be a multiple of 16 (MFMA k-step)", Cs);
+    if (K > 160) return fail("spx_make_plan: num_classes %d > 160 not supported by the fused head", K);
+    memset(out, 0, sizeof(*out));
+    out->num_prototypes = P;
+    out->num_classes = K;
+    out->num_scales = S;
+    out->channels_per_scale = Cs;
+    out->kc = (Cs % 32 == 0) ? 32 : 16;
+    out->ncb = (K + 31) / 32;
+    int per_max = 1, covered = 0;
+    for (int s = 0; s < S; ++s) {
+        const int n = hi[s] - lo[s];
+        if (lo[s] < 0 || hi[s] > P || n < 0) return fail("spx_make_plan: scale %d range (%d,%d) outside [0,%d]", s, lo[s], hi[s], P);
+        if (s && lo[s] != hi[s - 1]) return fail("spx_make_plan: scale ranges must be contiguous");
+        covered += n;
+        if (n == 0) continue;
+        const int np_s = (n + 191) / 192;
+        const int per = (n + np_s - 1) / np_s;
+        if (per > per_max) per_max = per;
+    }
+    // the reference's F.linear rejects a distance map narrower than the head (P % S != 0): same here
+    if (covered != P) return fail("spx_make_plan: scale table covers %d prototypes but the bank has %d (reference needs P %% S == 0)", covered, P);
+    out->npb = (per_max + 31) / 32;
+    const int cap = out->npb * 32;
+    int q = 0;
+    for (int s = 0; s < S; ++s) {
+        for (int p = lo[s]; p < hi[s]; p += cap) {
+            if (q >= SPX_MAX_PANELS) return fail("spx_make_plan: more than %d panels", SPX_MAX_PANELS);
+            out->panel_ch0[q] = s * Cs;
+            out->panel_p0[q] = p;
+            out->panel_np[q] = (hi[s] - p < cap) ? hi[s] - p : cap;
+            ++q;
+        }
+    }
+    if (q == 0) return fail("spx_make_plan: empty bank");
+    out->npanels = q;
+    return 0;
+}
+
+int32_t spx_gpad_rows(const spx_plan* pl) { return pl->npanels * pl->npb * 32; }
+
+size_t spx_packed_bank_bytes(const spx_plan* pl) {
+    return (size_t)pl->npanels * pl->npb * 32 * pl->channels_per_scale * 2;
+}
+size_t spx_packed_bankT_bytes(const spx_plan* pl) {
+    return (size_t)pl->npanels * pl->npb * 2 * ((pl->channels_per_scale + 31) / 32) * 1024;
+}
+size_t spx_packed_p2_bytes(const spx_plan* pl) { return (size_t)pl->npanels * pl->npb * 32 * 4; }
+size_t spx_packed_head_bytes(const spx_plan* pl) { return (size_t)pl->ncb * pl->npanels * pl->npb * 2 * 2048; }
+size_t spx_packed_headT_bytes(const spx_plan* pl) { return (size_t)pl->npanels * pl->npb * (pl->ncb * 2) * 2048; }
+
+int spx_pack_bank(const spx_plan* pl, const float* bank, void* pb, void* pbT, float* p2, void* stream) {
+    if (check_plan(pl)) return 1;
+    if (!bank || !pb || !p2) return fail("spx_pack_bank: NULL buffer");
+    return hip_status(spx_launch_pack_bank(*pl, bank, pb, pbT, p2, (hipStream_t)stream), "spx_pack_bank");
+}
+
+int spx_pack_head(const spx_plan* pl, const float* W, void* ph, void* phT, void* stream) {
+    if (check_plan(pl)) return 1;
+    if (!W || !ph) return fail("spx_pack_head: NULL buffer");
+    return hip_status(spx_launch_pack_head(*pl, W, ph, phT, (hipStream_t)stream), "spx_pack_head");
+}
+
+int spx_dist_fwd(const spx_plan* pl, const void* x, int32_t x_dtype, int32_t B, int32_t HW, const void* packed_bank,
+                 const float* packed_p2, const void* packed_head, float* distances, float* activations,
+                 float* logits, float epsilon, int32_t act_fn, void* stream) {
+    if (check_plan(pl)) return 1;
+    if (!x || !packed_bank || !packed_p2) return fail("spx_dist_fwd: NULL operand");
+    if (x_dtype != 0 && x_dtype != 1) return fail("spx_dist_fwd: x_dtype %d (0 = bf16, 1 = fp32)", x_dtype);
+    if (B < 1 || HW < 1) return fail("spx_dist_fwd: empty input (B=%d HW=%d)", B, HW);
+    if (act_fn != 0 && act_fn != 1) return fail("spx_dist_fwd: act_fn %d", act_fn);
+    if (logits && !packed_head) return fail("spx_dist_fwd: logits requested without a packed head");
+    const long long tiles = (long long)B * ((HW + SPX_TILE_PX - 1) / SPX_TILE_PX);
+    if (tiles > 0x7fffffffLL) return fail("spx_dist_fwd: too many pixel tiles");
+    SpxFwdArgs a;
+    a.plan = *pl;
+    a.x = x;
+    a.packed_bank = (const char*)packed_bank;
+    a.p2 = packed_p2;
+    a.packed_head = (const char*)packed_head;
+    a.dist = distances;
+    a.act = activations;
+    a.logits = logits;
+    a.B = B;
+    a.HW = HW;
+    a.vec_ok = x_vec_ok(x, x_dtype, HW);
+    a.eps = epsilon;
+    a.act_fn = act_fn;
+    return hip_status(spx_launch_fwd(a, x_dtype, (hipStream_t)stream), "spx_dist_fwd");
+}
+
+int spx_dist_bwd(const spx_plan* pl, const void* x, int32_t x_dtype, int32_t B, int32_t HW, const void* packed_bank,
+                 const void* packed_bankT, const float* packed_p2, const void* packed_headT, const float* d_dist,
+                 const float* d_act, const float* d_logits, void* dx, void* g_out, void* a_out, float epsilon,
+                 int32_t act_fn, void* stream) {
+    if (check_plan(pl)) return 1;
+    if (!x || !packed_bank || !packed_p2) return fail("spx_dist_bwd: NULL operand");
+    if (x_dtype != 0 && x_dtype != 1) return fail("spx_dist_bwd: x_dtype %d", x_dtype);
+    if (B < 1 || HW < 1) return fail("spx_dist_bwd: empty input");
+    if (dx && !packed_bankT) return fail("spx_dist_bwd: dx requested without packed bank^T");
+    if (d_logits && !packed_headT) return fail("spx_dist_bwd: d_logits given without packed head^T");
+    if (pl->channels_per_scale > 256) return fail("spx_dist_bwd: Cs %d > 256 not supported", pl->channels_per_scale);
+    SpxBwdArgs a;
+    a.plan = *pl;
+    a.x = x;
+    a.packed_bank = (const char*)packed_bank;
+    a.packed_bankT = (const char*)packed_bankT;
+    a.p2 = packed_p2;
+    a.packed_headT = (const char*)packed_headT;
+    a.d_dist = d_dist;
+    a.d_act = d_act;
+    a.d_logits = d_logits;
+    a.dx = dx;
+    a.g_out = (uint16_t*)g_out;
+    a.a_out = (uint16_t*)a_out;
+    a.B = B;
+    a.HW = HW;
+    a.HWp = (HW + 7) & ~7;
+    a.vec_ok = x_vec_ok(x, x_dtype, HW);
+    a.eps = epsilon;
+    a.act_fn = act_fn;
+    return hip_status(spx_launch_bwd(a, x_dtype, (hipStream_t)stream), "spx_dist_bwd");
+}
+
+size_t spx_bank_bwd_workspace_bytes(const spx_plan* pl, int32_t B, int32_t HW) {
+    const int nsplit = spx_bank_bwd_nsplit(*pl, B, HW);
+    return spx_bank_bwd_ws_floats(*pl, nsplit) * sizeof(float);
+}
+
+int spx_bank_bwd(const spx_plan* pl, const void* x, int32_t x_dtype, int32_t B, int32_t HW, const float* bank,
+                 const void* g_in, const void* a_in, const float* d_logits, float* d_bank, float* d_W,
+                 void* workspace, void* stream) {
+    if (check_plan(pl)) return 1;
+    if (!x || !bank || !workspace) return fail("spx_bank_bwd: NULL operand");
+    if (x_dtype != 0 && x_dtype != 1) return fail("spx_bank_bwd: x_dtype %d", x_dtype);
+    if (d_bank && !g_in) return fail("spx_bank_bwd: d_bank requested without G");
+    if (d_W && (!a_in || !d_logits)) return fail("spx_bank_bwd: d_W requested without activations / d_logits");
+    if (pl->channels_per_scale > 256) return fail("spx_bank_bwd: Cs %d > 256 not supported", pl->channels_per_scale);
+    SpxBankBwdArgs a;
+    a.plan = *pl;
+    a.x = x;
+    a.bank = bank;
+    a.g_in = (const uint16_t*)g_in;
+    a.a_in = (const uint16_t*)a_in;
+    a.d_logits = d_logits;
+    a.d_bank = d_bank;
+    a.d_W = d_W;
+    a.workspace = (float*)workspace;
+    a.B = B;
+    a.HW = HW;
+    a.HWp = (HW + 7) & ~7;
+    a.vec_ok = x_vec_ok(x, x_dtype, HW);
+    a.nsplit = spx_bank_bwd_nsplit(*pl, B, HW);
+    return hip_status(spx_launch_bank_bwd(a, x_dtype, (hipStream_t)stream), "spx_bank_bwd");
+}
+
+int spx_push_argmin(const float* distances, const int32_t* labels, const float* class_identity, int32_t B, int32_t P,
+                    int32_t K, int32_t HW, int32_t void_class, float max_dist, int64_t* indices, float* values,
+                    uint64_t* scratch, void* stream) {
+    if (!distances || !labels || !class_identity || !indices || !values || !scratch)
+        return fail("spx_push_argmin: NULL buffer");
+    if (B < 1 || P < 1 || K < 1 || HW < 1) return fail("spx_push_argmin: empty input");
+    if (K > 160) return fail("spx_push_argmin: num_classes %d > 160", K);
+    if (P > 65535 || B > 65535) return fail("spx_push_argmin: grid too large");
+    return hip_status(spx_launch_push_argmin(distances, labels, class_identity, B, P, K, HW, void_class, max_dist,
+                                             indices, values, scratch, (hipStream_t)stream),
+                      "spx_push_argmin");
+}
+
+int spx_argmin_images(const float* values, int32_t N, int32_t P, int64_t* best, void* stream) {
+    if (!values || !best) return fail("spx_argmin_images: NULL buffer");
+    if (N < 1 || P < 1) return fail("spx_argmin_images: empty input");
+    return hip_status(spx_launch_argmin_images(values, N, P, best, (hipStream_t)stream), "spx_argmin_images");
+}
+
+}  // extern "C"

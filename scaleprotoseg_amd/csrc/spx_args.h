@@ -1,0 +1,58 @@
+// Kernel argument blocks + launcher prototypes shared by the kernel translation units and the C ABI.
+#pragma once
+#include "spx_common.h"
+
+struct SpxFwdArgs {
+    spx_plan plan;
+    const void* x;
+    const char* packed_bank;
+    const float* p2;
+    const char* packed_head;
+    float* dist;
+    float* act;
+    float* logits;
+    int B, HW, vec_ok;
+    float eps;
+    int act_fn;
+};
+struct SpxBwdArgs {
+    spx_plan plan;
+    const void* x;
+    const char* packed_bank;
+    const char* packed_bankT;
+    const float* p2;
+    const char* packed_headT;
+    const float* d_dist;
+    const float* d_act;
+    const float* d_logits;
+    void* dx;
+    uint16_t* g_out;
+    uint16_t* a_out;
+    int B, HW, HWp, vec_ok;
+    float eps;
+    int act_fn;
+};
+struct SpxBankBwdArgs {
+    spx_plan plan;
+    const void* x;
+    const float* bank;
+    const uint16_t* g_in;
+    const uint16_t* a_in;
+    const float* d_logits;
+    float* d_bank;
+    float* d_W;
+    float* workspace;
+    int B, HW, HWp, vec_ok, nsplit;
+};
+hipError_t spx_launch_fwd(const SpxFwdArgs& a, int x_dtype, hipStream_t s);
+hipError_t spx_launch_bwd(const SpxBwdArgs& a, int x_dtype, hipStream_t s);
+hipError_t spx_launch_bank_bwd(const SpxBankBwdArgs& a, int x_dtype, hipStream_t s);
+int spx_bank_bwd_nsplit(const spx_plan& pl, int B, int HW);
+size_t spx_bank_bwd_ws_floats(const spx_plan& pl, int nsplit);
+hipError_t spx_launch_pack_bank(const spx_plan& pl, const float* bank, void* pb, void* pbT, float* p2, hipStream_t s);
+hipError_t spx_launch_pack_head(const spx_plan& pl, const float* W, void* ph, void* phT, hipStream_t s);
+hipError_t spx_launch_push_argmin(const float* dist, const int32_t* labels, const float* ident, int B, int P, int K,
+                                  int HW, int void_class, float max_dist, int64_t* idx, float* val,
+                                  uint64_t* scratch, hipStream_t s);
+hipError_t spx_launch_argmin_images(const float* values, int N, int P, int64_t* best, hipStream_t s);
+

@@ -1,0 +1,55 @@
+// Shared device helpers for the gfx950 prototype-distance kernels.
+// CDNA4 only: 64-lane wavefronts, v_mfma_f32_32x32x16_bf16, ds_read_b64_tr_b16.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/spx_hip.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+#define SPX_TILE_PX 128          // latent pixels per workgroup tile (4 waves x 32)
+#define SPX_XROW 160             // bf16 elements per LDS row of the [k][pixel] X image (128 + 32 pad:
+                                 // 320-B stride puts the 4 rows of a transposed read on disjoint banks)
+#define SPX_LDS_LIMIT (160 * 1024)
+
+// Row of a 32x32 MFMA accumulator held in register `reg` of lane half `h`
+// (cdna guide §3: row = (reg&3) + 8*(reg>>2) + 4*(lane>>5), col = lane&31).
+__device__ __forceinline__ int acc_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
+
+__device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+// fp32 -> (hi, lo) bf16 pair with hi + lo == x to ~2^-17 relative.
+__device__ __forceinline__ void split_bf16(float x, __bf16& hi, __bf16& lo) {
+    hi = (__bf16)x;
+    lo = (__bf16)(x - (float)hi);
+}
+
+// Transposed LDS read: 4 k-rows x (this lane's pixel) -> 4 bf16, see cdna guide T10.
+__device__ __forceinline__ s16x4 lds_tr_read(const char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+}
+
+__device__ __forceinline__ float act_log(float d, float eps) {
+    // log((d+1)/(d+eps)), segmentation/model/model_multiscale.py:326
+    return __logf(__fdividef(d + 1.0f, d + eps));
+}
+
+// monotone float -> uint32 key (total order incl. negatives), for packed (value,index) minima
+__device__ __forceinline__ uint32_t float_key(float v) {
+    uint32_t u = __float_as_uint(v);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key_float(uint32_t k) {
+    uint32_t u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    return __uint_as_float(u);
+}

@@ -1,0 +1,142 @@
+// Operand re-packing: fp32 parameters -> bf16 MFMA fragment order (one 1-KiB fragment = 64 lanes x 8 bf16,
+// stored lane-linear so a wave fetches it with one coalesced 16-B-per-lane load and LDS copies are verbatim).
+#include "spx_common.h"
+
+// A-fragment element map of v_mfma_f32_32x32x16_bf16: lane l holds A[row l&31][k = 8*(l>>5) + j], j = 0..7.
+// When the B operand is an accumulator tile (head / dX products) hardware k = 8h+j meets tile row
+// 16*s2 + 8*(j>>2) + 4*h + (j&3)  (cdna guide §3 'An accumulator tile as the next MFMA's operand').
+__device__ __forceinline__ int perm_row(int s2, int h, int j) { return 16 * s2 + 8 * (j >> 2) + 4 * h + (j & 3); }
+
+// packed_bank [panel][chunk][pb][ks][lane][8], p2 [panel][npb*32], packed_bankT [panel][pb][s2][chb][lane][8]
+__global__ void spx_pack_bank_kernel(const spx_plan pl, const float* __restrict__ bank, __bf16* __restrict__ pb_out,
+                                     __bf16* __restrict__ pbT_out, float* __restrict__ p2_out) {
+    const int Cs = pl.channels_per_scale;
+    const int nks = pl.kc >> 4, nchunks = Cs / pl.kc;
+    const int nchb = (Cs + 31) / 32;
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n_fwd = pl.npanels * pl.npb * 32 * Cs / 8;          // 8-element groups
+    const int n_T = pl.npanels * pl.npb * 2 * nchb * 64;
+    const int n_p2 = pl.npanels * pl.npb * 32;
+    if (gid < n_fwd) {
+        int t = gid;
+        const int lane = t & 63; t >>= 6;
+        const int ks = t % nks; t /= nks;
+        const int pb = t % pl.npb; t /= pl.npb;
+        const int chunk = t % nchunks; t /= nchunks;
+        const int panel = t;
+        const int row = pb * 32 + (lane & 31);
+        const int c0 = chunk * pl.kc + ks * 16 + 8 * (lane >> 5);
+        bf16x8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float f = 0.0f;
+            if (row < pl.panel_np[panel]) f = bank[(size_t)(pl.panel_p0[panel] + row) * Cs + c0 + j];
+            v[j] = (__bf16)f;
+        }
+        *(bf16x8*)(pb_out + (size_t)gid * 8) = v;
+    }
+    if (pbT_out && gid < n_T) {
+        int t = gid;
+        const int lane = t & 63; t >>= 6;
+        const int chb = t % nchb; t /= nchb;
+        const int s2 = t & 1; t >>= 1;
+        const int pb = t % pl.npb; t /= pl.npb;
+        const int panel = t;
+        const int ch = chb * 32 + (lane & 31);
+        bf16x8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int row = pb * 32 + perm_row(s2, lane >> 5, j);
+            float f = 0.0f;
+            if (row < pl.panel_np[panel] && ch < Cs) f = bank[(size_t)(pl.panel_p0[panel] + row) * Cs + ch];
+            v[j] = (__bf16)f;
+        }
+        *(bf16x8*)(pbT_out + (size_t)gid * 8) = v;
+    }
+    if (gid < n_p2) {
+        const int panel = gid / (pl.npb * 32), row = gid - panel * pl.npb * 32;
+        float s = 0.0f;
+        if (row < pl.panel_np[panel]) {
+            const float* src = bank + (size_t)(pl.panel_p0[panel] + row) * Cs;
+            for (int c = 0; c < Cs; ++c) {
+                const float f = (float)(__bf16)src[c];   // |p|^2 of the prototype the MFMA actually sees
+                s = __builtin_fmaf(f, f, s);
+            }
+        }
+        p2_out[gid] = s;
+    }
+}
+
+// packed_head  [cb][panel][pb][s2][hi|lo][lane][8]      (A = W rows, k = permuted prototype rows)
+// packed_headT [panel][pb][cstep][hi|lo][lane][8]        (A = W^T rows = prototypes, k = classes)
+__global__ void spx_pack_head_kernel(const spx_plan pl, const float* __restrict__ W, __bf16* __restrict__ ph,
+                                     __bf16* __restrict__ phT) {
+    const int P = pl.num_prototypes, K = pl.num_classes;
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n_h = pl.ncb * pl.npanels * pl.npb * 2 * 64;        // (hi,lo) pairs of 8-groups
+    const int n_t = pl.npanels * pl.npb * (pl.ncb * 2) * 64;
+    if (gid < n_h) {
+        int t = gid;
+        const int lane = t & 63; t >>= 6;
+        const int s2 = t & 1; t >>= 1;
+        const int pb = t % pl.npb; t /= pl.npb;
+        const int panel = t % pl.npanels; t /= pl.npanels;
+        const int cb = t;
+        const int cls = cb * 32 + (lane & 31);
+        bf16x8 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int row = pb * 32 + perm_row(s2, lane >> 5, j);
+            float f = 0.0f;
+            if (cls < K && row < pl.panel_np[panel]) f = W[(size_t)cls * P + pl.panel_p0[panel] + row];
+            __bf16 a, b;
+            split_bf16(f, a, b);
+            hi[j] = a;
+            lo[j] = b;
+        }
+        const size_t base = ((size_t)(gid >> 6) * 2) * 512 + (size_t)lane * 8;
+        *(bf16x8*)(ph + base) = hi;
+        *(bf16x8*)(ph + base + 512) = lo;
+    }
+    if (phT && gid < n_t) {
+        int t = gid;
+        const int lane = t & 63; t >>= 6;
+        const int cstep = t % (pl.ncb * 2); t /= (pl.ncb * 2);
+        const int pb = t % pl.npb; t /= pl.npb;
+        const int panel = t;
+        const int row = pb * 32 + (lane & 31);
+        bf16x8 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int cls = cstep * 16 + 8 * (lane >> 5) + j;
+            float f = 0.0f;
+            if (cls < K && row < pl.panel_np[panel]) f = W[(size_t)cls * P + pl.panel_p0[panel] + row];
+            __bf16 a, b;
+            split_bf16(f, a, b);
+            hi[j] = a;
+            lo[j] = b;
+        }
+        const size_t base = ((size_t)(gid >> 6) * 2) * 512 + (size_t)lane * 8;
+        *(bf16x8*)(phT + base) = hi;
+        *(bf16x8*)(phT + base + 512) = lo;
+    }
+}
+
+hipError_t spx_launch_pack_bank(const spx_plan& pl, const float* bank, void* pb, void* pbT, float* p2, hipStream_t s) {
+    const int Cs = pl.channels_per_scale, nchb = (Cs + 31) / 32;
+    int n = pl.npanels * pl.npb * 32 * Cs / 8;
+    const int nT = pl.npanels * pl.npb * 2 * nchb * 64;
+    if (nT > n) n = nT;
+    const int np2 = pl.npanels * pl.npb * 32;
+    if (np2 > n) n = np2;
+    hipLaunchKernelGGL(spx_pack_bank_kernel, dim3((n + 255) / 256), dim3(256), 0, s, pl, bank, (__bf16*)pb,
+                       (__bf16*)pbT, p2);
+    return hipGetLastError();
+}
+
+hipError_t spx_launch_pack_head(const spx_plan& pl, const float* W, void* ph, void* phT, hipStream_t s) {
+    const int n = pl.ncb * pl.npanels * pl.npb * 2 * 64;   // == n_t
+    hipLaunchKernelGGL(spx_pack_head_kernel, dim3((n + 255) / 256), dim3(256), 0, s, pl, W, (__bf16*)ph,
+                       (__bf16*)phT);
+    return hipGetLastError();
+}

@@ -1,0 +1,228 @@
+"""Autograd operators over the libspx_hip.so C ABI.
+
+`proto_head_forward` is the fused replacement of the reference's
+``_scale_l2_convolution`` -> ``distance_2_similarity`` -> ``last_layer`` chain
+(segmentation/model/model_multiscale.py:255-330, :243-244, :362-376) and of its
+autograd backward.  PyTorch is used for device memory, streams and autograd
+plumbing only; all arithmetic on the path runs in the HIP kernels.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Dict, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import SpxError, SpxPlan
+
+ACT_FN = {"log": 0, "linear": 1}
+
+
+@dataclass
+class BankLayout:
+    """Static description of the prototype bank that the kernels are planned for."""
+
+    num_prototypes: int
+    num_classes: int          # rows of the dense head matrix fed to the kernel
+    num_scales: int
+    channels_per_scale: int
+    scale_ranges: Tuple[Tuple[int, int], ...]
+
+    def plan(self) -> SpxPlan:
+        lo = [r[0] for r in self.scale_ranges]
+        hi = [r[1] for r in self.scale_ranges]
+        return _lib.make_plan(
+            self.num_prototypes, self.num_classes, self.num_scales, self.channels_per_scale, lo, hi
+        )
+
+
+def _x_dtype_code(x: torch.Tensor) -> int:
+    if x.dtype == torch.bfloat16:
+        return 0
+    if x.dtype == torch.float32:
+        return 1
+    raise SpxError(f"features must be bfloat16 or float32, got {x.dtype}")
+
+
+def _check_x(x: torch.Tensor, layout: BankLayout) -> Tuple[int, int]:
+    if x.dim() != 4:
+        raise SpxError(f"features must be [B, C, H, W], got shape {tuple(x.shape)}")
+    B, Cx, H, W = x.shape
+    if Cx != layout.num_scales * layout.channels_per_scale:
+        raise SpxError(
+            f"features have {Cx} channels, prototype bank expects "
+            f"{layout.num_scales} x {layout.channels_per_scale}"
+        )
+    return B, H * W
+
+
+class _Packs:
+    """Device buffers holding the MFMA-ordered operands of one forward."""
+
+    def __init__(self, plan: SpxPlan, bank2d: torch.Tensor, head: Optional[torch.Tensor], need_bwd: bool):
+        lib = _lib.load()
+        dev = bank2d.device
+        pp = C.byref(plan)
+        u8 = dict(dtype=torch.uint8, device=dev)
+        self.bank = torch.empty(lib.spx_packed_bank_bytes(pp), **u8)
+        self.bankT = torch.empty(lib.spx_packed_bankT_bytes(pp), **u8) if need_bwd else None
+        self.p2 = torch.empty(lib.spx_packed_p2_bytes(pp) // 4, dtype=torch.float32, device=dev)
+        s = _lib.stream_ptr()
+        _lib.check(lib.spx_pack_bank(pp, _lib.ptr(bank2d), _lib.ptr(self.bank), _lib.ptr(self.bankT), _lib.ptr(self.p2), s))
+        self.head = self.headT = None
+        if head is not None:
+            self.head = torch.empty(lib.spx_packed_head_bytes(pp), **u8)
+            self.headT = torch.empty(lib.spx_packed_headT_bytes(pp), **u8) if need_bwd else None
+            _lib.check(lib.spx_pack_head(pp, _lib.ptr(head), _lib.ptr(self.head), _lib.ptr(self.headT), s))
+
+
+class _ProtoHeadFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, bank, head, layout, want_dist, want_act, epsilon, act_fn):
+        lib = _lib.load()
+        B, HW = _check_x(x, layout)
+        P, K = layout.num_prototypes, layout.num_classes
+        xd = _x_dtype_code(x)
+        x = x.contiguous()
+        bank2d = bank.detach().reshape(P, layout.channels_per_scale).contiguous().float()
+        head2d = head.detach().contiguous().float() if head is not None else None
+        if head2d is not None and tuple(head2d.shape) != (K, P):
+            raise SpxError(f"head matrix must be [{K}, {P}], got {tuple(head2d.shape)}")
+        plan = layout.plan()
+        need_bwd = any(t is not None and t.requires_grad for t in (x, bank, head))
+        packs = _Packs(plan, bank2d, head2d, need_bwd)
+        f32 = dict(dtype=torch.float32, device=x.device)
+        dist = torch.empty((B, P) + tuple(x.shape[2:]), **f32) if want_dist else None
+        act = torch.empty((B * HW, P), **f32) if want_act else None
+        logits = torch.empty((B * HW, K), **f32) if head is not None else None
+        _lib.check(
+            lib.spx_dist_fwd(
+                C.byref(plan), _lib.ptr(x), xd, B, HW, _lib.ptr(packs.bank), _lib.ptr(packs.p2), _lib.ptr(packs.head),
+                _lib.ptr(dist), _lib.ptr(act), _lib.ptr(logits), float(epsilon), ACT_FN[act_fn], _lib.stream_ptr(),
+            )
+        )
+        ctx.layout, ctx.plan, ctx.packs = layout, plan, packs
+        ctx.epsilon, ctx.act_fn = float(epsilon), act_fn
+        ctx.have = (logits is not None, dist is not None, act is not None)
+        ctx.save_for_backward(x, bank2d, head2d)
+        ctx.bank_shape = tuple(bank.shape)
+        outs = tuple(t if t is not None else x.new_empty(0) for t in (logits, dist, act))
+        ctx.mark_non_differentiable(*[o for o, h in zip(outs, ctx.have) if not h])
+        return outs
+
+    @staticmethod
+    def backward(ctx, g_logits, g_dist, g_act):
+        lib = _lib.load()
+        x, bank2d, head2d = ctx.saved_tensors
+        layout, plan, packs = ctx.layout, ctx.plan, ctx.packs
+        B, HW = _check_x(x, layout)
+        P, K, Cs = layout.num_prototypes, layout.num_classes, layout.channels_per_scale
+        need_x, need_bank, need_head = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        have_l, have_d, have_a = ctx.have
+        gl = g_logits.contiguous().float() if (have_l and g_logits is not None) else None
+        gd = g_dist.contiguous().float() if (have_d and g_dist is not None) else None
+        ga = g_act.contiguous().float() if (have_a and g_act is not None) else None
+        if packs.bankT is None:
+            raise SpxError("backward requested but the forward ran without gradient packs")
+        pp = C.byref(plan)
+        dev = x.device
+        xd = _x_dtype_code(x)
+        HWp = (HW + 7) & ~7
+        rows = lib.spx_gpad_rows(pp)
+        need_head = need_head and gl is not None
+        dx = torch.empty_like(x) if need_x else None
+        g_scr = torch.empty((rows, B * HWp), dtype=torch.bfloat16, device=dev) if need_bank else None
+        a_scr = torch.empty((rows, B * HWp), dtype=torch.bfloat16, device=dev) if need_head else None
+        s = _lib.stream_ptr()
+        _lib.check(
+            lib.spx_dist_bwd(
+                pp, _lib.ptr(x), xd, B, HW, _lib.ptr(packs.bank), _lib.ptr(packs.bankT), _lib.ptr(packs.p2),
+                _lib.ptr(packs.headT) if gl is not None else None, _lib.ptr(gd), _lib.ptr(ga), _lib.ptr(gl),
+                _lib.ptr(dx), _lib.ptr(g_scr), _lib.ptr(a_scr), ctx.epsilon, ACT_FN[ctx.act_fn], s,
+            )
+        )
+        d_bank = d_head = None
+        if need_bank or need_head:
+            ws = torch.empty(lib.spx_bank_bwd_workspace_bytes(pp, B, HW) // 4, dtype=torch.float32, device=dev)
+            d_bank = torch.empty((P, Cs), dtype=torch.float32, device=dev) if need_bank else None
+            d_head = torch.empty((K, P), dtype=torch.float32, device=dev) if need_head else None
+            _lib.check(
+                lib.spx_bank_bwd(
+                    pp, _lib.ptr(x), xd, B, HW, _lib.ptr(bank2d), _lib.ptr(g_scr), _lib.ptr(a_scr), _lib.ptr(gl),
+                    _lib.ptr(d_bank), _lib.ptr(d_head), _lib.ptr(ws), s,
+                )
+            )
+            if d_bank is not None:
+                d_bank = d_bank.reshape(ctx.bank_shape)
+        elif ctx.needs_input_grad[2] and head2d is not None:
+            d_head = torch.zeros_like(head2d)
+        if ctx.needs_input_grad[2] and d_head is None and head2d is not None:
+            d_head = torch.zeros_like(head2d)
+        return dx, d_bank, d_head, None, None, None, None, None
+
+
+def proto_head_forward(
+    x: torch.Tensor,
+    bank: torch.Tensor,
+    head: Optional[torch.Tensor],
+    layout: BankLayout,
+    *,
+    want_distances: bool = True,
+    want_activations: bool = False,
+    epsilon: float = 1e-4,
+    activation: str = "log",
+):
+    """(logits [B*H*W, K] | None, distances [B,P,H,W] | None, activations [B*H*W, P] | None)."""
+    if activation not in ACT_FN:
+        raise SpxError(f"activation {activation!r} has no fused kernel (use 'log' or 'linear')")
+    if not x.is_cuda:
+        raise SpxError("scaleprotoseg_amd runs on an AMD GPU only; there is no CPU fallback")
+    logits, dist, act = _ProtoHeadFn.apply(x, bank, head, layout, want_distances, want_activations, epsilon, activation)
+    return (
+        logits if head is not None else None,
+        dist if want_distances else None,
+        act if want_activations else None,
+    )
+
+
+def push_masked_argmin(
+    distances: torch.Tensor,
+    labels: torch.Tensor,
+    class_identity: torch.Tensor,
+    *,
+    void_class: Optional[int] = 0,
+    max_dist: float = 1e10,
+) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(indices int64 [B,P], values f32 [B,P]); push_multiscale_optimization.py:74-91 on the GPU."""
+    lib = _lib.load()
+    if distances.dim() != 4:
+        raise SpxError("distances must be [B, P, H, W]")
+    B, P, H, W = distances.shape
+    K = class_identity.shape[1]
+    if tuple(labels.shape) != (B, H, W):
+        raise SpxError(f"labels must be [{B}, {H}, {W}], got {tuple(labels.shape)}")
+    d = distances.detach().contiguous().float()
+    lab = labels.to(device=d.device, dtype=torch.int32).contiguous()
+    ident = class_identity.to(device=d.device, dtype=torch.float32).contiguous()
+    idx = torch.empty((B, P), dtype=torch.int64, device=d.device)
+    val = torch.empty((B, P), dtype=torch.float32, device=d.device)
+    scratch = torch.empty((B * P,), dtype=torch.int64, device=d.device)
+    _lib.check(
+        lib.spx_push_argmin(
+            _lib.ptr(d), _lib.ptr(lab), _lib.ptr(ident), B, P, K, H * W, -1 if void_class is None else int(void_class),
+            float(max_dist), _lib.ptr(idx), _lib.ptr(val), _lib.ptr(scratch), _lib.stream_ptr(),
+        )
+    )
+    return idx, val
+
+
+def argmin_over_images(values: torch.Tensor) -> torch.Tensor:
+    """tot_dist.argmin(dim=0) with lowest-image tie-break; push_multiscale_optimization.py:135-137."""
+    lib = _lib.load()
+    v = values.detach().contiguous().float()
+    N, P = v.shape
+    best = torch.empty((P,), dtype=torch.int64, device=v.device)
+    _lib.check(lib.spx_argmin_images(_lib.ptr(v), N, P, _lib.ptr(best), _lib.stream_ptr()))
+    return best

@@ -1,0 +1,268 @@
+"""Drop-in ``PPNetMultiScale`` (prototype phase) on the MI355X kernels.
+
+Mirrors the public surface of the reference class
+(segmentation/model/model_multiscale.py:71-477: constructor, properties,
+``forward`` / ``forward_from_conv_features`` / ``push_forward`` / ``prune_prototypes``,
+``state_dict`` keys ``prototype_vectors``, ``ones``, ``last_layer.weight``,
+``features.*``) while the distance -> similarity -> head chain runs in one HIP
+kernel (scaleprotoseg_amd.functional).  There is no CPU path: tensors must live
+on an AMD GPU when the distance methods are called.
+"""
+from __future__ import annotations
+
+from typing import Any, Dict, List, Optional, Tuple, Union
+
+import torch
+import torch.nn as nn
+
+from .functional import BankLayout, SpxError, proto_head_forward
+
+
+def _first_add_on_channels(features: nn.Module) -> int:
+    """Backbone output width, by the reference's name dispatch (model_multiscale.py:153-171)."""
+    name = str(features).upper()
+    convs = lambda m: [i for i in m.modules() if isinstance(i, nn.Conv2d)]
+    if name.startswith("VGG") or name.startswith("RES"):
+        return convs(features)[-1].out_channels
+    if name.startswith("DENSE"):
+        return [i for i in features.modules() if isinstance(i, nn.BatchNorm2d)][-1].num_features
+    if name.startswith("DEEPLAB"):
+        return convs(features)[-2].out_channels
+    if name.startswith("MSC"):
+        return convs(features.base)[-2].out_channels
+    raise Exception(f"{name[:10]} base_architecture NOT implemented")
+
+
+def _build_add_on(kind: str, in_ch: int, proto_ch: int, bottleneck_stride: Optional[int]) -> nn.Sequential:
+    """Add-on stack between backbone and prototype layer (model_multiscale.py:173-218)."""
+    if kind == "deeplab_simple":
+        return nn.Sequential(nn.Sigmoid())
+    layers: List[nn.Module] = []
+    if kind == "bottleneck_pool":
+        layers += [nn.Conv2d(in_ch, in_ch, kernel_size=3, padding=1, stride=bottleneck_stride), nn.ReLU()]
+    if kind.startswith("bottleneck"):
+        cur = in_ch
+        while cur > proto_ch or len(layers) == 0:
+            out = max(proto_ch, cur // 2)
+            layers += [nn.Conv2d(cur, out, kernel_size=1), nn.ReLU(), nn.Conv2d(out, out, kernel_size=1)]
+            if out > proto_ch:
+                layers.append(nn.ReLU())
+            else:
+                assert out == proto_ch
+                layers.append(nn.Sigmoid())
+            cur = cur // 2
+        return nn.Sequential(*layers)
+    return nn.Sequential(
+        nn.Conv2d(in_ch, proto_ch, kernel_size=1), nn.ReLU(), nn.Conv2d(proto_ch, proto_ch, kernel_size=1), nn.Sigmoid()
+    )
+
+
+class _PrototypeBankMixin:
+    """State and helpers shared by the prototype-phase and group-phase modules."""
+
+    def _init_bank(self, prototype_shape, num_classes: int, num_scales: int):
+        self.epsilon = 1e-4  # model_multiscale.py:106
+        self.num_scales = num_scales
+        self.prototype_vectors = nn.Parameter(torch.rand(prototype_shape), requires_grad=True)  # :111
+        P = self.prototype_vectors.shape[0]
+        # one-hot prototype -> class table, scale-major / class-minor blocks (:129-141)
+        self.prototype_class_identity = torch.zeros(P, num_classes)
+        per_scale = P // num_scales
+        per_cs = P // num_classes // num_scales
+        for s in range(num_scales):
+            for k in range(num_classes):
+                self.prototype_class_identity[s * per_scale + k * per_cs : s * per_scale + (k + 1) * per_cs, k] = 1
+        self.scale_num_prototypes: Dict[int, Tuple[int, int]] = {
+            s: (s * per_scale, (s + 1) * per_scale) for s in range(num_scales)
+        }  # :146-149
+        # kept for state_dict parity only: the kernels never read it (|x|^2 is computed from the staged tile)
+        self.ones = nn.Parameter(torch.ones(prototype_shape), requires_grad=False)  # :222
+
+    @property
+    def prototype_shape(self):
+        return self.prototype_vectors.shape
+
+    @property
+    def num_prototypes(self) -> int:
+        return self.prototype_vectors.shape[0]
+
+    @property
+    def num_classes(self) -> int:
+        return self.prototype_class_identity.shape[1]
+
+    def _layout(self, head_rows: int) -> BankLayout:
+        cs = int(self.prototype_vectors.shape[1]) * int(self.prototype_vectors.shape[2]) * int(self.prototype_vectors.shape[3])
+        return BankLayout(
+            num_prototypes=self.num_prototypes,
+            num_classes=head_rows,
+            num_scales=self.num_scales,
+            channels_per_scale=cs,
+            scale_ranges=tuple(tuple(int(v) for v in self.scale_num_prototypes[s]) for s in range(self.num_scales)),
+        )
+
+    def _check_fusable(self):
+        if getattr(self, "scale_head", None) is not None:
+            raise SpxError("scale_head aggregation has no fused kernel (every reference config sets scale_head_type=None)")
+        if self.prototype_vectors.shape[2] != 1 or self.prototype_vectors.shape[3] != 1:
+            raise SpxError("only 1x1 prototypes are supported (all reference configs)")
+
+    # -- reference methods on the distance path ---------------------------------------------------
+    def conv_features(self, x):
+        """features -> add_on_layers, list-aware for MSC training inputs (model_multiscale.py:246-253)."""
+        x = self.features(x)
+        if isinstance(x, list):
+            return [self.add_on_layers(xs) for xs in x]
+        return self.add_on_layers(x)
+
+    def _scale_l2_convolution(self, x: torch.Tensor) -> torch.Tensor:
+        """[B,S*Cs,H,W] -> distances [B,P,H,W] (model_multiscale.py:283-317), one HIP launch."""
+        self._check_fusable()
+        _, d, _ = proto_head_forward(
+            x, self.prototype_vectors, None, self._layout(1), want_distances=True, epsilon=self.epsilon,
+            activation="linear",
+        )
+        return d
+
+    def prototype_distances(self, x: torch.Tensor) -> torch.Tensor:
+        return self._scale_l2_convolution(self.conv_features(x))  # :319-322
+
+    def distance_2_similarity(self, distances: torch.Tensor) -> torch.Tensor:
+        """Stand-alone similarity for callers outside the fused path (model_multiscale.py:324-330)."""
+        if self.prototype_activation_function == "log":
+            return torch.log((distances + 1) / (distances + self.epsilon))
+        if self.prototype_activation_function == "linear":
+            return -distances
+        return self.prototype_activation_function(distances)
+
+    def push_forward(self, x):
+        """(conv_features, distances) for the push (model_multiscale.py:390-398)."""
+        conv = self.conv_features(x)
+        if isinstance(conv, list):
+            return [(c, self._scale_l2_convolution(c)) for c in conv]
+        return conv, self._scale_l2_convolution(conv)
+
+    def forward(self, x, **kwargs):
+        conv = self.conv_features(x)
+        if isinstance(conv, list):  # MSC
+            return [self.forward_from_conv_features(c, **kwargs) for c in conv]
+        return self.forward_from_conv_features(conv, **kwargs)
+
+
+class PPNetMultiScale(_PrototypeBankMixin, nn.Module):
+    def __init__(
+        self,
+        features: nn.Module,
+        img_size: int,
+        prototype_shape: Tuple[int, int, int, int],
+        proto_layer_rf_info: List[float],
+        num_classes: int,
+        init_weights: bool = True,
+        prototype_activation_function: str = "log",
+        add_on_layers_type: str = "bottleneck",
+        bottleneck_stride: Optional[int] = None,
+        patch_classification: bool = False,
+        num_scales: int = 4,
+        scale_head_type: Optional[str] = None,
+    ):
+        super().__init__()
+        self.img_size = img_size
+        self.bottleneck_stride = bottleneck_stride
+        self.patch_classification = patch_classification
+        if scale_head_type is not None:
+            raise SpxError("scale_head_type is not supported: no reference config uses it (SURVEY.md §2 #5)")
+        self.scale_head = None
+        self.prototype_activation_function = prototype_activation_function
+        self._init_bank(prototype_shape, num_classes, num_scales)
+        self.proto_layer_rf_info = proto_layer_rf_info
+        self.features = features
+        in_ch = _first_add_on_channels(features)
+        self.add_on_layers = _build_add_on(add_on_layers_type, in_ch, self.prototype_shape[1], bottleneck_stride)
+        self.last_layer = nn.Linear(self.num_prototypes, self.num_classes, bias=False)  # :225
+        if init_weights:
+            self._initialize_weights()
+
+    def run_last_layer(self, prototype_activations: torch.Tensor) -> torch.Tensor:
+        return self.last_layer(prototype_activations)  # :243-244 (callers outside the fused path)
+
+    def forward_from_conv_features(
+        self, conv_features, return_activations: bool = False, return_distances: bool = False
+    ) -> Any:
+        """Same return-tuple rules as model_multiscale.py:340-388."""
+        if isinstance(conv_features, list):
+            return [self.forward_from_conv_features(c) for c in conv_features]  # flags dropped, as in :359
+        if not (hasattr(self, "patch_classification") and self.patch_classification):
+            raise Exception("Original Prototype Network Implementation")
+        self._check_fusable()
+        if callable(self.prototype_activation_function):
+            raise SpxError("callable prototype_activation_function has no fused kernel")
+        B, _, H, W = conv_features.shape
+        want_dist = return_distances or not return_activations
+        logits, dist, act = proto_head_forward(
+            conv_features, self.prototype_vectors, self.last_layer.weight, self._layout(self.num_classes),
+            want_distances=want_dist, want_activations=return_activations, epsilon=self.epsilon,
+            activation=self.prototype_activation_function,
+        )
+        logits = logits.reshape(B, H, W, -1)
+        if return_activations and not return_distances:
+            return logits, act
+        if return_activations and return_distances:
+            return logits, dist, act
+        return logits, dist
+
+    def prune_prototypes(self, prototypes_to_prune: List[int]):
+        """Drop prototype rows and re-pack the scale table (model_multiscale.py:400-432)."""
+        drop = set(int(i) for i in prototypes_to_prune)
+        keep = sorted(set(range(self.num_prototypes)) - drop)
+        prev_hi = 0
+        for s in range(self.num_scales):
+            lo, hi = self.scale_num_prototypes[s]
+            n = len(set(range(lo, hi)) - drop)
+            self.scale_num_prototypes[s] = (prev_hi, prev_hi + n)
+            prev_hi += n
+        self.prototype_vectors = nn.Parameter(self.prototype_vectors.data[keep, ...], requires_grad=True)
+        self.last_layer.in_features = self.num_prototypes
+        self.last_layer.out_features = self.num_classes
+        self.last_layer.weight.data = self.last_layer.weight.data[:, keep]
+        self.ones = nn.Parameter(self.ones.data[keep, ...], requires_grad=False)
+        self.prototype_class_identity = self.prototype_class_identity[keep, :]
+
+    def set_last_layer_incorrect_connection(self, incorrect_strength: float):
+        """+1 own class / incorrect_strength elsewhere (model_multiscale.py:449-464)."""
+        pos = torch.t(self.prototype_class_identity).to(self.last_layer.weight.device)
+        self.last_layer.weight.data.copy_(1 * pos + incorrect_strength * (1 - pos))
+
+    def _initialize_weights(self):
+        for m in self.add_on_layers.modules():  # :466-476
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+        self.set_last_layer_incorrect_connection(incorrect_strength=-0.5)
+
+    def __repr__(self):
+        return (
+            "PPNet(\n\tfeatures: {},\n\timg_size: {},\n\tprototype_shape: {},\n\tproto_layer_rf_info: {},\n"
+            "\tnum_classes: {},\n\tepsilon: {}\n)"
+        ).format(self.features, self.img_size, self.prototype_shape, self.proto_layer_rf_info, self.num_classes, self.epsilon)
+
+
+def construct_PPNet(
+    features: nn.Module,
+    img_size: int = 224,
+    prototype_shape: Tuple[int, int, int, int] = (2000, 512, 1, 1),
+    num_classes: int = 200,
+    prototype_activation_function: str = "log",
+    add_on_layers_type: str = "bottleneck",
+    scale_head_type: Optional[str] = None,
+    **kwargs,
+) -> PPNetMultiScale:
+    """Factory with the reference's argument meaning (model_multiscale.py:480-515); the backbone is passed
+    in as a module because the reference's backbone zoo (absent submodule, URL downloads) is out of scope."""
+    return PPNetMultiScale(
+        features=features, img_size=img_size, prototype_shape=prototype_shape, proto_layer_rf_info=[],
+        num_classes=num_classes, init_weights=True, prototype_activation_function=prototype_activation_function,
+        add_on_layers_type=add_on_layers_type, scale_head_type=scale_head_type, **kwargs,
+    )

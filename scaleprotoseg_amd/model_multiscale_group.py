@@ -1,0 +1,194 @@
+"""Drop-in group-phase ``PPNetMultiScale`` (ScaleProtoSeg phase 2) on the MI355X kernels.
+
+Mirrors segmentation/model/model_multiscale_group.py:82-519: same constructor, ``group_projection``
+(ModuleList of bias-free Linear(n_k -> G)), ``last_layer_group``, ``group_class_identity``,
+``compute_group`` (returns a list), ``state_dict`` keys (no ``last_layer``), simplex initialisation.
+
+Fused form of the grouping head: every class's projection is a row block of ONE dense [G*K', P] matrix
+(zeros outside the class's prototype columns), so ``cat_k(act[:, idx_k] @ W_k^T)`` is the kernel's head
+contraction act @ Wd^T; ``exp`` and the small ``last_layer_group`` product follow on the GPU.  The
+reference instead gathers per class with a host sync per class per forward (:297-301).
+"""
+from __future__ import annotations
+
+import os
+from typing import Any, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .functional import SpxError, proto_head_forward
+from .model_multiscale import _PrototypeBankMixin, _build_add_on, _first_add_on_channels
+from .utils import projection_simplex_sort
+
+
+class PPNetMultiScaleGroup(_PrototypeBankMixin, nn.Module):
+    def __init__(
+        self,
+        features: nn.Module,
+        img_size: int,
+        prototype_shape: Tuple[int, int, int, int],
+        proto_layer_rf_info: List[float],
+        num_classes: int,
+        init_weights: bool = True,
+        prototype_activation_function: str = "log",
+        add_on_layers_type: str = "bottleneck",
+        bottleneck_stride: Optional[int] = None,
+        patch_classification: bool = False,
+        num_scales: int = 4,
+        scale_head_type: Optional[str] = None,
+        num_groups: int = 3,
+        incorrect_strength: float = -0.5,
+        equiv_path: Optional[os.PathLike] = None,
+        equiv_scale_weight: float = 0.25,
+    ):
+        super().__init__()
+        self.img_size = img_size
+        self.bottleneck_stride = bottleneck_stride
+        self.patch_classification = patch_classification
+        self.num_groups = num_groups
+        self.incorrect_strength = incorrect_strength
+        if scale_head_type is not None:
+            raise SpxError("scale_head_type is not supported: no reference config uses it")
+        if equiv_path is not None:
+            raise SpxError("equiv_path initialisation is deprecated in the reference (NOT USED) and not built")
+        self.scale_head = None
+        self.prototype_activation_function = prototype_activation_function
+        self._init_bank(prototype_shape, num_classes, num_scales)
+        self.proto_layer_rf_info = proto_layer_rf_info
+        self.features = features
+        in_ch = _first_add_on_channels(features)
+        self.add_on_layers = _build_add_on(add_on_layers_type, in_ch, self.prototype_shape[1], bottleneck_stride)
+        self._group_index_cache = None
+        self._initialize_groups()
+        if init_weights:
+            self._initialize_weights()
+
+    # ---- group bookkeeping ------------------------------------------------------------------------
+    def _present_classes(self) -> List[int]:
+        ident = self.prototype_class_identity
+        return [k for k in range(self.num_classes) if int(ident[:, k].sum().item()) > 0]
+
+    def _initialize_groups(self):
+        """group_projection / group_class_identity / last_layer_group (model_multiscale_group.py:249-269)."""
+        ident = self.prototype_class_identity
+        present = self._present_classes()
+        self.group_projection = nn.ModuleList(
+            [nn.Linear(int(ident[:, k].sum().item()), self.num_groups, bias=False) for k in present]
+        )
+        n_groups = self.num_groups * len(present)
+        self.group_class_identity = torch.zeros(n_groups, self.num_classes)
+        for j, k in enumerate(present):
+            self.group_class_identity[j * self.num_groups : (j + 1) * self.num_groups, k] = 1
+        self.last_layer_group = nn.Linear(n_groups, self.num_classes, bias=False)
+        self._group_index_cache = None
+
+    def _group_index(self, device):
+        """(rows, cols) of every group-projection weight inside the dense [NG, P] head matrix."""
+        ident = self.prototype_class_identity
+        key = (id(ident), tuple(ident.shape), tuple(gp.weight.shape for gp in self.group_projection), str(device))
+        if self._group_index_cache is not None and self._group_index_cache[0] == key:
+            return self._group_index_cache[1]
+        rows, cols, r0 = [], [], 0
+        for j, k in enumerate(self._present_classes()):
+            idx = torch.nonzero(ident[:, k]).flatten()
+            g = self.group_projection[j].weight.shape[0]
+            rr = torch.arange(r0, r0 + g).repeat_interleave(idx.numel())
+            cc = idx.repeat(g)
+            rows.append(rr)
+            cols.append(cc)
+            r0 += g
+        out = (torch.cat(rows).to(device), torch.cat(cols).to(device), r0)
+        self._group_index_cache = (key, out)
+        return out
+
+    def _dense_group_matrix(self) -> torch.Tensor:
+        dev = self.prototype_vectors.device
+        rows, cols, ng = self._group_index(dev)
+        vals = torch.cat([gp.weight.reshape(-1) for gp in self.group_projection])
+        return torch.zeros(ng, self.num_prototypes, device=dev, dtype=vals.dtype).index_put((rows, cols), vals)
+
+    def compute_group(self, prototype_activations: torch.Tensor) -> List[torch.Tensor]:
+        """List of per-class group activations exp(act[:, idx_k] @ W_k^T) (model_multiscale_group.py:283-303).
+        Stand-alone form for callers (the KLD-group loss); the forward uses the fused dense product."""
+        ident = self.prototype_class_identity
+        outs = []
+        for j, k in enumerate(self._present_classes()):
+            idx = torch.nonzero(ident[:, k]).flatten().to(prototype_activations.device)
+            outs.append(torch.exp(self.group_projection[j](prototype_activations[:, idx])))
+        return outs
+
+    def run_last_layer(self, prototype_activations: torch.Tensor) -> torch.Tensor:
+        return self.last_layer_group(torch.cat(self.compute_group(prototype_activations), dim=-1))  # :305-308
+
+    # ---- forward ------------------------------------------------------------------------------------
+    def forward_from_conv_features(
+        self, conv_features, return_activations: bool = False, return_distances: bool = False
+    ) -> Any:
+        """Same return-tuple rules as model_multiscale_group.py:404-452."""
+        if isinstance(conv_features, list):
+            return [self.forward_from_conv_features(c) for c in conv_features]
+        if not (hasattr(self, "patch_classification") and self.patch_classification):
+            raise Exception("Original Prototype Network Implementation")
+        self._check_fusable()
+        if callable(self.prototype_activation_function):
+            raise SpxError("callable prototype_activation_function has no fused kernel")
+        B, _, H, W = conv_features.shape
+        wd = self._dense_group_matrix()
+        want_dist = return_distances or not return_activations
+        gpre, dist, act = proto_head_forward(
+            conv_features, self.prototype_vectors, wd, self._layout(wd.shape[0]),
+            want_distances=want_dist, want_activations=return_activations, epsilon=self.epsilon,
+            activation=self.prototype_activation_function,
+        )
+        logits = F.linear(torch.exp(gpre), self.last_layer_group.weight).reshape(B, H, W, -1)
+        if return_activations and not return_distances:
+            return logits, act
+        if return_activations and return_distances:
+            return logits, dist, act
+        return logits, dist
+
+    # ---- init ---------------------------------------------------------------------------------------
+    def set_last_layer_incorrect_connection(self):
+        pos = torch.t(self.group_class_identity).to(self.last_layer_group.weight.device)  # :480-491
+        self.last_layer_group.weight.data.copy_(1 * pos + self.incorrect_strength * (1 - pos))
+
+    def _initialize_weights(self, equiv_path=None, equiv_scale_weight: float = 0.25):
+        for m in self.add_on_layers.modules():  # :493-519
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+        if equiv_path is not None:
+            raise SpxError("equiv_path initialisation is deprecated in the reference (NOT USED) and not built")
+        for gp in self.group_projection:
+            gp.weight.data = projection_simplex_sort(gp.weight.data)
+        self.set_last_layer_incorrect_connection()
+
+    def __repr__(self):
+        return (
+            "PPNet(\n\tfeatures: {},\n\timg_size: {},\n\tprototype_shape: {},\n\tproto_layer_rf_info: {},\n"
+            "\tnum_classes: {},\n\tepsilon: {}\n)"
+        ).format(self.features, self.img_size, self.prototype_shape, self.proto_layer_rf_info, self.num_classes, self.epsilon)
+
+
+def construct_PPNet_Group(
+    features: nn.Module,
+    img_size: int = 224,
+    prototype_shape: Tuple[int, int, int, int] = (2000, 512, 1, 1),
+    num_classes: int = 200,
+    prototype_activation_function: str = "log",
+    add_on_layers_type: str = "bottleneck",
+    scale_head_type: Optional[str] = None,
+    **kwargs,
+) -> PPNetMultiScaleGroup:
+    """Factory with the reference's argument meaning (model_multiscale_group.py:589-624)."""
+    return PPNetMultiScaleGroup(
+        features=features, img_size=img_size, prototype_shape=prototype_shape, proto_layer_rf_info=[],
+        num_classes=num_classes, init_weights=True, prototype_activation_function=prototype_activation_function,
+        add_on_layers_type=add_on_layers_type, scale_head_type=scale_head_type, **kwargs,
+    )

@@ -1,0 +1,289 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle and the golden fixtures.
+
+Stated tolerances (inputs are bf16-representable fp32, SURVEY.md 8d "identical inputs"):
+  distances   |d - d_ref| <= 1e-4 * (1 + d_ref)
+  activations |a - a_ref| <= 2e-4 * (1 + |a_ref|)
+  logits      |l - l_ref| <= 1e-4 * max(1, max|l_ref|)      (1e-4 relative, north star)
+  gradients   max|g - g_ref| <= 3e-3 * max|g_ref| for dX (fp32 X) and dPrototypes, 8e-3 for dX in bf16 and
+              for dLastLayer (G, the activations and dLogits enter the pixel-sum MFMAs as bf16: unbiased
+              2^-9 operand rounding, which does not average out on the random-sign test gradients)
+  push        indices bit-exact, values bit-exact given the same distance map
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ppnet_oracle as O
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    return torch.device("cuda:0")
+
+
+def _problem(B, S, Cs, P, K, H, W, seed=0, x_dtype=torch.float32):
+    g = torch.Generator().manual_seed(20220227 + seed)
+    conv = O.bf16_representable(torch.sigmoid(torch.randn(B, S * Cs, H, W, generator=g)))
+    bank = O.bf16_representable(torch.rand(P, Cs, 1, 1, generator=g))
+    ident = O.default_class_identity(P, K, S)
+    Wl = O.last_layer_init(ident) + 0.05 * torch.randn(K, P, generator=g)
+    return conv, bank, Wl, ident, O.default_scale_ranges(P, S)
+
+
+def _layout(P, K, S, Cs, ranges):
+    from scaleprotoseg_amd.functional import BankLayout
+
+    return BankLayout(P, K, S, Cs, tuple(ranges[s] for s in range(S)))
+
+
+def _assert_fwd(logits, dist, act, ref_logits, ref_dist, ref_act):
+    if dist is not None:
+        err = (dist.cpu() - ref_dist).abs()
+        assert (err <= 1e-4 * (1 + ref_dist)).all(), f"distance err {err.max().item()}"
+    if act is not None:
+        err = (act.cpu() - ref_act).abs()
+        assert (err <= 2e-4 * (1 + ref_act.abs())).all(), f"activation err {err.max().item()}"
+    if logits is not None:
+        rl = ref_logits.reshape(-1, ref_logits.shape[-1])
+        err = (logits.cpu().reshape(rl.shape) - rl).abs().max().item()
+        assert err <= 1e-4 * max(1.0, rl.abs().max().item()), f"logit err {err}"
+
+
+SHAPES = [
+    # B, S, Cs,  P,   K,  H,  W
+    (2, 4, 64, 228, 19, 17, 19),     # Cityscapes ScaleProtoSeg bank, odd grid (scalar-load path)
+    (1, 1, 256, 190, 19, 16, 64),    # north-star bank, 16-B aligned rows (vector-load path)
+    (1, 1, 64, 210, 21, 13, 11),     # Pascal baseline bank (2 panels of 105)
+    (2, 4, 64, 252, 21, 8, 16),      # Pascal ScaleProtoSeg
+    (1, 3, 64, 171, 19, 9, 16),      # 3-scale variant
+    (1, 2, 16, 16, 3, 5, 7),         # Cs = 16 (kc = 16), floor semantics (unassigned prototypes)
+    (1, 4, 64, 1800, 150, 9, 8),     # ADE bank: 3 panels per scale, 5 class blocks
+    (1, 1, 64, 1500, 150, 6, 8),     # ADE literal 150 x 10
+]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("x_dtype", [torch.float32, torch.bfloat16])
+def test_forward_matches_oracle(shape, x_dtype):
+    from scaleprotoseg_amd.functional import proto_head_forward
+
+    dev = _dev()
+    B, S, Cs, P, K, H, W = shape
+    conv, bank, Wl, ident, ranges = _problem(*shape)
+    ref_logits, ref_dist, ref_act = O.forward_from_conv_features(conv, bank, ranges, S, Wl)
+    logits, dist, act = proto_head_forward(
+        conv.to(dev, x_dtype), bank.to(dev), Wl.to(dev), _layout(P, K, S, Cs, ranges),
+        want_distances=True, want_activations=True,
+    )
+    torch.cuda.synchronize()
+    assert dist.shape == (B, P, H, W) and act.shape == (B * H * W, P) and logits.shape == (B * H * W, K)
+    _assert_fwd(logits, dist, act, ref_logits, ref_dist, ref_act)
+
+
+@pytest.mark.parametrize("name", ["proto_ms_city", "proto_s1_wide", "proto_s3", "proto_floor", "proto_ms_small"])
+def test_forward_matches_golden(golden, name):
+    """Fixtures generated from the reference's own classes (oracle/gen_golden.py)."""
+    from scaleprotoseg_amd.functional import proto_head_forward
+
+    dev = _dev()
+    g = golden(name)
+    S = int(g["num_scales"])
+    conv = torch.from_numpy(g["conv"])
+    bank = torch.from_numpy(g["prototype_vectors"])
+    Wl = torch.from_numpy(g["last_layer_weight"])
+    P, Cs = bank.shape[0], bank.shape[1]
+    ranges = {s: (int(lo), int(hi)) for s, (lo, hi) in enumerate(g["scale_ranges"])}
+    logits, dist, act = proto_head_forward(
+        conv.to(dev), bank.to(dev), Wl.to(dev), _layout(P, Wl.shape[0], S, Cs, ranges),
+        want_distances=True, want_activations=True,
+    )
+    _assert_fwd(logits, dist, act, torch.from_numpy(g["logits"]), torch.from_numpy(g["distances"]),
+                torch.from_numpy(g["activations"]))
+
+
+def _grad_close(got, ref, what, tol=3e-3):
+    got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
+    scale = ref.abs().max().item() + 1e-30
+    err = (got - ref).abs().max().item()
+    assert err <= tol * scale, f"{what}: err {err:.3e} vs scale {scale:.3e}"
+
+
+BWD_SHAPES = [
+    (2, 4, 64, 228, 19, 17, 19),
+    (1, 1, 256, 190, 19, 16, 64),
+    (1, 1, 64, 210, 21, 13, 11),
+    (1, 2, 16, 16, 3, 5, 7),
+    (1, 4, 64, 1800, 150, 5, 8),
+]
+
+
+@pytest.mark.parametrize("shape", BWD_SHAPES)
+@pytest.mark.parametrize("x_dtype", [torch.float32, torch.bfloat16])
+def test_backward_matches_oracle(shape, x_dtype):
+    from scaleprotoseg_amd.functional import proto_head_forward
+
+    dev = _dev()
+    B, S, Cs, P, K, H, W = shape
+    conv, bank, Wl, ident, ranges = _problem(*shape, seed=1)
+    g = torch.Generator().manual_seed(7)
+    g_logits = torch.randn(B, H, W, K, generator=g) * 1e-3
+    g_dist = torch.randn(B, P, H, W, generator=g) * 1e-3
+    g_act = torch.randn(B * H * W, P, generator=g) * 1e-3
+    _, _, _, dx_ref, dp_ref, dw_ref = O.fwd_bwd_reference(conv, bank, ranges, S, Wl, g_logits, g_dist, g_act)
+
+    x = conv.to(dev, x_dtype).requires_grad_(True)
+    pv = bank.to(dev).requires_grad_(True)
+    w = Wl.to(dev).requires_grad_(True)
+    logits, dist, act = proto_head_forward(x, pv, w, _layout(P, K, S, Cs, ranges), want_distances=True, want_activations=True)
+    loss = (logits * g_logits.reshape(-1, K).to(dev)).sum() + (dist * g_dist.to(dev)).sum() + (act * g_act.to(dev)).sum()
+    loss.backward()
+    torch.cuda.synchronize()
+    assert x.grad.dtype == x_dtype and x.grad.shape == x.shape
+    _grad_close(x.grad, dx_ref, "dX", tol=3e-3 if x_dtype == torch.float32 else 8e-3)
+    _grad_close(pv.grad, dp_ref, "dPrototypes")
+    _grad_close(w.grad, dw_ref, "dLastLayer", tol=8e-3)
+
+
+@pytest.mark.parametrize("name", ["proto_ms_city", "proto_s1_wide"])
+def test_backward_matches_golden(golden, name):
+    from scaleprotoseg_amd.functional import proto_head_forward
+
+    dev = _dev()
+    g = golden(name)
+    S = int(g["num_scales"])
+    bank = torch.from_numpy(g["prototype_vectors"])
+    Wl = torch.from_numpy(g["last_layer_weight"])
+    P, Cs, K = bank.shape[0], bank.shape[1], Wl.shape[0]
+    ranges = {s: (int(lo), int(hi)) for s, (lo, hi) in enumerate(g["scale_ranges"])}
+    x = torch.from_numpy(g["conv"]).to(dev).requires_grad_(True)
+    pv = bank.to(dev).requires_grad_(True)
+    w = Wl.to(dev).requires_grad_(True)
+    logits, dist, act = proto_head_forward(x, pv, w, _layout(P, K, S, Cs, ranges), want_distances=True, want_activations=True)
+    loss = (
+        (logits * torch.from_numpy(g["g_logits"]).reshape(-1, K).to(dev)).sum()
+        + (dist * torch.from_numpy(g["g_dist"]).to(dev)).sum()
+        + (act * torch.from_numpy(g["g_act"]).to(dev)).sum()
+    )
+    loss.backward()
+    _grad_close(x.grad, torch.from_numpy(g["d_conv"]), "dX")
+    _grad_close(pv.grad, torch.from_numpy(g["d_prototypes"]), "dPrototypes")
+    _grad_close(w.grad, torch.from_numpy(g["d_last_layer"]), "dLastLayer", tol=8e-3)
+
+
+def test_backward_partial_inputs():
+    """Only logits consumed, bank frozen: dX and dW still flow; distances-only: dX and dP flow."""
+    from scaleprotoseg_amd.functional import proto_head_forward
+
+    dev = _dev()
+    shape = (1, 4, 64, 228, 19, 9, 16)
+    B, S, Cs, P, K, H, W = shape
+    conv, bank, Wl, ident, ranges = _problem(*shape, seed=2)
+    g = torch.Generator().manual_seed(3)
+    g_logits = torch.randn(B, H, W, K, generator=g) * 1e-3
+    zeros_d = torch.zeros(B, P, H, W)
+    _, _, _, dx_ref, dp_ref, dw_ref = O.fwd_bwd_reference(conv, bank, ranges, S, Wl, g_logits, zeros_d)
+    x = conv.to(dev).requires_grad_(True)
+    w = Wl.to(dev).requires_grad_(True)
+    logits, dist, _ = proto_head_forward(x, bank.to(dev), w, _layout(P, K, S, Cs, ranges))
+    (logits * g_logits.reshape(-1, K).to(dev)).sum().backward()
+    _grad_close(x.grad, dx_ref, "dX (logits only)")
+    _grad_close(w.grad, dw_ref, "dW (logits only)", tol=8e-3)
+
+    g_dist = torch.randn(B, P, H, W, generator=g) * 1e-3
+    _, _, _, dx_ref, dp_ref, _ = O.fwd_bwd_reference(conv, bank, ranges, S, Wl, torch.zeros(B, H, W, K), g_dist)
+    x = conv.to(dev).requires_grad_(True)
+    pv = bank.to(dev).requires_grad_(True)
+    _, dist, _ = proto_head_forward(x, pv, None, _layout(P, 1, S, Cs, ranges))
+    (dist * g_dist.to(dev)).sum().backward()
+    _grad_close(x.grad, dx_ref, "dX (distances only)")
+    _grad_close(pv.grad, dp_ref, "dP (distances only)")
+
+
+def test_push_argmin_golden(golden):
+    from scaleprotoseg_amd.functional import push_masked_argmin
+
+    dev = _dev()
+    g = golden("push_argmin")
+    idx, val = push_masked_argmin(
+        torch.from_numpy(g["distances"]).to(dev), torch.from_numpy(g["target"])[None].to(dev),
+        torch.from_numpy(g["class_identity"]), void_class=0,
+    )
+    np.testing.assert_array_equal(idx.cpu().numpy(), g["indices"])
+    np.testing.assert_array_equal(val.cpu().numpy(), g["values"])
+
+
+@pytest.mark.parametrize("hw", [(129, 257), (65, 65), (96, 512)])
+def test_push_argmin_random(hw):
+    """Bit-exact indices incl. absent classes, exact ties and multi-chunk rows."""
+    from scaleprotoseg_amd.functional import push_masked_argmin
+
+    dev = _dev()
+    H, W = hw
+    B, K, S, r = 2, 19, 4, 3
+    P = K * S * r
+    g = torch.Generator().manual_seed(11)
+    dist = torch.rand(B, P, H, W, generator=g) * 50
+    # coarse quantisation -> many exact ties; lowest flat index must win
+    dist[:, ::3] = torch.floor(dist[:, ::3] * 4) / 4
+    target = torch.randint(0, K + 1, (B, H, W), generator=g)
+    target[target == 5] = 1       # class 4 absent everywhere
+    target[1][target[1] == 9] = 0  # class 8 absent in image 1
+    ident = O.default_class_identity(P, K, S)
+    ref_idx, ref_val = O.push_masked_argmin(dist, target, ident, K, void_class=0)
+    idx, val = push_masked_argmin(dist.to(dev), target.to(dev), ident, void_class=0)
+    np.testing.assert_array_equal(idx.cpu().numpy(), ref_idx.numpy())
+    np.testing.assert_array_equal(val.cpu().numpy(), ref_val.numpy())
+    assert (ref_val == 1e10).any()
+
+
+def test_argmin_over_images():
+    from scaleprotoseg_amd.functional import argmin_over_images
+
+    dev = _dev()
+    g = torch.Generator().manual_seed(5)
+    vals = torch.floor(torch.rand(37, 228, generator=g) * 8)  # ties -> lowest image index
+    best = argmin_over_images(vals.to(dev))
+    np.testing.assert_array_equal(best.cpu().numpy(), vals.argmin(dim=0).numpy())
+
+
+def test_prototype_equal_to_pixel():
+    """After a push a prototype IS a latent pixel: its distance there must be ~0 and win the argmin."""
+    from scaleprotoseg_amd.functional import proto_head_forward, push_masked_argmin
+
+    dev = _dev()
+    shape = (1, 4, 64, 228, 19, 12, 16)
+    B, S, Cs, P, K, H, W = shape
+    conv, bank, Wl, ident, ranges = _problem(*shape, seed=4)
+    cv = conv.view(S, Cs, H, W)
+    for p in range(0, P, 7):
+        s = p // (P // S)
+        bank[p, :, 0, 0] = cv[s, :, (p * 5) % H, (p * 3) % W]
+    _, dist, _ = proto_head_forward(conv.to(dev), bank.to(dev), None, _layout(P, 1, S, Cs, ranges))
+    for p in range(0, P, 7):
+        assert dist[0, p, (p * 5) % H, (p * 3) % W].item() <= 1e-4
+    ref = O.scale_l2_convolution(conv, bank, ranges, S)
+    assert ((dist.cpu() - ref).abs() <= 1e-4 * (1 + ref)).all()
+
+
+def test_large_shape_properties():
+    """North-star bank at a multi-megapixel grid: tile-independent properties instead of a CPU reference.
+    (a) a pixel's outputs do not depend on where it sits in the grid, (b) logits are linear in the head."""
+    from scaleprotoseg_amd.functional import proto_head_forward
+
+    dev = _dev()
+    S, Cs, P, K = 1, 256, 190, 19
+    H, W = 256, 512
+    conv, bank, Wl, ident, ranges = _problem(1, S, Cs, P, K, 8, 16, seed=6)
+    small = conv.to(dev, torch.bfloat16)
+    big = small.repeat(1, 1, H // 8, W // 16).contiguous()
+    lay = _layout(P, K, S, Cs, ranges)
+    l_s, d_s, _ = proto_head_forward(small, bank.to(dev), Wl.to(dev), lay)
+    l_b, d_b, _ = proto_head_forward(big, bank.to(dev), Wl.to(dev), lay)
+    torch.cuda.synchronize()
+    assert torch.equal(d_b, d_s.repeat(1, 1, H // 8, W // 16))
+    assert torch.equal(l_b.view(H, W, K), l_s.view(8, 16, K).repeat(H // 8, W // 16, 1))
+    l2, _, _ = proto_head_forward(big, bank.to(dev), (2 * Wl).to(dev), lay)
+    assert torch.allclose(l2, 2 * l_b, rtol=1e-5, atol=1e-5)
