@@ -1,0 +1,239 @@
+#!/usr/bin/env python3
+"""Benchmark of the prototype-distance hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = forward (logits + the fp32 distance map, the reference's forward contract) + backward
+(incoming dLogits and dDistances -> dX, dPrototypes, dLastLayer) of ONE synthetic Cityscapes-shaped image per
+GPU (1024x2048 latent pixels x 256 channels, 190 prototypes, 19 classes, bf16 features), followed — for
+N > 1 — by one RCCL all-reduce of the flat gradient bucket.  Inputs are resident in HBM before the timed
+region.  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (C, P, S, K, H, W)   latent grid H x W per image, one image per GPU
+    "cityscapes_1024x2048_c256_p190_s1": (256, 190, 1, 19, 1024, 2048),   # north-star shape (SURVEY.md 8d primary)
+    "cityscapes_native_129x257_p228_s4": (256, 228, 4, 19, 129, 257),     # scaleproto_cityscapes.gin full image
+}
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
+MFMA_BF16_PEAK_TFLOPS = 2500.0
+
+
+def algorithmic_bytes_per_px(C, P, K):
+    """bf16 X, fp32 distances + logits, distances materialised."""
+    fwd = 2 * C + 4 * P + 4 * K
+    bwd = 4 * P + 4 * K + 2 * C + 2 * C
+    return fwd, bwd
+
+
+def cpu_baseline(C, P, S, K, sample_hw, reps=3):
+    """The oracle (CPU restatement of the reference op sequence) timed on this host's cores."""
+    from oracle import ppnet_oracle as O
+
+    H, W = sample_hw
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    g = torch.Generator().manual_seed(20220227)
+    conv = O.bf16_representable(torch.sigmoid(torch.randn(1, C, H, W, generator=g)))
+    bank = O.bf16_representable(torch.rand(P, C // S, 1, 1, generator=g))
+    ident = O.default_class_identity(P, K, S)
+    Wl = O.last_layer_init(ident)
+    gl = torch.randn(1, H, W, K, generator=g) * 1e-3
+    gd = torch.randn(1, P, H, W, generator=g) * 1e-3
+    ranges = O.default_scale_ranges(P, S)
+    O.fwd_bwd_reference(conv, bank, ranges, S, Wl, gl, gd)  # warm-up
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        O.fwd_bwd_reference(conv, bank, ranges, S, Wl, gl, gd)
+    dt = (time.perf_counter() - t0) / reps
+    return {
+        "value": round(H * W / dt / 1e6, 4),
+        "unit": "Mpix/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"oracle fwd+bwd, 1x{C}x{H}x{W} latent px slice of the workload, P={P}, S={S}, fp32, "
+                  f"{reps} reps after 1 warm-up, {dt:.2f} s/rep, torch {torch.__version__} CPU",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="cityscapes_1024x2048_c256_p190_s1", choices=sorted(WORKLOADS))
+    ap.add_argument("--x-dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    import scaleprotoseg_amd as spx
+    from scaleprotoseg_amd import functional as F_
+    from scaleprotoseg_amd.dp import FlatGradBucket
+
+    spx.load_library()
+    C, P, S, K, H, W = WORKLOADS[args.workload]
+    Cs = C // S
+    xdt = torch.bfloat16 if args.x_dtype == "bf16" else torch.float32
+
+    # ---- synthetic inputs, resident in HBM (SURVEY.md 8d "Synthetic inputs") ----
+    g = torch.Generator(device=dev).manual_seed(20220227 + rank)
+    x = torch.sigmoid(torch.randn(1, C, H, W, device=dev, generator=g)).to(xdt).requires_grad_(True)
+    per_scale = P // S
+    layout = spx.BankLayout(P, K, S, Cs, tuple((s * per_scale, (s + 1) * per_scale) for s in range(S)))
+    gp = torch.Generator(device=dev).manual_seed(20220227)           # identical parameters on every rank
+    bank = torch.rand(P, Cs, 1, 1, device=dev, generator=gp).to(torch.bfloat16).float().requires_grad_(True)
+    ident = torch.zeros(P, K, device=dev)
+    per_cs = P // K // S
+    for s in range(S):
+        for k in range(K):
+            ident[s * per_scale + k * per_cs : s * per_scale + (k + 1) * per_cs, k] = 1
+    head = (ident.t() - 0.5 * (1 - ident.t())).contiguous().requires_grad_(True)
+    g_logits = torch.randn(H * W, K, device=dev, generator=g) * 1e-3
+    g_dist = torch.randn(1, P, H, W, device=dev, generator=g) * 1e-3
+    bucket = FlatGradBucket([bank, head])
+
+    def step():
+        x.grad = None
+        bank.grad = None
+        head.grad = None
+        logits, dmap, _ = spx.proto_head_forward(x, bank, head, layout, want_distances=True)
+        torch.autograd.backward([logits, dmap], [g_logits, g_dist])
+        if world > 1:
+            bucket.all_reduce()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    prof = []
+    fence()
+    F_.set_profile(prof)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    F_.set_profile(None)
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- per-operator durations from the HIP events of the timed steps ----
+    per_op = {}
+    for name, e0, e1 in prof:
+        per_op.setdefault(name, []).append(e0.elapsed_time(e1))
+    op_ms = {k: sum(v) / len(v) for k, v in per_op.items()}
+    M = H * W
+    fwd_b, bwd_b = algorithmic_bytes_per_px(C, P, K)
+    nb = P * Cs  # sum_s Cs * Ps
+    op_bytes = {"spx_dist_fwd": fwd_b * M, "spx_dist_bwd": bwd_b * M, "spx_bank_bwd": 0}
+    op_flops = {"spx_dist_fwd": 2 * nb * M, "spx_dist_bwd": 2 * nb * M, "spx_bank_bwd": 2 * nb * M}
+    dominant = max(op_ms, key=op_ms.get) if op_ms else None
+    kernels = {
+        k: {
+            "ms": round(v, 4),
+            "algorithmic_GBs": round(op_bytes.get(k, 0) / (v * 1e-3) / 1e9, 1),
+            "algorithmic_TFLOPs": round(op_flops.get(k, 0) / (v * 1e-3) / 1e12, 1),
+        }
+        for k, v in op_ms.items()
+    }
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = world * M / (elapsed / args.steps) / 1e6
+        out = {
+            "metric": "Mpix/s fwd+bwd prototype-distance, Cityscapes 1024x2048",
+            "value": round(value, 2),
+            "unit": "Mpix/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "bf16" if args.x_dtype == "bf16" else "fp32->bf16",
+            "data": "synthetic",
+            "config": {
+                "workload": args.workload,
+                "latent_px_per_gpu": M,
+                "channels": C,
+                "prototypes": P,
+                "scales": S,
+                "classes": K,
+                "features_dtype": args.x_dtype,
+                "outputs": "logits + fp32 distance map (reference forward contract); grads dX, dPrototypes, dLastLayer",
+                "parallelism": f"dp{world}" if world > 1 else "single",
+            },
+            "kernels": kernels,
+        }
+        if dominant is not None:
+            dom_ms = op_ms[dominant]
+            # algorithmic bytes of the operator (for the backward: of the whole backward, charged to its pixel-side
+            # kernel; the parameter-side reduction moves no algorithmic bytes, its time shows in roofline_step)
+            ach = op_bytes[dominant] / (dom_ms * 1e-3) / 1e9 if op_bytes.get(dominant) else (fwd_b + bwd_b) * M / (dom_ms * 1e-3) / 1e9
+            out["roofline"] = {
+                "kernel": dominant,
+                "bound": "hbm",
+                "achieved": round(ach, 1),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(ach / HBM_PEAK_GBS, 4),
+                "traffic": None,
+            }
+            step_gbs = (fwd_b + bwd_b) * M / (ms_per_step * 1e-3) / 1e9
+            out["roofline_step"] = {
+                "bound": "hbm",
+                "achieved": round(step_gbs, 1),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(step_gbs / HBM_PEAK_GBS, 4),
+                "mfma_frac": round(6 * nb * M / (ms_per_step * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+                "algorithmic_bytes_per_px": fwd_b + bwd_b,
+                "algorithmic_flop_per_px": 6 * nb,
+            }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(C, P, S, K, (128, W) if H >= 128 else (H, W))
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,116 @@
+"""Data-parallel layer for the prototype path: one process per GPU, RCCL over xGMI.
+
+The reference is single-GPU; this is new capability:
+  * training: the image batch is sharded over ranks, every rank runs the fused forward/backward on its
+    own images, and the (tiny: 0.08-1.6 MB) parameter gradients are summed with ONE all-reduce of a flat
+    fp32 bucket per optimizer step — the exchange is latency-bound, so one message, not one per tensor;
+  * push: the image list is cut into contiguous ranges, each rank reduces its range on the GPU, and one
+    all-gather of (value, image, flat index) per prototype is followed by a local lexicographic minimum
+    that keeps the reference's tie-break (lowest image index, push_multiscale_optimization.py:137).
+Backend: "nccl" (= RCCL on ROCm) for GPU tensors; the same code runs over "gloo" on CPU tensors, which is
+how tests/test_dp_gloo.py covers the world_size > 1 logic without a GPU.
+"""
+from __future__ import annotations
+
+from typing import Iterable, List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_items: int, rank: int, world_size: int) -> range:
+    """Contiguous, balanced shard of ``range(n_items)`` for ``rank``."""
+    base, rem = divmod(n_items, world_size)
+    start = rank * base + min(rank, rem)
+    return range(start, start + base + (1 if rank < rem else 0))
+
+
+class FlatGradBucket:
+    """One flat fp32 buffer holding the gradients of a fixed parameter list."""
+
+    def __init__(self, params: Sequence[torch.nn.Parameter]):
+        self.params = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("FlatGradBucket needs at least one trainable parameter")
+        self.sizes = [p.numel() for p in self.params]
+        dev = self.params[0].device
+        self.flat = torch.zeros(sum(self.sizes), dtype=torch.float32, device=dev)
+        self.views = []
+        off = 0
+        for p, n in zip(self.params, self.sizes):
+            self.views.append(self.flat[off : off + n].view_as(p))
+            off += n
+
+    def gather(self):
+        for p, v in zip(self.params, self.views):
+            if p.grad is None:
+                v.zero_()
+            else:
+                v.copy_(p.grad)
+
+    def scatter(self):
+        for p, v in zip(self.params, self.views):
+            if p.grad is None:
+                p.grad = v.clone()
+            else:
+                p.grad.copy_(v)
+
+    def all_reduce(self, group=None, average: bool = False):
+        """Sum (or mean) the bucket over the ranks with one collective and write the grads back."""
+        self.gather()
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+            if average:
+                self.flat.div_(dist.get_world_size(group))
+        self.scatter()
+
+
+def allreduce_gradients(params: Iterable[torch.nn.Parameter], group=None, average: bool = False) -> FlatGradBucket:
+    bucket = FlatGradBucket(list(params))
+    bucket.all_reduce(group=group, average=average)
+    return bucket
+
+
+def reduce_push_candidates(
+    local_best_img: torch.Tensor,
+    local_values: torch.Tensor,
+    local_flat_idx: torch.Tensor,
+    image_offset: int,
+    group=None,
+) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """Combine per-rank push winners into the global ones.
+
+    local_best_img [P] (position inside this rank's shard), local_values [P] (its masked minimum),
+    local_flat_idx [P] (its flat latent index).  Returns (global image index [P] int64, value [P] f32,
+    flat index [P] int64), identical on every rank.  Lexicographic minimum on (value, global image index):
+    because shards are contiguous ranges, this equals the single-process ``argmin`` over all images."""
+    gimg = local_best_img.to(torch.int64) + int(image_offset)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return gimg, local_values, local_flat_idx.to(torch.int64)
+    world = dist.get_world_size(group)
+    # pack to one int64 triple per prototype so a single all_gather moves everything (values via bit cast)
+    vbits = local_values.to(torch.float32).contiguous().view(torch.int32).to(torch.int64)
+    payload = torch.stack([vbits, gimg, local_flat_idx.to(torch.int64)], dim=0).contiguous()
+    gathered = [torch.empty_like(payload) for _ in range(world)]
+    dist.all_gather(gathered, payload, group=group)
+    allp = torch.stack(gathered, dim=0)                      # [world, 3, P]
+    vals = allp[:, 0].to(torch.int32).view(torch.float32)    # [world, P]
+    imgs = allp[:, 1]
+    flats = allp[:, 2]
+    # ranks hold increasing image ranges, so the first rank attaining the minimum value holds the lowest image
+    vmin = vals.min(dim=0).values
+    is_min = vals == vmin[None]
+    big = torch.iinfo(torch.int64).max
+    cand_img = torch.where(is_min, imgs, torch.full_like(imgs, big))
+    win_rank = cand_img.argmin(dim=0)
+    ar = torch.arange(vals.shape[1], device=vals.device)
+    return imgs[win_rank, ar], vals[win_rank, ar], flats[win_rank, ar]
+
+
+def gather_push_patches(local_patches: torch.Tensor, owner_mask: torch.Tensor, group=None) -> torch.Tensor:
+    """[P, Cs] feature vectors: each rank fills the rows it owns (owner_mask), zeros elsewhere; a sum
+    all-reduce assembles the full bank (exact: every row has exactly one non-zero contributor)."""
+    out = torch.where(owner_mask[:, None], local_patches, torch.zeros_like(local_patches)).contiguous()
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(out, op=dist.ReduceOp.SUM, group=group)
+    return out

@@ -19,6 +19,33 @@ from ._lib import SpxError, SpxPlan
 
 ACT_FN = {"log": 0, "linear": 1}
 
+# Optional per-operator timing used by bench.py: when a list is installed here, every C-ABI operator call is
+# bracketed by HIP events recorded on the stream the kernel is launched on (torch's current stream).
+_PROFILE: Optional[list] = None
+
+
+def set_profile(sink: Optional[list]) -> None:
+    global _PROFILE
+    _PROFILE = sink
+
+
+class _timed:
+    def __init__(self, name: str):
+        self.name = name
+
+    def __enter__(self):
+        if _PROFILE is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if _PROFILE is not None:
+            self.e1.record()
+            _PROFILE.append((self.name, self.e0, self.e1))
+        return False
+
 
 @dataclass
 class BankLayout:
@@ -97,12 +124,14 @@ class _ProtoHeadFn(torch.autograd.Function):
         dist = torch.empty((B, P) + tuple(x.shape[2:]), **f32) if want_dist else None
         act = torch.empty((B * HW, P), **f32) if want_act else None
         logits = torch.empty((B * HW, K), **f32) if head is not None else None
-        _lib.check(
-            lib.spx_dist_fwd(
-                C.byref(plan), _lib.ptr(x), xd, B, HW, _lib.ptr(packs.bank), _lib.ptr(packs.p2), _lib.ptr(packs.head),
-                _lib.ptr(dist), _lib.ptr(act), _lib.ptr(logits), float(epsilon), ACT_FN[act_fn], _lib.stream_ptr(),
+        with _timed("spx_dist_fwd"):
+            _lib.check(
+                lib.spx_dist_fwd(
+                    C.byref(plan), _lib.ptr(x), xd, B, HW, _lib.ptr(packs.bank), _lib.ptr(packs.p2),
+                    _lib.ptr(packs.head), _lib.ptr(dist), _lib.ptr(act), _lib.ptr(logits), float(epsilon),
+                    ACT_FN[act_fn], _lib.stream_ptr(),
+                )
             )
-        )
         ctx.layout, ctx.plan, ctx.packs = layout, plan, packs
         ctx.epsilon, ctx.act_fn = float(epsilon), act_fn
         ctx.have = (logits is not None, dist is not None, act is not None)
@@ -136,24 +165,26 @@ class _ProtoHeadFn(torch.autograd.Function):
         g_scr = torch.empty((rows, B * HWp), dtype=torch.bfloat16, device=dev) if need_bank else None
         a_scr = torch.empty((rows, B * HWp), dtype=torch.bfloat16, device=dev) if need_head else None
         s = _lib.stream_ptr()
-        _lib.check(
-            lib.spx_dist_bwd(
-                pp, _lib.ptr(x), xd, B, HW, _lib.ptr(packs.bank), _lib.ptr(packs.bankT), _lib.ptr(packs.p2),
-                _lib.ptr(packs.headT) if gl is not None else None, _lib.ptr(gd), _lib.ptr(ga), _lib.ptr(gl),
-                _lib.ptr(dx), _lib.ptr(g_scr), _lib.ptr(a_scr), ctx.epsilon, ACT_FN[ctx.act_fn], s,
+        with _timed("spx_dist_bwd"):
+            _lib.check(
+                lib.spx_dist_bwd(
+                    pp, _lib.ptr(x), xd, B, HW, _lib.ptr(packs.bank), _lib.ptr(packs.bankT), _lib.ptr(packs.p2),
+                    _lib.ptr(packs.headT) if gl is not None else None, _lib.ptr(gd), _lib.ptr(ga), _lib.ptr(gl),
+                    _lib.ptr(dx), _lib.ptr(g_scr), _lib.ptr(a_scr), ctx.epsilon, ACT_FN[ctx.act_fn], s,
+                )
             )
-        )
         d_bank = d_head = None
         if need_bank or need_head:
             ws = torch.empty(lib.spx_bank_bwd_workspace_bytes(pp, B, HW) // 4, dtype=torch.float32, device=dev)
             d_bank = torch.empty((P, Cs), dtype=torch.float32, device=dev) if need_bank else None
             d_head = torch.empty((K, P), dtype=torch.float32, device=dev) if need_head else None
-            _lib.check(
-                lib.spx_bank_bwd(
-                    pp, _lib.ptr(x), xd, B, HW, _lib.ptr(bank2d), _lib.ptr(g_scr), _lib.ptr(a_scr), _lib.ptr(gl),
-                    _lib.ptr(d_bank), _lib.ptr(d_head), _lib.ptr(ws), s,
+            with _timed("spx_bank_bwd"):
+                _lib.check(
+                    lib.spx_bank_bwd(
+                        pp, _lib.ptr(x), xd, B, HW, _lib.ptr(bank2d), _lib.ptr(g_scr), _lib.ptr(a_scr),
+                        _lib.ptr(gl), _lib.ptr(d_bank), _lib.ptr(d_head), _lib.ptr(ws), s,
+                    )
                 )
-            )
             if d_bank is not None:
                 d_bank = d_bank.reshape(ctx.bank_shape)
         elif ctx.needs_input_grad[2] and head2d is not None:
