@@ -46,7 +46,11 @@ def cpu_baseline(C, P, S, K, sample_hw, reps=3):
     from oracle import ppnet_oracle as O
 
     H, W = sample_hw
-    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, int(os.environ.get("SPX_CPU_THREADS", "16"))))   # a 1-GPU box has a 16-core share
     torch.set_num_threads(cores)
     g = torch.Generator().manual_seed(20220227)
     conv = O.bf16_representable(torch.sigmoid(torch.randn(1, C, H, W, generator=g)))

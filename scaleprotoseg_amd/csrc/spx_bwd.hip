@@ -17,11 +17,15 @@
 #include "spx_args.h"
 #include "spx_mainloop.h"
 
+#ifndef SPX_BWD_WAVES
+#define SPX_BWD_WAVES 1
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // kernel 1: pixel side
 // ------------------------------------------------------------------------------------------------
 template <int NPB, int NCB, int NCHB, bool XF32>
-__global__ __launch_bounds__(256, 2) void spx_bwd_kernel(const SpxBwdArgs a) {
+__global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const spx_plan& pl = a.plan;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -34,38 +38,50 @@ __global__ __launch_bounds__(256, 2) void spx_bwd_kernel(const SpxBwdArgs a) {
     const int P = pl.num_prototypes, K = pl.num_classes;
     const int nchb = (Cs + 31) / 32;
     const int ncstep = pl.ncb * 2;
+    const uint32_t HW = (uint32_t)a.HW;
     const size_t Mp = (size_t)a.B * a.HWp;
+    constexpr int ESZ = XF32 ? 4 : 2;
 
-    SpxTileCtx tc;
-    tc.x = (const char*)a.x + (size_t)b * C * a.HW * (XF32 ? 4 : 2);
-    tc.hw = a.HW;
-    tc.px0 = px0;
-    tc.vec_ok = a.vec_ok;
+    const char* x_img = (const char*)a.x + (size_t)b * C * a.HW * ESZ;
+    const SpxTileCtx tc = SpxStager<NPB, XF32>::make_ctx(x_img, a.packed_bank, a.HW, px0, a.vec_ok, tid);
 
     const int stage = spx_stage_bytes(pl.kc, pl.npb);
     const int xs_bytes = pl.kc * SPX_XROW * 2;
     const int nchunks = Cs / pl.kc;
     const int nks = pl.kc >> 4;
-    const int chunk_bytes = pl.npb * nks * 1024;
+    const uint32_t chunk_bytes = (uint32_t)(pl.npb * nks * 1024);
     const int total = pl.npanels * nchunks;
 
     const int px = px0 + 32 * wave + r;
     const bool px_ok = px < a.HW;
     const bool px_pad_ok = px < a.HWp;
+    // per-lane byte offsets (fixed for the kernel); row/block selection rides on wave-uniform SGPR offsets
+    const uint32_t voff_d = ((uint32_t)(4 * h) * HW + (uint32_t)px) * 4u;             // [row][px] fp32 maps
+    const uint32_t voff_a = ((uint32_t)px * (uint32_t)P + (uint32_t)(4 * h)) * 4u;    // dAct [px][row]
+    const uint32_t voff_x = ((uint32_t)(4 * h) * HW + (uint32_t)px) * ESZ;            // X / dX [ch][px]
+    const uint32_t voff_g = (uint32_t)(((size_t)(4 * h) * Mp + (size_t)b * a.HWp + px) * 2);   // G/a scratch rows
+    const spx_rsrc htr = make_rsrc(a.packed_headT);
+    const spx_rsrc btr = make_rsrc(a.packed_bankT);
+    const spx_rsrc xir = make_rsrc(x_img);
+    const spx_rsrc dxr = make_rsrc(a.dx ? (char*)a.dx + (size_t)b * C * a.HW * ESZ : nullptr);
 
     // dLogits of this lane's pixel as split-bf16 B fragments: element j of k-step c <-> class 16c + 8h + j
     bf16x8 dlhi[NCB * 2], dllo[NCB * 2];
+    {
+        const spx_rsrc lr = make_rsrc(a.d_logits ? a.d_logits + (size_t)b * a.HW * K : nullptr);
+        const uint32_t voff_l = ((uint32_t)px * (uint32_t)K + (uint32_t)(8 * h)) * 4u;
 #pragma unroll
-    for (int c = 0; c < NCB * 2; ++c) {
+        for (int c = 0; c < NCB * 2; ++c) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float v = 0.0f;
-            const int cls = c * 16 + 8 * h + j;
-            if (a.d_logits && px_ok && c < ncstep && cls < K) v = a.d_logits[((size_t)b * a.HW + px) * K + cls];
-            __bf16 hi, lo;
-            split_bf16(v, hi, lo);
-            dlhi[c][j] = hi;
-            dllo[c][j] = lo;
+            for (int j = 0; j < 8; ++j) {
+                float v = 0.0f;
+                const int cls = c * 16 + 8 * h + j;
+                if (a.d_logits && px_ok && c < ncstep && cls < K) v = buf_load_f32(lr, voff_l, (uint32_t)((c * 16 + j) * 4));
+                __bf16 hi, lo;
+                split_bf16(v, hi, lo);
+                dlhi[c][j] = hi;
+                dllo[c][j] = lo;
+            }
         }
     }
 
@@ -73,7 +89,7 @@ __global__ __launch_bounds__(256, 2) void spx_bwd_kernel(const SpxBwdArgs a) {
     f32x16 acc[NPB];
     float x2part = 0.0f;
 
-    st.load(tc, pl, a.packed_bank, pl.panel_ch0[0], tid);
+    st.load(tc, pl, 0u, pl.panel_ch0[0], tid);
     st.write(pl, smem, smem + xs_bytes, tid);
     __syncthreads();
 
@@ -90,7 +106,7 @@ __global__ __launch_bounds__(256, 2) void spx_bwd_kernel(const SpxBwdArgs a) {
         const bool more = step + 1 < total;
         if (more) {
             const int np_ = (step + 1) / nchunks, nc_ = (step + 1) - np_ * nchunks;
-            st.load(tc, pl, a.packed_bank + (size_t)(step + 1) * chunk_bytes, pl.panel_ch0[np_] + nc_ * pl.kc, tid);
+            st.load(tc, pl, (uint32_t)(step + 1) * chunk_bytes, pl.panel_ch0[np_] + nc_ * pl.kc, tid);
         }
         char* cur = smem + buf * stage;
         spx_compute_chunk<NPB>(acc, x2part, pl, cur, cur + xs_bytes, lane, wave);
@@ -106,7 +122,7 @@ __global__ __launch_bounds__(256, 2) void spx_bwd_kernel(const SpxBwdArgs a) {
         const float x2 = x2part + __shfl_xor(x2part, 32);
         const int p0 = pl.panel_p0[panel], np = pl.panel_np[panel];
         const int ch0 = pl.panel_ch0[panel];
-        const float* p2p = a.p2 + panel * pl.npb * 32;
+        const spx_rsrc p2r = make_rsrc(a.p2 + panel * pl.npb * 32);
         bf16x8 gpk[NPB][2];
         float rs = 0.0f;
 #pragma unroll
@@ -115,6 +131,9 @@ __global__ __launch_bounds__(256, 2) void spx_bwd_kernel(const SpxBwdArgs a) {
             for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) gpk[pb][s2][j] = (__bf16)0.0f;
+            const size_t grow = (size_t)panel * pl.npb * 32 + pb * 32;
+            const spx_rsrc gr = make_rsrc(a.g_out ? a.g_out + grow * Mp : nullptr);
+            const spx_rsrc ar = make_rsrc(a.a_out ? a.a_out + grow * Mp : nullptr);
             if (pb < pl.npb && pb * 32 < np) {
                 f32x16 ga;
 #pragma unroll
@@ -123,26 +142,27 @@ __global__ __launch_bounds__(256, 2) void spx_bwd_kernel(const SpxBwdArgs a) {
 #pragma unroll
                     for (int c = 0; c < NCB * 2; ++c) {
                         if (c < ncstep) {
-                            const char* wf = a.packed_headT + (((size_t)panel * pl.npb + pb) * ncstep + c) * 2048 + lane * 16;
-                            const bf16x8 whi = *(const bf16x8*)wf;
-                            const bf16x8 wlo = *(const bf16x8*)(wf + 1024);
+                            const uint32_t so = (uint32_t)(((panel * pl.npb + pb) * ncstep + c) * 2048);
+                            const bf16x8 whi = __builtin_bit_cast(bf16x8, buf_load_b128(htr, (uint32_t)lane * 16u, so));
+                            const bf16x8 wlo = __builtin_bit_cast(bf16x8, buf_load_b128(htr, (uint32_t)lane * 16u, so + 1024u));
                             ga = mfma_bf16(whi, dlhi[c], ga);
                             ga = mfma_bf16(wlo, dlhi[c], ga);
                             ga = mfma_bf16(whi, dllo[c], ga);
                         }
                     }
                 }
+                const spx_rsrc ddr = make_rsrc(a.d_dist ? a.d_dist + ((size_t)b * P + p0 + pb * 32) * a.HW : nullptr);
+                const spx_rsrc dar = make_rsrc(a.d_act ? a.d_act + (size_t)b * a.HW * P + p0 + pb * 32 : nullptr);
                 float gv[16];
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
-                    const int row0 = pb * 32 + 8 * g4 + 4 * h;
-                    const f32x4 p2v = *(const f32x4*)(p2p + row0);
+                    const int row0 = 8 * g4 + 4 * h;
+                    const u32x4 p2u = buf_load_b128(p2r, (uint32_t)(16 * h), (uint32_t)((pb * 32 + 8 * g4) * 4));
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int reg = 4 * g4 + e;
-                        const int pl_row = row0 + e;
-                        const bool valid = px_ok && pl_row < np;
-                        const float d_raw = __builtin_fmaf(-2.0f, acc[pb][reg], p2v[e]) + x2;
+                        const bool valid = px_ok && (pb * 32 + row0 + e < np);
+                        const float d_raw = __builtin_fmaf(-2.0f, acc[pb][reg], __uint_as_float(p2u[e])) + x2;
                         const float d = fmaxf(d_raw, 0.0f);
                         float dact;   // act'(d)
                         float aval;
@@ -156,16 +176,16 @@ __global__ __launch_bounds__(256, 2) void spx_bwd_kernel(const SpxBwdArgs a) {
                         float gtot = ga[reg];
                         float dd = 0.0f;
                         if (valid) {
-                            if (a.d_act) gtot += a.d_act[((size_t)b * a.HW + px) * P + p0 + pl_row];
-                            if (a.d_dist) dd = a.d_dist[((size_t)b * P + (p0 + pl_row)) * a.HW + px];
+                            if (a.d_act) gtot += buf_load_f32(dar, voff_a, (uint32_t)((8 * g4 + e) * 4));
+                            if (a.d_dist) dd = buf_load_f32(ddr, voff_d, (uint32_t)(8 * g4 + e) * HW * 4u);
                         }
                         const float G = (valid && d_raw > 0.0f) ? dd + gtot * dact : 0.0f;
                         rs += G;
                         gv[reg] = G;
                         if (px_pad_ok) {
-                            const size_t o = ((size_t)panel * pl.npb * 32 + pl_row) * Mp + (size_t)b * a.HWp + px;
-                            if (a.g_out) a.g_out[o] = __builtin_bit_cast(uint16_t, (__bf16)G);
-                            if (a.a_out) a.a_out[o] = __builtin_bit_cast(uint16_t, (__bf16)(valid ? aval : 0.0f));
+                            const uint32_t so = (uint32_t)((size_t)(8 * g4 + e) * Mp * 2);
+                            if (a.g_out) buf_store_u16(__builtin_bit_cast(uint16_t, (__bf16)G), gr, voff_g, so);
+                            if (a.a_out) buf_store_u16(__builtin_bit_cast(uint16_t, (__bf16)(valid ? aval : 0.0f)), ar, voff_g, so);
                         }
                     }
                 }
@@ -173,13 +193,14 @@ __global__ __launch_bounds__(256, 2) void spx_bwd_kernel(const SpxBwdArgs a) {
                 for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
                     for (int j = 0; j < 8; ++j) gpk[pb][s2][j] = (__bf16)gv[8 * s2 + j];
+                __builtin_amdgcn_sched_barrier(0);   // keep later blocks' loads out of this block (VGPR budget)
             } else if (pb < pl.npb && px_pad_ok) {
                 // wholly padded prototype block: kernel 2 still reads these rows -> keep them finite (zero)
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) {
-                    const size_t o = ((size_t)panel * pl.npb * 32 + pb * 32 + acc_row(reg, h)) * Mp + (size_t)b * a.HWp + px;
-                    if (a.g_out) a.g_out[o] = 0;
-                    if (a.a_out) a.a_out[o] = 0;
+                    const uint32_t so = (uint32_t)((size_t)((reg & 3) + 8 * (reg >> 2)) * Mp * 2);
+                    if (a.g_out) buf_store_u16(0, gr, voff_g, so);
+                    if (a.a_out) buf_store_u16(0, ar, voff_g, so);
                 }
             }
         }
@@ -188,52 +209,62 @@ __global__ __launch_bounds__(256, 2) void spx_bwd_kernel(const SpxBwdArgs a) {
         // ---------------- phase 2: dX^T[ch x px] = 2 (rs * x - P^T . G) ----------------
         const float rs_tot = rs + __shfl_xor(rs, 32);
         const bool first_of_scale = (panel == 0) || (pl.panel_ch0[panel - 1] != ch0);
-        f32x16 accx[NCHB];
+        __builtin_amdgcn_sched_barrier(0);
+        constexpr int CG = NCHB < 4 ? NCHB : 4;          // channel blocks per pass (<= 64 accumulator registers)
 #pragma unroll
-        for (int chb = 0; chb < NCHB; ++chb)
+        for (int cg = 0; cg < NCHB; cg += CG) {
+            if (cg >= nchb) break;
+            f32x16 accx[CG];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) accx[chb][i] = 0.0f;
+            for (int c = 0; c < CG; ++c)
 #pragma unroll
-        for (int pb = 0; pb < NPB; ++pb) {
-            if (pb < pl.npb && pb * 32 < np) {
+                for (int i = 0; i < 16; ++i) accx[c][i] = 0.0f;
 #pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
+            for (int pb = 0; pb < NPB; ++pb) {
+                if (pb < pl.npb && pb * 32 < np) {
 #pragma unroll
-                    for (int chb = 0; chb < NCHB; ++chb) {
-                        if (chb < nchb) {
-                            const char* pf = a.packed_bankT + ((((size_t)panel * pl.npb + pb) * 2 + s2) * nchb + chb) * 1024 + lane * 16;
-                            accx[chb] = mfma_bf16(*(const bf16x8*)pf, gpk[pb][s2], accx[chb]);
-                        }
-                    }
-                }
-            }
-        }
-        if (px_ok) {
+                    for (int s2 = 0; s2 < 2; ++s2) {
 #pragma unroll
-            for (int chb = 0; chb < NCHB; ++chb) {
-                if (chb < nchb) {
-#pragma unroll
-                    for (int reg = 0; reg < 16; ++reg) {
-                        const int ch = chb * 32 + acc_row(reg, h);
-                        if (ch < Cs) {
-                            const size_t o = ((size_t)b * C + ch0 + ch) * a.HW + px;
-                            float xv, prev = 0.0f;
-                            if (XF32) {
-                                xv = ((const float*)a.x)[o];
-                                if (!first_of_scale) prev = ((const float*)a.dx)[o];
-                            } else {
-                                xv = (float)__builtin_bit_cast(__bf16, ((const uint16_t*)a.x)[o]);
-                                if (!first_of_scale) prev = (float)__builtin_bit_cast(__bf16, ((const uint16_t*)a.dx)[o]);
+                        for (int c = 0; c < CG; ++c) {
+                            const int chb = cg + c;
+                            if (chb < nchb) {
+                                const uint32_t so = (uint32_t)(((((panel * pl.npb + pb) * 2 + s2) * nchb) + chb) * 1024);
+                                const bf16x8 pf = __builtin_bit_cast(bf16x8, buf_load_b128(btr, (uint32_t)lane * 16u, so));
+                                accx[c] = mfma_bf16(pf, gpk[pb][s2], accx[c]);
                             }
-                            const float v = prev + 2.0f * (rs_tot * xv - accx[chb][reg]);
-                            if (XF32)
-                                ((float*)a.dx)[o] = v;
-                            else
-                                ((uint16_t*)a.dx)[o] = __builtin_bit_cast(uint16_t, (__bf16)v);
                         }
                     }
                 }
             }
+            if (px_ok) {
+#pragma unroll
+                for (int c = 0; c < CG; ++c) {
+                    const int chb = cg + c;
+                    if (chb < nchb) {
+#pragma unroll
+                        for (int reg = 0; reg < 16; ++reg) {
+                            const int chl = chb * 32 + (reg & 3) + 8 * (reg >> 2);     // + 4h rides in voff_x
+                            if (chl + 4 * h < Cs) {
+                                const uint32_t so = (uint32_t)(ch0 + chl) * HW * ESZ;
+                                float xv, prev = 0.0f;
+                                if (XF32) {
+                                    xv = buf_load_f32(xir, voff_x, so);
+                                    if (!first_of_scale) prev = buf_load_f32(dxr, voff_x, so);
+                                } else {
+                                    xv = (float)__builtin_bit_cast(__bf16, buf_load_u16(xir, voff_x, so));
+                                    if (!first_of_scale) prev = (float)__builtin_bit_cast(__bf16, buf_load_u16(dxr, voff_x, so));
+                                }
+                                const float v = prev + 2.0f * (rs_tot * xv - accx[c][reg]);
+                                if (XF32)
+                                    buf_store_f32(v, dxr, voff_x, so);
+                                else
+                                    buf_store_u16(__builtin_bit_cast(uint16_t, (__bf16)v), dxr, voff_x, so);
+                            }
+                        }
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 }

@@ -20,6 +20,35 @@ typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
                                  // 320-B stride puts the 4 rows of a transposed read on disjoint banks)
 #define SPX_LDS_LIMIT (160 * 1024)
 
+// ---- buffer (SRSRC) addressing: one 32-bit per-lane offset + a wave-uniform SGPR offset per access.
+// The epilogues touch ~100 distinct rows per tile; with flat 64-bit pointers every one of them costs two
+// VGPRs of address and two VALU adds, which is what pushed these kernels into scratch.
+typedef __amdgpu_buffer_rsrc_t spx_rsrc;
+__device__ __forceinline__ spx_rsrc make_rsrc(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0xFFFFFFFFu, 0x00020000);
+}
+// Resource whose range check is used for predication: valid offsets stay below 2 GiB, a lane that must not
+// access memory passes SPX_OOB as its offset and the hardware drops the access (no exec-mask branches).
+#define SPX_OOB 0x80000000u
+__device__ __forceinline__ spx_rsrc make_rsrc_pred(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x80000000u, 0x00020000);
+}
+__device__ __forceinline__ float buf_load_f32(spx_rsrc r, uint32_t voff, uint32_t soff) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ void buf_store_f32(float v, spx_rsrc r, uint32_t voff, uint32_t soff) {
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, 0);
+}
+__device__ __forceinline__ uint16_t buf_load_u16(spx_rsrc r, uint32_t voff, uint32_t soff) {
+    return (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(r, voff, soff, 0);
+}
+__device__ __forceinline__ void buf_store_u16(uint16_t v, spx_rsrc r, uint32_t voff, uint32_t soff) {
+    __builtin_amdgcn_raw_buffer_store_b16((short)v, r, voff, soff, 0);
+}
+__device__ __forceinline__ u32x4 buf_load_b128(spx_rsrc r, uint32_t voff, uint32_t soff) {
+    return __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+}
+
 // Row of a 32x32 MFMA accumulator held in register `reg` of lane half `h`
 // (cdna guide §3: row = (reg&3) + 8*(reg>>2) + 4*(lane>>5), col = lane&31).
 __device__ __forceinline__ int acc_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
@@ -40,8 +69,13 @@ __device__ __forceinline__ s16x4 lds_tr_read(const char* p) {
 }
 
 __device__ __forceinline__ float act_log(float d, float eps) {
-    // log((d+1)/(d+eps)), segmentation/model/model_multiscale.py:326
-    return __logf(__fdividef(d + 1.0f, d + eps));
+    // log((d+1)/(d+eps)), segmentation/model/model_multiscale.py:326.  The ratio lies in [1, 1/eps], so the raw
+    // v_rcp_f32 / v_log_f32 (1 ulp each, no denormal fix-up code) are exact enough: 6 VALU per element.
+    return __builtin_amdgcn_logf((d + 1.0f) * __builtin_amdgcn_rcpf(d + eps)) * 0.69314718056f;
+}
+__device__ __forceinline__ float act_log_grad(float d, float eps) {
+    // d/dd log((d+1)/(d+eps)) = 1/(d+1) - 1/(d+eps) = -(1-eps) / ((d+1)(d+eps))
+    return -(1.0f - eps) * __builtin_amdgcn_rcpf((d + 1.0f) * (d + eps));
 }
 
 // monotone float -> uint32 key (total order incl. negatives), for packed (value,index) minima

@@ -18,9 +18,11 @@
 #include "spx_common.h"
 
 struct SpxTileCtx {
-    const char* x;        // features of image b, channel 0, pixel 0 (bytes)
-    int hw;               // pixels per image
-    int px0;              // first pixel of the tile
+    spx_rsrc xr;          // features of image b (buffer resource over channel 0, pixel 0)
+    spx_rsrc br;          // packed bank fragments
+    uint32_t x_voff;      // this thread's byte offset inside a 16-row pass: (row0 * HW + px) * esz
+    uint32_t hw;          // pixels per image
+    int px;               // first of this thread's 8 staged pixels
     int vec_ok;           // 16-B vector loads allowed (row starts 16-B aligned)
 };
 
@@ -28,42 +30,46 @@ template <int NPB, bool XF32>
 struct SpxStager {
     static constexpr int XPASS = 2;                 // kc <= 32 -> at most 2 row passes of 16
     static constexpr int APASS = (NPB * 2 + 3) / 4; // bank chunk <= NPB*2 KiB, 4 KiB per pass
+    static constexpr int ESZ = XF32 ? 4 : 2;
     u32x4 xr[XPASS][XF32 ? 2 : 1];
     u32x4 ar[APASS];
 
-    // issue the global loads of one step
-    __device__ __forceinline__ void load(const SpxTileCtx& t, const spx_plan& pl, const char* bank_chunk,
-                                         int ch_first, int tid) {
-        const int piece = tid & 15, row0 = tid >> 4;
-        const int px = t.px0 + piece * 8;
+    __device__ __forceinline__ static SpxTileCtx make_ctx(const void* x_img, const void* packed_bank, int hw, int px0,
+                                                         int vec_ok, int tid) {
+        SpxTileCtx t;
+        t.xr = make_rsrc(x_img);
+        t.br = make_rsrc(packed_bank);
+        t.hw = (uint32_t)hw;
+        t.px = px0 + (tid & 15) * 8;
+        t.x_voff = ((uint32_t)(tid >> 4) * (uint32_t)hw + (uint32_t)t.px) * ESZ;
+        t.vec_ok = vec_ok;
+        return t;
+    }
+
+    // issue the global loads of one step: X rows ch_first.., bank chunk at byte offset bank_off
+    __device__ __forceinline__ void load(const SpxTileCtx& t, const spx_plan& pl, uint32_t bank_off, int ch_first,
+                                         int tid) {
         const int npass = pl.kc >> 4;
+        const bool full = t.vec_ok && (uint32_t)(t.px + 8) <= t.hw;
 #pragma unroll
         for (int i = 0; i < XPASS; ++i) {
             if (i < npass) {
-                const size_t row = (size_t)(ch_first + row0 + 16 * i) * (size_t)t.hw;
-                if (XF32) {
-                    const float* src = (const float*)t.x + row + px;
-                    if (t.vec_ok && px + 8 <= t.hw) {
-                        xr[i][0] = *(const u32x4*)src;
-                        xr[i][1] = *(const u32x4*)(src + 4);
-                    } else {
+                const uint32_t soff = (uint32_t)(ch_first + 16 * i) * t.hw * ESZ;
+                if (full) {
+                    xr[i][0] = buf_load_b128(t.xr, t.x_voff, soff);
+                    if (XF32) xr[i][1] = buf_load_b128(t.xr, t.x_voff + 16, soff);
+                } else if (XF32) {
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            float v = (px + e < t.hw) ? src[e] : 0.0f;
-                            xr[i][e >> 2][e & 3] = __float_as_uint(v);
-                        }
+                    for (int e = 0; e < 8; ++e) {
+                        const bool ok = (uint32_t)(t.px + e) < t.hw;
+                        xr[i][e >> 2][e & 3] = ok ? __builtin_amdgcn_raw_buffer_load_b32(t.xr, t.x_voff + 4 * e, soff, 0) : 0u;
                     }
                 } else {
-                    const uint16_t* src = (const uint16_t*)t.x + row + px;
-                    if (t.vec_ok && px + 8 <= t.hw) {
-                        xr[i][0] = *(const u32x4*)src;
-                    } else {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            uint32_t lo = (px + 2 * e < t.hw) ? src[2 * e] : 0u;
-                            uint32_t hi = (px + 2 * e + 1 < t.hw) ? src[2 * e + 1] : 0u;
-                            xr[i][0][e] = lo | (hi << 16);
-                        }
+                    for (int e = 0; e < 4; ++e) {
+                        const uint32_t lo = ((uint32_t)(t.px + 2 * e) < t.hw) ? buf_load_u16(t.xr, t.x_voff + 4 * e, soff) : 0u;
+                        const uint32_t hi = ((uint32_t)(t.px + 2 * e + 1) < t.hw) ? buf_load_u16(t.xr, t.x_voff + 4 * e + 2, soff) : 0u;
+                        xr[i][0][e] = lo | (hi << 16);
                     }
                 }
             }
@@ -72,7 +78,7 @@ struct SpxStager {
 #pragma unroll
         for (int i = 0; i < APASS; ++i) {
             const int off = i * 4096 + tid * 16;
-            if (off < abytes) ar[i] = *(const u32x4*)(bank_chunk + off);
+            if (off < abytes) ar[i] = buf_load_b128(t.br, (uint32_t)off, bank_off);
         }
     }
 
