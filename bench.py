@@ -83,6 +83,8 @@ def main():
     ap.add_argument("--workload", default="cityscapes_1024x2048_c256_p190_s1", choices=sorted(WORKLOADS))
     ap.add_argument("--x-dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--grads", default="logits,dist", help="diagnostic only: which output gradients flow back")
+    ap.add_argument("--freeze", default="", help="diagnostic only: comma list of x,bank,head to exclude from the backward")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -124,14 +126,21 @@ def main():
     head = (ident.t() - 0.5 * (1 - ident.t())).contiguous().requires_grad_(True)
     g_logits = torch.randn(H * W, K, device=dev, generator=g) * 1e-3
     g_dist = torch.randn(1, P, H, W, device=dev, generator=g) * 1e-3
-    bucket = FlatGradBucket([bank, head])
+    for name in filter(None, args.freeze.split(",")):
+        {"x": x, "bank": bank, "head": head}[name].requires_grad_(False)
+    bucket = FlatGradBucket([p for p in (bank, head) if p.requires_grad] or [bank.requires_grad_(True)])
 
     def step():
         x.grad = None
         bank.grad = None
         head.grad = None
         logits, dmap, _ = spx.proto_head_forward(x, bank, head, layout, want_distances=True)
-        torch.autograd.backward([logits, dmap], [g_logits, g_dist])
+        outs, gouts = [], []
+        if "logits" in args.grads:
+            outs.append(logits); gouts.append(g_logits)
+        if "dist" in args.grads:
+            outs.append(dmap); gouts.append(g_dist)
+        torch.autograd.backward(outs, gouts)
         if world > 1:
             bucket.all_reduce()
 

@@ -91,7 +91,7 @@ int spx_dist_fwd(const spx_plan* plan, const void* x, int32_t x_dtype, int32_t B
 /* Backward, pixel side: recomputes the distance tile, forms
  *   G = (dDist + (dAct + dLogits.W) * act'(d)) * [d > 0]
  * and writes dX = 2 (rowsum_s(G) x - G.P) in X's dtype, plus bf16 copies of G and of the
- * activations (both [P_pad, B*HW], prototype-major) for spx_bank_bwd.  Replaces autograd through
+ * activations (MFMA-fragment order, spx_bwd_scratch_bytes() each) for spx_bank_bwd.  Replaces autograd through
  * model_multiscale.py:255-281,324-330,243-244.  d_dist / d_act / d_logits may be NULL (treated as 0);
  * dx may be NULL (X frozen); g_out / a_out may be NULL when the bank / head are frozen. */
 int spx_dist_bwd(const spx_plan* plan, const void* x, int32_t x_dtype, int32_t B, int32_t HW,
@@ -101,8 +101,8 @@ int spx_dist_bwd(const spx_plan* plan, const void* x, int32_t x_dtype, int32_t B
                  void* dx, void* g_out, void* a_out,
                  float epsilon, int32_t act_fn, void* stream);
 
-/* Rows of the g_out / a_out scratch of spx_dist_bwd (= padded prototype count). */
-int32_t spx_gpad_rows(const spx_plan* plan);
+/* Bytes of the g_out (and of the a_out) scratch of spx_dist_bwd. */
+size_t spx_bwd_scratch_bytes(const spx_plan* plan, int32_t B, int32_t HW);
 
 /* Backward, parameter side: d_bank [P, Cs] = 2 (p colsum(G) - G^T X) and d_W [K, P] = dLogits^T A,
  * as a pixel-split MFMA reduction with per-workgroup fp32 partial slabs summed in a fixed order

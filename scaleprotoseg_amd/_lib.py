@@ -57,7 +57,7 @@ SIGNATURES = {
     "spx_pack_head": (C.c_int, [_PP, _V, _V, _V, _V]),
     "spx_dist_fwd": (C.c_int, [_PP, _V, _I, _I, _I, _V, _V, _V, _V, _V, _V, _F, _I, _V]),
     "spx_dist_bwd": (C.c_int, [_PP, _V, _I, _I, _I, _V, _V, _V, _V, _V, _V, _V, _V, _V, _V, _F, _I, _V]),
-    "spx_gpad_rows": (_I, [_PP]),
+    "spx_bwd_scratch_bytes": (C.c_size_t, [_PP, _I, _I]),
     "spx_bank_bwd_workspace_bytes": (C.c_size_t, [_PP, _I, _I]),
     "spx_bank_bwd": (C.c_int, [_PP, _V, _I, _I, _I, _V, _V, _V, _V, _V, _V, _V, _V]),
     "spx_push_argmin": (C.c_int, [_V, _V, _V, _I, _I, _I, _I, _I, _F, _V, _V, _V, _V]),

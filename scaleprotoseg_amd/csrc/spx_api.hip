@@ -81,7 +81,7 @@ int spx_make_plan(int32_t P, int32_t K, int32_t S, int32_t Cs, const int32_t* lo
     return 0;
 }
 
-int32_t spx_gpad_rows(const spx_plan* pl) { return pl->npanels * pl->npb * 32; }
+size_t spx_bwd_scratch_bytes(const spx_plan* pl, int32_t B, int32_t HW) { return spx_bwd_scratch_elems(*pl, B, HW) * 2; }
 
 size_t spx_packed_bank_bytes(const spx_plan* pl) {
     return (size_t)pl->npanels * pl->npb * 32 * pl->channels_per_scale * 2;
@@ -116,6 +116,8 @@ int spx_dist_fwd(const spx_plan* pl, const void* x, int32_t x_dtype, int32_t B, 
     if (logits && !packed_head) return fail("spx_dist_fwd: logits requested without a packed head");
     const long long tiles = (long long)B * ((HW + SPX_TILE_PX - 1) / SPX_TILE_PX);
     if (tiles > 0x7fffffffLL) return fail("spx_dist_fwd: too many pixel tiles");
+    if ((long long)pl->num_prototypes * HW >= (1LL << 29)) return fail("spx_dist_fwd: P*HW too large for 32-bit offsets");
+    if ((long long)pl->num_scales * pl->channels_per_scale * HW * (x_dtype ? 4 : 2) >= (1LL << 32)) return fail("spx_dist_fwd: one image of features exceeds 4 GiB");
     SpxFwdArgs a;
     a.plan = *pl;
     a.x = x;
@@ -143,7 +145,7 @@ int spx_dist_bwd(const spx_plan* pl, const void* x, int32_t x_dtype, int32_t B, 
     if (B < 1 || HW < 1) return fail("spx_dist_bwd: empty input");
     if (dx && !packed_bankT) return fail("spx_dist_bwd: dx requested without packed bank^T");
     if (d_logits && !packed_headT) return fail("spx_dist_bwd: d_logits given without packed head^T");
-    if (pl->channels_per_scale > 256) return fail("spx_dist_bwd: Cs %d > 256 not supported", pl->channels_per_scale);
+    if ((long long)pl->num_prototypes * HW >= (1LL << 29)) return fail("spx_dist_bwd: P*HW too large for 32-bit offsets");
     SpxBwdArgs a;
     a.plan = *pl;
     a.x = x;
@@ -159,7 +161,6 @@ int spx_dist_bwd(const spx_plan* pl, const void* x, int32_t x_dtype, int32_t B, 
     a.a_out = (uint16_t*)a_out;
     a.B = B;
     a.HW = HW;
-    a.HWp = (HW + 7) & ~7;
     a.vec_ok = x_vec_ok(x, x_dtype, HW);
     a.eps = epsilon;
     a.act_fn = act_fn;
@@ -192,7 +193,6 @@ int spx_bank_bwd(const spx_plan* pl, const void* x, int32_t x_dtype, int32_t B, 
     a.workspace = (float*)workspace;
     a.B = B;
     a.HW = HW;
-    a.HWp = (HW + 7) & ~7;
     a.vec_ok = x_vec_ok(x, x_dtype, HW);
     a.nsplit = spx_bank_bwd_nsplit(*pl, B, HW);
     return hip_status(spx_launch_bank_bwd(a, x_dtype, (hipStream_t)stream), "spx_bank_bwd");

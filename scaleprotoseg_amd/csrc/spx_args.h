@@ -28,7 +28,7 @@ struct SpxBwdArgs {
     void* dx;
     uint16_t* g_out;
     uint16_t* a_out;
-    int B, HW, HWp, vec_ok;
+    int B, HW, vec_ok;
     float eps;
     int act_fn;
 };
@@ -42,12 +42,13 @@ struct SpxBankBwdArgs {
     float* d_bank;
     float* d_W;
     float* workspace;
-    int B, HW, HWp, vec_ok, nsplit;
+    int B, HW, vec_ok, nsplit;
 };
 hipError_t spx_launch_fwd(const SpxFwdArgs& a, int x_dtype, hipStream_t s);
 hipError_t spx_launch_bwd(const SpxBwdArgs& a, int x_dtype, hipStream_t s);
 hipError_t spx_launch_bank_bwd(const SpxBankBwdArgs& a, int x_dtype, hipStream_t s);
 int spx_bank_bwd_nsplit(const spx_plan& pl, int B, int HW);
+size_t spx_bwd_scratch_elems(const spx_plan& pl, int B, int HW);
 size_t spx_bank_bwd_ws_floats(const spx_plan& pl, int nsplit);
 hipError_t spx_launch_pack_bank(const spx_plan& pl, const float* bank, void* pb, void* pbT, float* p2, hipStream_t s);
 hipError_t spx_launch_pack_head(const spx_plan& pl, const float* W, void* ph, void* phT, hipStream_t s);

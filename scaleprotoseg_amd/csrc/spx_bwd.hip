@@ -10,36 +10,66 @@
 //
 // Kernel 1 (pixel side, spx_bwd_kernel): same tiling and main loop as the forward (the x.p tile is
 // recomputed with identical arithmetic, so the relu mask is the forward's bit for bit — cheaper than
-// re-reading the fp32 distance map: 2*P*C flop/px on the matrix pipe vs 4*P bytes/px of HBM), then G, dX,
-// and bf16 copies of G and a in prototype-major [P_pad][B*HWp] order for kernel 2.
-// Kernel 2 (parameter side, spx_bank_bwd_kernel): pixel-split MFMA reduction G^T.X and a^T.dLogits with
-// per-workgroup fp32 partial slabs; kernel 3 sums the slabs in a fixed order (no float atomics).
+// re-reading the fp32 distance map: 2*P*C flop/px on the matrix pipe vs 4*P bytes/px of HBM).
+//   phase 1: G and a in accumulator layout (lane = pixel), packed to bf16 MFMA B-fragments; the fragments
+//            are dumped verbatim ("blobs": 1 KiB per 32 px x 16 prototypes, one 16-B store per lane) for
+//            kernel 2, and kept in registers for
+//   phase 2: dX^T[ch x px] = P^T . G with the G fragments as B operand (accumulator -> operand, no LDS) and
+//            the P^T fragments streamed through LDS; the result is transposed through LDS so that X is read
+//            and dX written in whole 256-B pixel rows.
+// Kernel 2 (parameter side, spx_bank_bwd_kernel): pixel-split MFMA reduction G^T.X and a^T.dLogits; the blobs
+// are laid out [pixel][prototype] in LDS and read back with ds_read_b64_tr_b16 (pixel becomes the MFMA k).
+// Per-workgroup fp32 partial slabs, summed in a fixed order by kernel 3 (no float atomics).
 #include "spx_args.h"
 #include "spx_mainloop.h"
 
 #ifndef SPX_BWD_WAVES
-#define SPX_BWD_WAVES 1
+#define SPX_BWD_WAVES 2
 #endif
+
+#define SPX_BT_BYTES 12288                // one P^T stage: fragments of one 32-channel block, <= 6 blocks x 2 k-steps x 1 KiB
+#define SPX_T_ROW 528                     // fp32 transpose tile row: 128 px * 4 B + 16 B pad
+#define SPX_T_BYTES (32 * SPX_T_ROW)
+
+__host__ __device__ inline int spx_bwd_head_lds_bytes(const spx_plan& pl) {
+    const int b = pl.npb * pl.ncb * 2 * 2048;
+    return b <= 32768 ? b : 0;
+}
+__host__ __device__ inline int spx_bwd_region0_bytes(const spx_plan& pl) {
+    const int a = 2 * spx_stage_bytes(pl.kc, pl.npb);
+    const int b = 2 * SPX_BT_BYTES + 2 * SPX_T_BYTES;
+    return a > b ? a : b;
+}
+__host__ __device__ inline int spx_bwd_lds_bytes(const spx_plan& pl) {
+    return spx_bwd_region0_bytes(pl) + spx_bwd_head_lds_bytes(pl) + pl.npb * 32 * 4 + SPX_TILE_PX * 4;
+}
+// bf16 elements of one G (or a) scratch: [panel][tile][wave][pb][s2] fragments of 512 elements
+size_t spx_bwd_scratch_elems(const spx_plan& pl, int B, int HW) {
+    const size_t tiles = (size_t)B * ((HW + SPX_TILE_PX - 1) / SPX_TILE_PX);
+    return (size_t)pl.npanels * tiles * 4 * pl.npb * 2 * 512;
+}
 
 // ------------------------------------------------------------------------------------------------
 // kernel 1: pixel side
 // ------------------------------------------------------------------------------------------------
-template <int NPB, int NCB, int NCHB, bool XF32>
+template <int NPB, int NCB, bool XF32, bool ACT_LOG>
 __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const spx_plan& pl = a.plan;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
     const int tiles_per_img = (a.HW + SPX_TILE_PX - 1) / SPX_TILE_PX;
     const int b = blockIdx.x / tiles_per_img;
-    const int px0 = (blockIdx.x % tiles_per_img) * SPX_TILE_PX;
+    const int tile_i = blockIdx.x % tiles_per_img;
+    const int px0 = tile_i * SPX_TILE_PX;
+    const size_t ntiles = (size_t)a.B * tiles_per_img;
     const int Cs = pl.channels_per_scale;
     const int C = pl.num_scales * Cs;
     const int P = pl.num_prototypes, K = pl.num_classes;
     const int nchb = (Cs + 31) / 32;
     const int ncstep = pl.ncb * 2;
     const uint32_t HW = (uint32_t)a.HW;
-    const size_t Mp = (size_t)a.B * a.HWp;
     constexpr int ESZ = XF32 ? 4 : 2;
 
     const char* x_img = (const char*)a.x + (size_t)b * C * a.HW * ESZ;
@@ -50,33 +80,30 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
     const int nchunks = Cs / pl.kc;
     const int nks = pl.kc >> 4;
     const uint32_t chunk_bytes = (uint32_t)(pl.npb * nks * 1024);
-    const int total = pl.npanels * nchunks;
+    const int head_lds = spx_bwd_head_lds_bytes(pl);
+    char* const hlds = smem + spx_bwd_region0_bytes(pl);
+    float* const p2s = (float*)(hlds + head_lds);
+    float* const rss = p2s + pl.npb * 32;
 
     const int px = px0 + 32 * wave + r;
     const bool px_ok = px < a.HW;
-    const bool px_pad_ok = px < a.HWp;
-    // per-lane byte offsets (fixed for the kernel); row/block selection rides on wave-uniform SGPR offsets
-    const uint32_t voff_d = ((uint32_t)(4 * h) * HW + (uint32_t)px) * 4u;             // [row][px] fp32 maps
-    const uint32_t voff_a = ((uint32_t)px * (uint32_t)P + (uint32_t)(4 * h)) * 4u;    // dAct [px][row]
-    const uint32_t voff_x = ((uint32_t)(4 * h) * HW + (uint32_t)px) * ESZ;            // X / dX [ch][px]
-    const uint32_t voff_g = (uint32_t)(((size_t)(4 * h) * Mp + (size_t)b * a.HWp + px) * 2);   // G/a scratch rows
+    const uint32_t voff_d = px_ok ? ((uint32_t)(4 * h) * HW + (uint32_t)px) * 4u : SPX_OOB;            // [row][px] fp32
+    const uint32_t voff_a = px_ok ? ((uint32_t)px * (uint32_t)P + (uint32_t)(4 * h)) * 4u : SPX_OOB;   // [px][row] fp32
     const spx_rsrc htr = make_rsrc(a.packed_headT);
-    const spx_rsrc btr = make_rsrc(a.packed_bankT);
-    const spx_rsrc xir = make_rsrc(x_img);
-    const spx_rsrc dxr = make_rsrc(a.dx ? (char*)a.dx + (size_t)b * C * a.HW * ESZ : nullptr);
+    const spx_rsrc btr = make_rsrc_pred(a.packed_bankT);
+    const spx_rsrc p2r = make_rsrc(a.p2);
 
     // dLogits of this lane's pixel as split-bf16 B fragments: element j of k-step c <-> class 16c + 8h + j
     bf16x8 dlhi[NCB * 2], dllo[NCB * 2];
     {
-        const spx_rsrc lr = make_rsrc(a.d_logits ? a.d_logits + (size_t)b * a.HW * K : nullptr);
-        const uint32_t voff_l = ((uint32_t)px * (uint32_t)K + (uint32_t)(8 * h)) * 4u;
+        const spx_rsrc lr = make_rsrc_pred(a.d_logits ? a.d_logits + (size_t)b * a.HW * K : nullptr);
+        const uint32_t voff_l = (a.d_logits && px_ok) ? ((uint32_t)px * (uint32_t)K + (uint32_t)(8 * h)) * 4u : SPX_OOB;
 #pragma unroll
         for (int c = 0; c < NCB * 2; ++c) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                float v = 0.0f;
                 const int cls = c * 16 + 8 * h + j;
-                if (a.d_logits && px_ok && c < ncstep && cls < K) v = buf_load_f32(lr, voff_l, (uint32_t)((c * 16 + j) * 4));
+                const float v = buf_load_f32(lr, (c < ncstep && cls < K) ? voff_l : SPX_OOB, (uint32_t)((c * 16 + j) * 4));
                 __bf16 hi, lo;
                 split_bf16(v, hi, lo);
                 dlhi[c][j] = hi;
@@ -85,56 +112,85 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
         }
     }
 
-    SpxStager<NPB, XF32> st;
+    SpxStager<NPB, XF32> stA, stB;
     f32x16 acc[NPB];
+#pragma unroll
+    for (int pb = 0; pb < NPB; ++pb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[pb][i] = 0.0f;
     float x2part = 0.0f;
 
-    st.load(tc, pl, 0u, pl.panel_ch0[0], tid);
-    st.write(pl, smem, smem + xs_bytes, tid);
-    __syncthreads();
+    auto stage_panel_consts = [&](int panel) {
+        if (a.d_logits && head_lds) {
+            const uint32_t so = (uint32_t)(panel * pl.npb * ncstep * 2048);
+            for (int off = tid * 16; off < head_lds; off += 256 * 16) *(u32x4*)(hlds + off) = buf_load_b128(htr, (uint32_t)off, so);
+        }
+        if (tid < pl.npb * 32) p2s[tid] = buf_load_f32(p2r, (uint32_t)tid * 4u, (uint32_t)(panel * pl.npb * 32 * 4));
+    };
 
-    int buf = 0;
-    for (int step = 0; step < total; ++step) {
-        const int panel = step / nchunks, chunk = step - panel * nchunks;
-        if (chunk == 0) {
-#pragma unroll
-            for (int pb = 0; pb < NPB; ++pb)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) acc[pb][i] = 0.0f;
-            x2part = 0.0f;
-        }
-        const bool more = step + 1 < total;
-        if (more) {
-            const int np_ = (step + 1) / nchunks, nc_ = (step + 1) - np_ * nchunks;
-            st.load(tc, pl, (uint32_t)(step + 1) * chunk_bytes, pl.panel_ch0[np_] + nc_ * pl.kc, tid);
-        }
-        char* cur = smem + buf * stage;
-        spx_compute_chunk<NPB>(acc, x2part, pl, cur, cur + xs_bytes, lane, wave);
-        if (more) {
-            char* nxt = smem + (buf ^ 1) * stage;
-            st.write(pl, nxt, nxt + xs_bytes, tid);
-        }
-        __syncthreads();
-        buf ^= 1;
-        if (chunk != nchunks - 1) continue;
-
-        // ---------------- panel epilogue, phase 1: G ----------------
+    // ---------------- panel epilogue ----------------
+    auto epilogue = [&](int panel) {
         const float x2 = x2part + __shfl_xor(x2part, 32);
         const int p0 = pl.panel_p0[panel], np = pl.panel_np[panel];
         const int ch0 = pl.panel_ch0[panel];
-        const spx_rsrc p2r = make_rsrc(a.p2 + panel * pl.npb * 32);
-        bf16x8 gpk[NPB][2];
+        const int nv = (np + 31) >> 5;                   // prototype blocks holding >= 1 real prototype
+        const size_t tile_g = (size_t)b * tiles_per_img + tile_i;
+        const size_t blob0 = (((size_t)panel * ntiles + tile_g) * 4) * pl.npb * 2 * 1024;   // bytes
+        const spx_rsrc gr = make_rsrc(a.g_out ? (const char*)a.g_out + blob0 : nullptr);
+        const spx_rsrc ar = make_rsrc(a.a_out ? (const char*)a.a_out + blob0 : nullptr);
+
+        // ---- phase 1: G, a — a ROLLED loop over the panel's 32-prototype blocks.  The block being processed is
+        // always acc[0]; acc is rotated after each block and the packed G fragments enter a register queue, so
+        // the body is compiled once with a fixed register footprint (an unrolled version spilled hundreds of
+        // registers).  Exactly NPB iterations, so the queue ends aligned: gpk[i] = block i.
+        // The packed G fragments (8 registers per block) are stored in the accumulator slot that the rotation
+        // frees (16 registers), so after NPB iterations acc[i] holds block i's fragments and no second register
+        // array is needed.
         float rs = 0.0f;
+        float ddn[16];              // dDist of the NEXT block: its loads run one block ahead
+        auto load_ddist = [&](int pb) {
+            const spx_rsrc ddr = make_rsrc_pred(a.d_dist + ((size_t)b * P + p0 + pb * 32) * a.HW);
+            const bool full = pb * 32 + 32 <= np;
 #pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int rb = (reg & 3) + 8 * (reg >> 2);
+                ddn[reg] = buf_load_f32(ddr, (full || (pb * 32 + rb + 4 * h < np)) ? voff_d : SPX_OOB, (uint32_t)rb * HW * 4u);
+            }
+        };
+        if (a.d_dist) {
+            load_ddist(0);
+        } else {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) ddn[reg] = 0.0f;
+        }
+#pragma unroll 1
         for (int pb = 0; pb < NPB; ++pb) {
+            bf16x8 gnew[2], anew[2];
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) gpk[pb][s2][j] = (__bf16)0.0f;
-            const size_t grow = (size_t)panel * pl.npb * 32 + pb * 32;
-            const spx_rsrc gr = make_rsrc(a.g_out ? a.g_out + grow * Mp : nullptr);
-            const spx_rsrc ar = make_rsrc(a.a_out ? a.a_out + grow * Mp : nullptr);
-            if (pb < pl.npb && pb * 32 < np) {
+                for (int j = 0; j < 8; ++j) {
+                    gnew[s2][j] = (__bf16)0.0f;
+                    anew[s2][j] = (__bf16)0.0f;
+                }
+            if (pb < nv) {
+                float ddc[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) ddc[i] = ddn[i];
+                if (a.d_dist && pb + 1 < nv) load_ddist(pb + 1);
+                const bool full = pb * 32 + 32 <= np;
+                float dac[16];
+                if (a.d_act) {
+                    const spx_rsrc dar = make_rsrc_pred(a.d_act + (size_t)b * a.HW * P + p0 + pb * 32);
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        const int rb = (reg & 3) + 8 * (reg >> 2);
+                        dac[reg] = buf_load_f32(dar, (full || (pb * 32 + rb + 4 * h < np)) ? voff_a : SPX_OOB, (uint32_t)(rb * 4));
+                    }
+                } else {
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) dac[reg] = 0.0f;
+                }
                 f32x16 ga;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) ga[i] = 0.0f;
@@ -142,139 +198,260 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
 #pragma unroll
                     for (int c = 0; c < NCB * 2; ++c) {
                         if (c < ncstep) {
-                            const uint32_t so = (uint32_t)(((panel * pl.npb + pb) * ncstep + c) * 2048);
-                            const bf16x8 whi = __builtin_bit_cast(bf16x8, buf_load_b128(htr, (uint32_t)lane * 16u, so));
-                            const bf16x8 wlo = __builtin_bit_cast(bf16x8, buf_load_b128(htr, (uint32_t)lane * 16u, so + 1024u));
+                            bf16x8 whi, wlo;
+                            if (head_lds) {
+                                const char* wf = hlds + (pb * ncstep + c) * 2048 + lane * 16;
+                                whi = *(const bf16x8*)wf;
+                                wlo = *(const bf16x8*)(wf + 1024);
+                            } else {
+                                const uint32_t so = (uint32_t)(((panel * pl.npb + pb) * ncstep + c) * 2048);
+                                whi = __builtin_bit_cast(bf16x8, buf_load_b128(htr, (uint32_t)lane * 16u, so));
+                                wlo = __builtin_bit_cast(bf16x8, buf_load_b128(htr, (uint32_t)lane * 16u, so + 1024u));
+                            }
                             ga = mfma_bf16(whi, dlhi[c], ga);
                             ga = mfma_bf16(wlo, dlhi[c], ga);
                             ga = mfma_bf16(whi, dllo[c], ga);
                         }
                     }
                 }
-                const spx_rsrc ddr = make_rsrc(a.d_dist ? a.d_dist + ((size_t)b * P + p0 + pb * 32) * a.HW : nullptr);
-                const spx_rsrc dar = make_rsrc(a.d_act ? a.d_act + (size_t)b * a.HW * P + p0 + pb * 32 : nullptr);
-                float gv[16];
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
-                    const int row0 = 8 * g4 + 4 * h;
-                    const u32x4 p2u = buf_load_b128(p2r, (uint32_t)(16 * h), (uint32_t)((pb * 32 + 8 * g4) * 4));
+                    const f32x4 p2v = *(const f32x4*)(p2s + pb * 32 + 8 * g4 + 4 * h);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int reg = 4 * g4 + e;
-                        const bool valid = px_ok && (pb * 32 + row0 + e < np);
-                        const float d_raw = __builtin_fmaf(-2.0f, acc[pb][reg], __uint_as_float(p2u[e])) + x2;
+                        const bool valid = px_ok && (full || (pb * 32 + 8 * g4 + 4 * h + e < np));
+                        const float d_raw = __builtin_fmaf(-2.0f, acc[0][reg], p2v[e]) + x2;
                         const float d = fmaxf(d_raw, 0.0f);
-                        float dact;   // act'(d)
-                        float aval;
-                        if (a.act_fn == 0) {
-                            dact = -(1.0f - a.eps) * __fdividef(1.0f, (d + 1.0f) * (d + a.eps));
-                            aval = act_log(d, a.eps);
-                        } else {
-                            dact = -1.0f;
-                            aval = -d;
-                        }
-                        float gtot = ga[reg];
-                        float dd = 0.0f;
-                        if (valid) {
-                            if (a.d_act) gtot += buf_load_f32(dar, voff_a, (uint32_t)((8 * g4 + e) * 4));
-                            if (a.d_dist) dd = buf_load_f32(ddr, voff_d, (uint32_t)(8 * g4 + e) * HW * 4u);
-                        }
-                        const float G = (valid && d_raw > 0.0f) ? dd + gtot * dact : 0.0f;
+                        const float dact = ACT_LOG ? act_log_grad(d, a.eps) : -1.0f;
+                        const float aval = ACT_LOG ? act_log(d, a.eps) : -d;
+                        const float G = (valid && d_raw > 0.0f) ? ddc[reg] + (ga[reg] + dac[reg]) * dact : 0.0f;
                         rs += G;
-                        gv[reg] = G;
-                        if (px_pad_ok) {
-                            const uint32_t so = (uint32_t)((size_t)(8 * g4 + e) * Mp * 2);
-                            if (a.g_out) buf_store_u16(__builtin_bit_cast(uint16_t, (__bf16)G), gr, voff_g, so);
-                            if (a.a_out) buf_store_u16(__builtin_bit_cast(uint16_t, (__bf16)(valid ? aval : 0.0f)), ar, voff_g, so);
-                        }
+                        // register reg = 8 s2 + j of the tile -> element j of k-step s2 of the B fragment
+                        gnew[g4 >> 1][4 * (g4 & 1) + e] = (__bf16)G;
+                        anew[g4 >> 1][4 * (g4 & 1) + e] = (__bf16)(valid ? aval : 0.0f);
                     }
                 }
+            }
+            if (pb < pl.npb) {
+                // fragment dump for kernel 2 (wholly padded blocks are written as zeros: kernel 2 reads them)
 #pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2)
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const uint32_t so = (uint32_t)(((wave * pl.npb + pb) * 2 + s2) * 1024);
+                    if (a.g_out) buf_store_b128(__builtin_bit_cast(u32x4, gnew[s2]), gr, (uint32_t)lane * 16u, so);
+                    if (a.a_out) buf_store_b128(__builtin_bit_cast(u32x4, anew[s2]), ar, (uint32_t)lane * 16u, so);
+                }
+            }
+            // rotate: next block -> acc[0]; this block's G fragments enter the vacated slot
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) gpk[pb][s2][j] = (__bf16)gv[8 * s2 + j];
-                __builtin_amdgcn_sched_barrier(0);   // keep later blocks' loads out of this block (VGPR budget)
-            } else if (pb < pl.npb && px_pad_ok) {
-                // wholly padded prototype block: kernel 2 still reads these rows -> keep them finite (zero)
+            for (int i = 0; i + 1 < NPB; ++i) acc[i] = acc[i + 1];
+            {
+                const u32x4 g0 = __builtin_bit_cast(u32x4, gnew[0]), g1 = __builtin_bit_cast(u32x4, gnew[1]);
 #pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    const uint32_t so = (uint32_t)((size_t)((reg & 3) + 8 * (reg >> 2)) * Mp * 2);
-                    if (a.g_out) buf_store_u16(0, gr, voff_g, so);
-                    if (a.a_out) buf_store_u16(0, ar, voff_g, so);
+                for (int i = 0; i < 4; ++i) {
+                    acc[NPB - 1][i] = __uint_as_float(g0[i]);
+                    acc[NPB - 1][4 + i] = __uint_as_float(g1[i]);
+                    acc[NPB - 1][8 + i] = 0.0f;
+                    acc[NPB - 1][12 + i] = 0.0f;
                 }
             }
         }
-        if (!a.dx) continue;
-
-        // ---------------- phase 2: dX^T[ch x px] = 2 (rs * x - P^T . G) ----------------
+        auto g_frag = [&](int pb, int s2) -> bf16x8 {
+            u32x4 w;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) w[i] = __float_as_uint(acc[pb][4 * s2 + i]);
+            return __builtin_bit_cast(bf16x8, w);
+        };
+        auto clear_acc = [&]() {
+#pragma unroll
+            for (int pb = 0; pb < NPB; ++pb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[pb][i] = 0.0f;
+        };
+        if (!a.dx) {
+            clear_acc();
+            return;
+        }
+        // ---- phase 2: dX^T[ch x px] = 2 (rs * x - P^T . G), one 32-channel block per (rolled) iteration ----
         const float rs_tot = rs + __shfl_xor(rs, 32);
+        if (h == 0) rss[32 * wave + r] = rs_tot;
         const bool first_of_scale = (panel == 0) || (pl.panel_ch0[panel - 1] != ch0);
-        __builtin_amdgcn_sched_barrier(0);
-        constexpr int CG = NCHB < 4 ? NCHB : 4;          // channel blocks per pass (<= 64 accumulator registers)
+        char* const bt = smem;                               // 2 x SPX_BT_BYTES  (P^T fragments of one channel block)
+        char* const tt = smem + 2 * SPX_BT_BYTES;            // 2 x SPX_T_BYTES   (fp32 transpose tiles)
+        const int frow = tid >> 3, fseg = tid & 7;           // finish mapping: channel row, 16-px segment
+        const int fpx = px0 + fseg * 16;
+        // this thread's segment inside a 32-channel block (resources are re-based per block: offsets < 2 GiB)
+        const uint32_t fvo = ((uint32_t)frow * HW + (uint32_t)fpx) * ESZ;
+        constexpr int NV = XF32 ? 4 : 2;                     // 16-B vectors per 16 px
+        constexpr int PV = 16 / NV;                          // pixels per vector
+        constexpr int BTP = (NPB * 2 + 3) / 4;               // fragment passes of the stage loader
+
+        // stage loader: fragment f = wave + 4 i  <->  (pb = f >> 1, s2 = f & 1) of channel block chb
+        u32x4 bt_reg[BTP];
+        auto bt_load = [&](int chb) {
 #pragma unroll
-        for (int cg = 0; cg < NCHB; cg += CG) {
-            if (cg >= nchb) break;
-            f32x16 accx[CG];
+            for (int i = 0; i < BTP; ++i) {
+                const int f = wave + 4 * i;
+                const uint32_t so = (uint32_t)((((panel * pl.npb) * 2 + f) * nchb + chb) * 1024);
+                bt_reg[i] = buf_load_b128(btr, (f < 2 * nv) ? (uint32_t)lane * 16u : SPX_OOB, so);
+            }
+        };
+        auto bt_write = [&](int buf) {
 #pragma unroll
-            for (int c = 0; c < CG; ++c)
+            for (int i = 0; i < BTP; ++i) {
+                const int f = wave + 4 * i;
+                if (f < 2 * NPB) *(u32x4*)(bt + buf * SPX_BT_BYTES + f * 1024 + lane * 16) = bt_reg[i];
+            }
+        };
+        bt_load(0);
+        bt_write(0);
+        __syncthreads();
+        for (int chb = 0; chb < nchb; ++chb) {
+            if (chb + 1 < nchb) bt_load(chb + 1);
+            // x (and the previous partial dX) of this thread's finish segment: in flight across MFMAs + barrier
+            const bool ch_ok = chb * 32 + frow < Cs;
+            const spx_rsrc xir = make_rsrc_pred(x_img + (size_t)(ch0 + chb * 32) * a.HW * ESZ);
+            const spx_rsrc dxr = make_rsrc_pred((char*)a.dx + ((size_t)b * C + ch0 + chb * 32) * a.HW * ESZ);
+            float xv[16], pv[16];
+            if (a.vec_ok) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) accx[c][i] = 0.0f;
+                for (int v = 0; v < NV; ++v) {
+                    const bool ok = ch_ok && (fpx + (v + 1) * PV <= a.HW);
+                    const u32x4 xw = buf_load_b128(xir, ok ? fvo + 16u * v : SPX_OOB, 0);
+                    u32x4 pw = {0u, 0u, 0u, 0u};
+                    if (!first_of_scale) pw = buf_load_b128(dxr, ok ? fvo + 16u * v : SPX_OOB, 0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (XF32) {
+                            xv[4 * v + e] = __uint_as_float(xw[e]);
+                            pv[4 * v + e] = __uint_as_float(pw[e]);
+                        } else {
+                            xv[8 * v + 2 * e] = __uint_as_float(xw[e] << 16);
+                            xv[8 * v + 2 * e + 1] = __uint_as_float(xw[e] & 0xffff0000u);
+                            pv[8 * v + 2 * e] = __uint_as_float(pw[e] << 16);
+                            pv[8 * v + 2 * e + 1] = __uint_as_float(pw[e] & 0xffff0000u);
+                        }
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const uint32_t vo = (ch_ok && fpx + e < a.HW) ? fvo + (uint32_t)e * ESZ : SPX_OOB;
+                    if (XF32) {
+                        xv[e] = buf_load_f32(xir, vo, 0);
+                        pv[e] = first_of_scale ? 0.0f : buf_load_f32(dxr, vo, 0);
+                    } else {
+                        xv[e] = __uint_as_float((uint32_t)buf_load_u16(xir, vo, 0) << 16);
+                        pv[e] = first_of_scale ? 0.0f : __uint_as_float((uint32_t)buf_load_u16(dxr, vo, 0) << 16);
+                    }
+                }
+            }
+            f32x16 accx;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) accx[i] = 0.0f;
+            const char* cur = bt + (chb & 1) * SPX_BT_BYTES + lane * 16;
 #pragma unroll
             for (int pb = 0; pb < NPB; ++pb) {
-                if (pb < pl.npb && pb * 32 < np) {
+                if (pb < nv) {
 #pragma unroll
-                    for (int s2 = 0; s2 < 2; ++s2) {
-#pragma unroll
-                        for (int c = 0; c < CG; ++c) {
-                            const int chb = cg + c;
-                            if (chb < nchb) {
-                                const uint32_t so = (uint32_t)(((((panel * pl.npb + pb) * 2 + s2) * nchb) + chb) * 1024);
-                                const bf16x8 pf = __builtin_bit_cast(bf16x8, buf_load_b128(btr, (uint32_t)lane * 16u, so));
-                                accx[c] = mfma_bf16(pf, gpk[pb][s2], accx[c]);
-                            }
-                        }
-                    }
+                    for (int s2 = 0; s2 < 2; ++s2)
+                        accx = mfma_bf16(*(const bf16x8*)(cur + (pb * 2 + s2) * 1024), g_frag(pb, s2), accx);
                 }
             }
-            if (px_ok) {
+            char* T = tt + (chb & 1) * SPX_T_BYTES;
 #pragma unroll
-                for (int c = 0; c < CG; ++c) {
-                    const int chb = cg + c;
-                    if (chb < nchb) {
+            for (int reg = 0; reg < 16; ++reg)
+                *(float*)(T + acc_row(reg, h) * SPX_T_ROW + (32 * wave + r) * 4) = accx[reg];
+            if (chb + 1 < nchb) bt_write((chb + 1) & 1);
+            __syncthreads();
+            float ov[16];
 #pragma unroll
-                        for (int reg = 0; reg < 16; ++reg) {
-                            const int chl = chb * 32 + (reg & 3) + 8 * (reg >> 2);     // + 4h rides in voff_x
-                            if (chl + 4 * h < Cs) {
-                                const uint32_t so = (uint32_t)(ch0 + chl) * HW * ESZ;
-                                float xv, prev = 0.0f;
-                                if (XF32) {
-                                    xv = buf_load_f32(xir, voff_x, so);
-                                    if (!first_of_scale) prev = buf_load_f32(dxr, voff_x, so);
-                                } else {
-                                    xv = (float)__builtin_bit_cast(__bf16, buf_load_u16(xir, voff_x, so));
-                                    if (!first_of_scale) prev = (float)__builtin_bit_cast(__bf16, buf_load_u16(dxr, voff_x, so));
-                                }
-                                const float v = prev + 2.0f * (rs_tot * xv - accx[c][reg]);
-                                if (XF32)
-                                    buf_store_f32(v, dxr, voff_x, so);
-                                else
-                                    buf_store_u16(__builtin_bit_cast(uint16_t, (__bf16)v), dxr, voff_x, so);
-                            }
+            for (int v = 0; v < 4; ++v) {
+                const f32x4 tv = *(const f32x4*)(T + frow * SPX_T_ROW + fseg * 64 + v * 16);
+                const f32x4 rv = *(const f32x4*)(rss + fseg * 16 + v * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ov[4 * v + e] = pv[4 * v + e] + 2.0f * (rv[e] * xv[4 * v + e] - tv[e]);
+            }
+            if (a.vec_ok) {
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    const bool ok = ch_ok && (fpx + (v + 1) * PV <= a.HW);
+                    u32x4 w;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (XF32) {
+                            w[e] = __float_as_uint(ov[4 * v + e]);
+                        } else {
+                            bf16x2 p;
+                            p[0] = (__bf16)ov[8 * v + 2 * e];
+                            p[1] = (__bf16)ov[8 * v + 2 * e + 1];
+                            w[e] = __builtin_bit_cast(uint32_t, p);
                         }
                     }
+                    buf_store_b128(w, dxr, ok ? fvo + 16u * v : SPX_OOB, 0);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const uint32_t vo = (ch_ok && fpx + e < a.HW) ? fvo + (uint32_t)e * ESZ : SPX_OOB;
+                    if (XF32)
+                        buf_store_f32(ov[e], dxr, vo, 0);
+                    else
+                        buf_store_u16(__builtin_bit_cast(uint16_t, (__bf16)ov[e]), dxr, vo, 0);
                 }
             }
-            __builtin_amdgcn_sched_barrier(0);
         }
+        clear_acc();       // the next panel accumulates from zero
+        __syncthreads();   // T tiles / P^T stages are rewritten by the next panel's main loop
+    };
+
+    // Software pipeline inside a panel: global loads run two K-chunks ahead of the MFMAs.  Nothing is kept in
+    // flight across the epilogue (its register budget is the binding one).
+    auto do_chunk = [&](int panel, int chunk, SpxStager<NPB, XF32>& far, SpxStager<NPB, XF32>& nxt) {
+        const uint32_t bank0 = (uint32_t)(panel * nchunks) * chunk_bytes;
+        if (chunk + 2 < nchunks)
+            far.load(tc, pl, bank0 + (uint32_t)(chunk + 2) * chunk_bytes, pl.panel_ch0[panel] + (chunk + 2) * pl.kc, tid);
+        char* cur = smem + (chunk & 1) * stage;
+        spx_compute_chunk<NPB>(acc, x2part, pl, cur, cur + xs_bytes, lane, wave);
+        if (chunk + 1 < nchunks) {
+            char* dst = smem + ((chunk + 1) & 1) * stage;
+            nxt.write(pl, dst, dst + xs_bytes, tid);
+        }
+        __syncthreads();
+    };
+
+    for (int panel = 0; panel < pl.npanels; ++panel) {
+        const uint32_t bank0 = (uint32_t)(panel * nchunks) * chunk_bytes;
+        x2part = 0.0f;
+        stage_panel_consts(panel);
+        stA.load(tc, pl, bank0, pl.panel_ch0[panel], tid);
+        if (nchunks > 1) stB.load(tc, pl, bank0 + chunk_bytes, pl.panel_ch0[panel] + pl.kc, tid);
+        stA.write(pl, smem, smem + xs_bytes, tid);
+        __syncthreads();
+        for (int chunk = 0; chunk < nchunks; chunk += 2) {
+            do_chunk(panel, chunk, stA, stB);
+            if (chunk + 1 < nchunks) do_chunk(panel, chunk + 1, stB, stA);
+        }
+#ifdef SPX_DIAG_SKIP_EPILOGUE
+        if (a.eps > 1e30f) epilogue(panel);   // timing-only build: keeps the code alive, never runs it
+        else { float s = x2part; for (int pb = 0; pb < NPB; ++pb) for (int i = 0; i < 16; ++i) { s += acc[pb][i]; acc[pb][i] = 0.0f; } if (s == 1.2345f) rss[0] = s; }
+#else
+        epilogue(panel);
+#endif
+        __syncthreads();     // the epilogue re-uses the staging LDS and the head / |p|^2 images
     }
 }
 
-template <int NPB, int NCB, int NCHB>
+template <int NPB, int NCB>
 static hipError_t launch_bwd_x(const SpxBwdArgs& a, int x_dtype, dim3 grid, size_t lds, hipStream_t s) {
-    if (x_dtype == 1)
-        hipLaunchKernelGGL((spx_bwd_kernel<NPB, NCB, NCHB, true>), grid, dim3(256), lds, s, a);
-    else
-        hipLaunchKernelGGL((spx_bwd_kernel<NPB, NCB, NCHB, false>), grid, dim3(256), lds, s, a);
+    const bool lg = a.act_fn == 0;
+    if (x_dtype == 1) {
+        if (lg) hipLaunchKernelGGL((spx_bwd_kernel<NPB, NCB, true, true>), grid, dim3(256), lds, s, a);
+        else hipLaunchKernelGGL((spx_bwd_kernel<NPB, NCB, true, false>), grid, dim3(256), lds, s, a);
+    } else {
+        if (lg) hipLaunchKernelGGL((spx_bwd_kernel<NPB, NCB, false, true>), grid, dim3(256), lds, s, a);
+        else hipLaunchKernelGGL((spx_bwd_kernel<NPB, NCB, false, false>), grid, dim3(256), lds, s, a);
+    }
     return hipGetLastError();
 }
 
@@ -282,31 +459,30 @@ hipError_t spx_launch_bwd(const SpxBwdArgs& a, int x_dtype, hipStream_t s) {
     const spx_plan& pl = a.plan;
     const int tiles = (a.HW + SPX_TILE_PX - 1) / SPX_TILE_PX;
     dim3 grid((unsigned)(tiles * a.B));
-    const size_t lds = 2 * (size_t)spx_stage_bytes(pl.kc, pl.npb);
-    const bool small_p = pl.npb <= 2;
-    const bool small_c = pl.channels_per_scale <= 64;
+    const size_t lds = (size_t)spx_bwd_lds_bytes(pl);
     if (pl.ncb <= 1) {
-        if (small_p && small_c) return launch_bwd_x<2, 1, 2>(a, x_dtype, grid, lds, s);
-        if (small_p) return launch_bwd_x<2, 1, 8>(a, x_dtype, grid, lds, s);
-        if (small_c) return launch_bwd_x<6, 1, 2>(a, x_dtype, grid, lds, s);
-        return launch_bwd_x<6, 1, 8>(a, x_dtype, grid, lds, s);
+        if (pl.npb <= 2) return launch_bwd_x<2, 1>(a, x_dtype, grid, lds, s);
+        return launch_bwd_x<6, 1>(a, x_dtype, grid, lds, s);
     }
-    if (small_c) return launch_bwd_x<6, 5, 2>(a, x_dtype, grid, lds, s);
-    return launch_bwd_x<6, 5, 8>(a, x_dtype, grid, lds, s);
+    return launch_bwd_x<6, 5>(a, x_dtype, grid, lds, s);
 }
 
 // ------------------------------------------------------------------------------------------------
 // kernel 2: parameter side   S[q][row][col] = sum_px Gq[row][px] * Xs[col][px]   (+ a^T.dLogits, colsum G)
 // ------------------------------------------------------------------------------------------------
-#define SPX_BK_PX 64          // pixels per K-chunk
-#define SPX_BK_ROW 144        // LDS row stride in bytes (128 + 16: conflict-free ds_read_b128 over 16 rows)
+#define SPX_BK_PX 64          // pixels per K-chunk (half a kernel-1 tile)
+#define SPX_BK_ROW 144        // LDS row stride of the [channel][px] images (128 + 16: conflict-free ds_read_b128)
+
+// row stride of the [px][prototype] images: the 4 pixel rows of a transposed read must fall on disjoint
+// 64-B bank windows -> stride = 64 or 192 (mod 256)
+__host__ __device__ inline int spx_bk_grow(int npb) { return npb * 64 + ((npb & 1) ? 0 : 64); }
 
 __host__ __device__ inline int spx_bk_wstride(const spx_plan& pl) {
     return ((pl.channels_per_scale + 31) / 32) * 32 + pl.ncb * 32 + 32;   // [dP cols | dW cols | colsum + pad]
 }
 int spx_bank_bwd_nsplit(const spx_plan& pl, int B, int HW) {
-    const long long chunks = (long long)B * ((HW + SPX_BK_PX - 1) / SPX_BK_PX);
-    long long n = 512 / pl.npanels;
+    const long long chunks = 2LL * B * ((HW + SPX_TILE_PX - 1) / SPX_TILE_PX);
+    long long n = 256 / pl.npanels;
     if (n < 1) n = 1;
     if (n > chunks) n = chunks;
     return (int)n;
@@ -319,7 +495,8 @@ template <int NPB, int NCB, bool XF32>
 __global__ __launch_bounds__(256, 1) void spx_bank_bwd_kernel(const SpxBankBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const spx_plan& pl = a.plan;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
     const int q = blockIdx.y, split = blockIdx.x;
     const int Cs = pl.channels_per_scale, K = pl.num_classes;
@@ -327,109 +504,114 @@ __global__ __launch_bounds__(256, 1) void spx_bank_bwd_kernel(const SpxBankBwdAr
     const int nchb = (Cs + 31) / 32;
     const int rows = pl.npb * 32;
     const int ch0 = pl.panel_ch0[q];
-    const size_t Mp = (size_t)a.B * a.HWp;
-    const int nci = (a.HW + SPX_BK_PX - 1) / SPX_BK_PX;
+    const int tiles_per_img = (a.HW + SPX_TILE_PX - 1) / SPX_TILE_PX;
+    const size_t ntiles = (size_t)a.B * tiles_per_img;
+    const int nci = 2 * tiles_per_img;                       // 64-px chunks per image
     const long long total = (long long)a.B * nci;
     const long long per = (total + a.nsplit - 1) / a.nsplit;
     const long long c_begin = split * per;
     const long long c_end = (c_begin + per < total) ? c_begin + per : total;
     const bool want_w = a.d_W != nullptr;
     const bool want_p = a.d_bank != nullptr;
+    const int grow = spx_bk_grow(pl.npb);
+    constexpr int ESZ = XF32 ? 4 : 2;
 
-    char* Gs = smem;                                  // [rows][144 B]
-    char* As = Gs + rows * SPX_BK_ROW;                // [rows][144 B]
-    char* Xs = As + rows * SPX_BK_ROW;                // [nchb*32][144 B]
-    char* Ls = Xs + nchb * 32 * SPX_BK_ROW;           // [ncb*32][144 B] dLogits^T (bf16)
+    char* Gs = smem;                                  // [64 px][grow B]   G^T image  (k = px)
+    char* As = Gs + SPX_BK_PX * grow;                 // [64 px][grow B]   a^T image
+    char* Xs = As + SPX_BK_PX * grow;                 // [nchb*32][144 B]  X rows
+    char* Ls = Xs + nchb * 32 * SPX_BK_ROW;           // [ncb*32][144 B]   dLogits^T (bf16)
 
-    // staging registers: 16-B pieces (8 px) of G, a, X rows
-    constexpr int GP = NPB;                // rows*8/256 pieces per thread for G (and for a)
-    constexpr int XP = 8;                  // <= 256 rows * 8 / 256
+    constexpr int GP = NPB;                // fragment passes: 4*npb fragments per chunk, 4 per pass
+    constexpr int XP = 8;                  // <= 256 rows * 8 pieces / 256 threads
     u32x4 gr[GP], ar[GP], xr[XP][XF32 ? 2 : 1];
     f32x16 accp[NPB][2];
     f32x16 accw[2][NCB];
+    float csum[NPB];
 #pragma unroll
-    for (int pb = 0; pb < NPB; ++pb)
+    for (int pb = 0; pb < NPB; ++pb) {
+        csum[pb] = 0.0f;
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int i = 0; i < 16; ++i) accp[pb][t][i] = 0.0f;
+    }
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
             for (int i = 0; i < 16; ++i) accw[t][cb][i] = 0.0f;
-    float csum[GP];
-#pragma unroll
-    for (int i = 0; i < GP; ++i) csum[i] = 0.0f;
 
     const u32x4 zero4 = {0u, 0u, 0u, 0u};
-    const int piece = tid & 7, prow = tid >> 3;      // piece of 8 px, row within a pass of 32 rows
+    const int piece = tid & 7, prow = tid >> 3;      // X staging: piece of 8 px, row within a pass of 32 rows
 
     auto issue = [&](long long c) {
         const int b = (int)(c / nci);
-        const int px0 = (int)(c - (long long)b * nci) * SPX_BK_PX;
-        const int px = px0 + piece * 8;
-        const size_t goff = (size_t)b * a.HWp + px;
+        const int ci = (int)(c - (long long)b * nci);
+        const size_t tile_g = (size_t)b * tiles_per_img + (ci >> 1);
+        // fragments of this chunk: f = wave + 4 i  ->  (wsel, pb, s2), kernel-1 wave = 2 (ci & 1) + wsel
+        const size_t blob0 = (((size_t)q * ntiles + tile_g) * 4) * pl.npb * 2 * 1024;
+        const spx_rsrc grs = make_rsrc(a.g_in ? (const char*)a.g_in + blob0 : nullptr);
+        const spx_rsrc ars = make_rsrc(a.a_in ? (const char*)a.a_in + blob0 : nullptr);
 #pragma unroll
         for (int i = 0; i < GP; ++i) {
-            const int row = prow + 32 * i;
             gr[i] = zero4;
             ar[i] = zero4;
-            if (i < pl.npb && px < a.HWp) {
-                const size_t o = ((size_t)q * rows + row) * Mp + goff;
-                if (want_p) gr[i] = *(const u32x4*)(a.g_in + o);
-                if (want_w) ar[i] = *(const u32x4*)(a.a_in + o);
+            if (i < pl.npb) {
+                const int f = wave + 4 * i;
+                const int wsel = f / (pl.npb * 2), rem = f - wsel * pl.npb * 2;
+                const uint32_t so = (uint32_t)((((2 * (ci & 1) + wsel) * pl.npb) * 2 + rem) * 1024);
+                if (want_p) gr[i] = buf_load_b128(grs, (uint32_t)lane * 16u, so);
+                if (want_w) ar[i] = buf_load_b128(ars, (uint32_t)lane * 16u, so);
             }
         }
         if (want_p) {
+            const int px = (ci * SPX_BK_PX) + piece * 8;
+            const bool full = a.vec_ok && px + 8 <= a.HW;
 #pragma unroll
             for (int i = 0; i < XP; ++i) {
                 const int row = prow + 32 * i;
 #pragma unroll
                 for (int w = 0; w < (XF32 ? 2 : 1); ++w) xr[i][w] = zero4;
                 if (row < Cs) {
-                    const size_t o = ((size_t)b * C + ch0 + row) * a.HW + px;
-                    if (XF32) {
-                        const float* src = (const float*)a.x + o;
-                        if (a.vec_ok && px + 8 <= a.HW) {
-                            xr[i][0] = *(const u32x4*)src;
-                            xr[i][1] = *(const u32x4*)(src + 4);
-                        } else {
+                    // rebase per (image, 32-row block): offsets from the tensor base can exceed 4 GiB for large batches
+                    const spx_rsrc xb = make_rsrc_pred((const char*)a.x + ((size_t)b * C + ch0 + 32 * i) * a.HW * ESZ);
+                    const uint32_t vo = ((uint32_t)prow * (uint32_t)a.HW + (uint32_t)px) * ESZ;
+                    if (full) {
+                        xr[i][0] = buf_load_b128(xb, vo, 0);
+                        if (XF32) xr[i][1] = buf_load_b128(xb, vo + 16, 0);
+                    } else if (XF32) {
 #pragma unroll
-                            for (int e = 0; e < 8; ++e)
-                                xr[i][e >> 2][e & 3] = (px + e < a.HW) ? __float_as_uint(src[e]) : 0u;
-                        }
+                        for (int e = 0; e < 8; ++e)
+                            xr[i][e >> 2][e & 3] = __float_as_uint(buf_load_f32(xb, px + e < a.HW ? vo + 4 * e : SPX_OOB, 0));
                     } else {
-                        const uint16_t* src = (const uint16_t*)a.x + o;
-                        if (a.vec_ok && px + 8 <= a.HW) {
-                            xr[i][0] = *(const u32x4*)src;
-                        } else {
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                const uint32_t lo = (px + 2 * e < a.HW) ? src[2 * e] : 0u;
-                                const uint32_t hi = (px + 2 * e + 1 < a.HW) ? src[2 * e + 1] : 0u;
-                                xr[i][0][e] = lo | (hi << 16);
-                            }
+                        for (int e = 0; e < 4; ++e) {
+                            const uint32_t lo = buf_load_u16(xb, px + 2 * e < a.HW ? vo + 4 * e : SPX_OOB, 0);
+                            const uint32_t hi = buf_load_u16(xb, px + 2 * e + 1 < a.HW ? vo + 4 * e + 2 : SPX_OOB, 0);
+                            xr[i][0][e] = lo | (hi << 16);
                         }
                     }
                 }
             }
         }
     };
+
     auto commit = [&](long long c) {
 #pragma unroll
         for (int i = 0; i < GP; ++i) {
             if (i < pl.npb) {
-                const int row = prow + 32 * i;
-                *(u32x4*)(Gs + row * SPX_BK_ROW + piece * 16) = gr[i];
-                *(u32x4*)(As + row * SPX_BK_ROW + piece * 16) = ar[i];
-                // colsum(G) partial of this thread's 8 px of row `row`
-                const bf16x8 gv8 = __builtin_bit_cast(bf16x8, gr[i]);
-                float sum8 = 0.0f;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) sum8 += (float)gv8[j];
-                csum[i] += sum8;
+                // fragment element j of lane (r, h): prototype 16 s2 + 8 (j>>2) + 4 h + (j&3) of block pb, pixel r
+                const int f = wave + 4 * i;
+                const int wsel = f / (pl.npb * 2), rem = f - wsel * pl.npb * 2;
+                const int pb = rem >> 1, s2 = rem & 1;
+                const int off = (wsel * 32 + r) * grow + (pb * 32 + 16 * s2 + 4 * h) * 2;
+                const u32x2 g0 = {gr[i][0], gr[i][1]}, g1 = {gr[i][2], gr[i][3]};
+                const u32x2 a0 = {ar[i][0], ar[i][1]}, a1 = {ar[i][2], ar[i][3]};
+                *(u32x2*)(Gs + off) = g0;
+                *(u32x2*)(Gs + off + 16) = g1;
+                *(u32x2*)(As + off) = a0;
+                *(u32x2*)(As + off + 16) = a1;
             }
         }
 #pragma unroll
@@ -455,11 +637,11 @@ __global__ __launch_bounds__(256, 1) void spx_bank_bwd_kernel(const SpxBankBwdAr
             // dLogits of the chunk's 64 px (contiguous [64][K] floats) -> bf16 [class][px]
             const int b = (int)(c / nci);
             const int px0 = (int)(c - (long long)b * nci) * SPX_BK_PX;
-            const float* src = a.d_logits + ((size_t)b * a.HW + px0) * K;
+            const spx_rsrc lb = make_rsrc_pred(a.d_logits + ((size_t)b * a.HW + px0) * K);
             const int n = SPX_BK_PX * K;
             for (int e = tid; e < n; e += 256) {
                 const int p = e / K, cls = e - p * K;
-                const float v = (px0 + p < a.HW) ? src[e] : 0.0f;
+                const float v = buf_load_f32(lb, px0 + p < a.HW ? (uint32_t)e * 4u : SPX_OOB, 0);
                 *(uint16_t*)(Ls + cls * SPX_BK_ROW + p * 2) = __builtin_bit_cast(uint16_t, (__bf16)v);
             }
         }
@@ -471,6 +653,11 @@ __global__ __launch_bounds__(256, 1) void spx_bank_bwd_kernel(const SpxBankBwdAr
             if (cls >= K) *(uint16_t*)(Ls + cls * SPX_BK_ROW + p * 2) = 0;
         }
     }
+    // transposed-read lane address inside a 16-px k-step of a [px][proto] image (same map as the X image of
+    // the main loop: rows = k, columns = this lane's MFMA row)
+    const int tg = lane >> 4, tli = lane & 15, tq = tli >> 2, tpp = tli & 3;
+    const int tr_off = (8 * (tg >> 1) + tq) * grow + (16 * (tg & 1) + 4 * tpp) * 2;
+
     if (c_begin < c_end) issue(c_begin);
     for (long long c = c_begin; c < c_end; ++c) {
         commit(c);
@@ -490,7 +677,17 @@ __global__ __launch_bounds__(256, 1) void spx_bank_bwd_kernel(const SpxBankBwdAr
 #pragma unroll
                 for (int pb = 0; pb < NPB; ++pb) {
                     if (pb < pl.npb) {
-                        const bf16x8 gf = *(const bf16x8*)(Gs + (pb * 32 + r) * SPX_BK_ROW + koff);
+                        const char* gp = Gs + ks * 16 * grow + tr_off + pb * 64;
+                        const bf16x4 g0 = __builtin_bit_cast(bf16x4, lds_tr_read(gp));
+                        const bf16x4 g1 = __builtin_bit_cast(bf16x4, lds_tr_read(gp + 4 * grow));
+                        const bf16x8 gf = __builtin_shufflevector(g0, g1, 0, 1, 2, 3, 4, 5, 6, 7);
+                        // colsum(G): every lane holds 8 px of its prototype row; lanes r and r+32 cover the k-step
+                        if (wave == (pb & 3)) {
+                            float s8 = 0.0f;
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) s8 += (float)gf[j];
+                            csum[pb] += s8;
+                        }
 #pragma unroll
                         for (int t = 0; t < 2; ++t)
                             if (wave + 4 * t < nchb) accp[pb][t] = mfma_bf16(gf, xb[t], accp[pb][t]);
@@ -502,7 +699,10 @@ __global__ __launch_bounds__(256, 1) void spx_bank_bwd_kernel(const SpxBankBwdAr
                 for (int t = 0; t < 2; ++t) {
                     const int pb = wave + 4 * t;
                     if (pb < pl.npb) {
-                        const bf16x8 af = *(const bf16x8*)(As + (pb * 32 + r) * SPX_BK_ROW + koff);
+                        const char* ap = As + ks * 16 * grow + tr_off + pb * 64;
+                        const bf16x4 a0 = __builtin_bit_cast(bf16x4, lds_tr_read(ap));
+                        const bf16x4 a1 = __builtin_bit_cast(bf16x4, lds_tr_read(ap + 4 * grow));
+                        const bf16x8 af = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
                         for (int cb = 0; cb < NCB; ++cb) {
                             if (cb < pl.ncb) {
@@ -533,16 +733,10 @@ __global__ __launch_bounds__(256, 1) void spx_bank_bwd_kernel(const SpxBankBwdAr
                             slab[(size_t)(pb * 32 + acc_row(reg, h)) * ws + chb * 32 + r] = accp[pb][t][reg];
                     }
                 }
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < GP; ++i) {
-            if (i < pl.npb) {
-                float s = csum[i];
-                s += __shfl_xor(s, 1);
-                s += __shfl_xor(s, 2);
-                s += __shfl_xor(s, 4);
-                if (piece == 0) slab[(size_t)(prow + 32 * i) * ws + nchb * 32 + pl.ncb * 32] = s;
+                if (wave == (pb & 3)) {
+                    const float s = csum[pb] + __shfl_xor(csum[pb], 32);
+                    if (h == 0) slab[(size_t)(pb * 32 + r) * ws + nchb * 32 + pl.ncb * 32] = s;
+                }
             }
         }
     }
@@ -611,7 +805,7 @@ static hipError_t launch_bank_x(const SpxBankBwdArgs& a, int x_dtype, dim3 grid,
 hipError_t spx_launch_bank_bwd(const SpxBankBwdArgs& a, int x_dtype, hipStream_t s) {
     const spx_plan& pl = a.plan;
     const int rows = pl.npb * 32, nchb = (pl.channels_per_scale + 31) / 32;
-    const size_t lds = (size_t)(2 * rows + nchb * 32 + pl.ncb * 32) * SPX_BK_ROW;
+    const size_t lds = (size_t)2 * SPX_BK_PX * spx_bk_grow(pl.npb) + (size_t)(nchb * 32 + pl.ncb * 32) * SPX_BK_ROW;
     dim3 grid((unsigned)a.nsplit, (unsigned)pl.npanels);
     hipError_t e;
     if (pl.ncb <= 1)

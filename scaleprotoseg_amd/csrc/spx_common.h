@@ -48,6 +48,15 @@ __device__ __forceinline__ void buf_store_u16(uint16_t v, spx_rsrc r, uint32_t v
 __device__ __forceinline__ u32x4 buf_load_b128(spx_rsrc r, uint32_t voff, uint32_t soff) {
     return __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
 }
+__device__ __forceinline__ void buf_store_b128(u32x4 v, spx_rsrc r, uint32_t voff, uint32_t soff) {
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, soff, 0);
+}
+__device__ __forceinline__ u32x2 buf_load_b64(spx_rsrc r, uint32_t voff, uint32_t soff) {
+    return __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+}
+__device__ __forceinline__ void buf_store_b64(u32x2 v, spx_rsrc r, uint32_t voff, uint32_t soff) {
+    __builtin_amdgcn_raw_buffer_store_b64(v, r, voff, soff, 0);
+}
 
 // Row of a 32x32 MFMA accumulator held in register `reg` of lane half `h`
 // (cdna guide §3: row = (reg&3) + 8*(reg>>2) + 4*(lane>>5), col = lane&31).

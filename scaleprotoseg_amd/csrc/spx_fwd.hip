@@ -19,7 +19,7 @@ __host__ __device__ inline int spx_fwd_lds_bytes(const spx_plan& pl) {
     return 2 * spx_stage_bytes(pl.kc, pl.npb) + spx_fwd_head_lds_bytes(pl) + pl.npb * 32 * 4;
 }
 
-template <int NPB, int NCB, bool XF32>
+template <int NPB, int NCB, bool XF32, bool ACT_LOG>
 __global__ __launch_bounds__(256, SPX_FWD_WAVES) void spx_fwd_kernel(const SpxFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const spx_plan& pl = a.plan;
@@ -52,6 +52,10 @@ __global__ __launch_bounds__(256, SPX_FWD_WAVES) void spx_fwd_kernel(const SpxFw
     for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
         for (int i = 0; i < 16; ++i) accl[cb][i] = 0.0f;
+#pragma unroll
+    for (int pb = 0; pb < NPB; ++pb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[pb][i] = 0.0f;
     float x2part = 0.0f;
 
     const int px = px0 + 32 * wave + r;        // this lane's pixel
@@ -77,16 +81,20 @@ __global__ __launch_bounds__(256, SPX_FWD_WAVES) void spx_fwd_kernel(const SpxFw
         if (tid < pl.npb * 32) p2s[tid] = buf_load_f32(p2r, (uint32_t)tid * 4u, (uint32_t)(panel * pl.npb * 32 * 4));
     };
 
+    // Panel epilogue as a ROLLED loop over the panel's 32-prototype blocks: the block being finished is always
+    // acc[0] and the accumulator array is rotated after each block (NPB-1 register-tile moves), so the body is
+    // compiled once with a small, fixed register footprint instead of NPB unrolled copies.
     auto epilogue = [&](int panel) {
         const float x2 = x2part + __shfl_xor(x2part, 32);
         const int p0 = pl.panel_p0[panel], np = pl.panel_np[panel];
-#pragma unroll
-        for (int pb = 0; pb < NPB; ++pb) {
-            if (pb < pl.npb && pb * 32 < np) {
+#pragma unroll 1
+        for (int pb = 0; pb < pl.npb; ++pb) {
+            if (pb * 32 < np) {
                 const spx_rsrc dr = make_rsrc_pred(a.dist ? a.dist + ((size_t)b * P + p0 + pb * 32) * a.HW : nullptr);
                 const spx_rsrc ar = make_rsrc_pred(a.act ? a.act + (size_t)b * a.HW * P + p0 + pb * 32 : nullptr);
                 const bool full = pb * 32 + 32 <= np;       // wave-uniform: no per-row predication needed
-                float av[16];
+                // all arithmetic first (one straight-line block), then the stores under wave-uniform conditions
+                float dv[16], av[16];
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
                     // rows 8*g4 + 4h + (0..3) of the block <-> registers 4*g4..4*g4+3
@@ -94,13 +102,25 @@ __global__ __launch_bounds__(256, SPX_FWD_WAVES) void spx_fwd_kernel(const SpxFw
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int reg = 4 * g4 + e;
-                        float d = __builtin_fmaf(-2.0f, acc[pb][reg], p2v[e]) + x2;
-                        d = fmaxf(d, 0.0f);
-                        const bool row_ok = full || (pb * 32 + 8 * g4 + 4 * h + e < np);
-                        if (a.dist) buf_store_f32(d, dr, row_ok ? voff_d : SPX_OOB, (uint32_t)(8 * g4 + e) * HW * 4u);
-                        const float act = a.act_fn == 0 ? act_log(d, a.eps) : -d;
-                        if (a.act) buf_store_f32(act, ar, row_ok ? voff_a : SPX_OOB, (uint32_t)((8 * g4 + e) * 4));
-                        av[reg] = act;
+                        const float d = fmaxf(__builtin_fmaf(-2.0f, acc[0][reg], p2v[e]) + x2, 0.0f);
+                        dv[reg] = d;
+                        av[reg] = ACT_LOG ? act_log(d, a.eps) : -d;
+                    }
+                }
+                if (a.dist) {
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        const int rb = (reg & 3) + 8 * (reg >> 2);
+                        const uint32_t vo = (full || (pb * 32 + rb + 4 * h < np)) ? voff_d : SPX_OOB;
+                        buf_store_f32(dv[reg], dr, vo, (uint32_t)rb * HW * 4u);
+                    }
+                }
+                if (a.act) {
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        const int rb = (reg & 3) + 8 * (reg >> 2);
+                        const uint32_t vo = (full || (pb * 32 + rb + 4 * h < np)) ? voff_a : SPX_OOB;
+                        buf_store_f32(av[reg], ar, vo, (uint32_t)(rb * 4));
                     }
                 }
                 if (want_head) {
@@ -135,6 +155,11 @@ __global__ __launch_bounds__(256, SPX_FWD_WAVES) void spx_fwd_kernel(const SpxFw
                     }
                 }
             }
+            // rotate: next block -> acc[0]; the vacated slot is zero (= the next panel's initial accumulator)
+#pragma unroll
+            for (int i = 0; i + 1 < NPB; ++i) acc[i] = acc[i + 1];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[NPB - 1][i] = 0.0f;
         }
     };
 
@@ -144,10 +169,6 @@ __global__ __launch_bounds__(256, SPX_FWD_WAVES) void spx_fwd_kernel(const SpxFw
     auto do_step = [&](int step, SpxStager<NPB, XF32>& far, SpxStager<NPB, XF32>& nxt) {
         const int panel = step / nchunks, chunk = step - panel * nchunks;
         if (chunk == 0) {
-#pragma unroll
-            for (int pb = 0; pb < NPB; ++pb)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) acc[pb][i] = 0.0f;
             x2part = 0.0f;
             stage_panel_consts(panel);
         }
@@ -198,10 +219,14 @@ __global__ __launch_bounds__(256, SPX_FWD_WAVES) void spx_fwd_kernel(const SpxFw
 
 template <int NPB, int NCB>
 static hipError_t launch_fwd_x(const SpxFwdArgs& a, int x_dtype, dim3 grid, size_t lds, hipStream_t s) {
-    if (x_dtype == 1)
-        hipLaunchKernelGGL((spx_fwd_kernel<NPB, NCB, true>), grid, dim3(256), lds, s, a);
-    else
-        hipLaunchKernelGGL((spx_fwd_kernel<NPB, NCB, false>), grid, dim3(256), lds, s, a);
+    const bool lg = a.act_fn == 0;
+    if (x_dtype == 1) {
+        if (lg) hipLaunchKernelGGL((spx_fwd_kernel<NPB, NCB, true, true>), grid, dim3(256), lds, s, a);
+        else hipLaunchKernelGGL((spx_fwd_kernel<NPB, NCB, true, false>), grid, dim3(256), lds, s, a);
+    } else {
+        if (lg) hipLaunchKernelGGL((spx_fwd_kernel<NPB, NCB, false, true>), grid, dim3(256), lds, s, a);
+        else hipLaunchKernelGGL((spx_fwd_kernel<NPB, NCB, false, false>), grid, dim3(256), lds, s, a);
+    }
     return hipGetLastError();
 }
 

@@ -19,6 +19,7 @@
 
 struct SpxTileCtx {
     spx_rsrc xr;          // features of image b (buffer resource over channel 0, pixel 0)
+    spx_rsrc xp;          // same base, range-checked (offsets >= 2 GiB are dropped): predicated element loads
     spx_rsrc br;          // packed bank fragments
     uint32_t x_voff;      // this thread's byte offset inside a 16-row pass: (row0 * HW + px) * esz
     uint32_t hw;          // pixels per image
@@ -38,6 +39,7 @@ struct SpxStager {
                                                          int vec_ok, int tid) {
         SpxTileCtx t;
         t.xr = make_rsrc(x_img);
+        t.xp = make_rsrc_pred(x_img);
         t.br = make_rsrc(packed_bank);
         t.hw = (uint32_t)hw;
         t.px = px0 + (tid & 15) * 8;
@@ -59,16 +61,17 @@ struct SpxStager {
                     xr[i][0] = buf_load_b128(t.xr, t.x_voff, soff);
                     if (XF32) xr[i][1] = buf_load_b128(t.xr, t.x_voff + 16, soff);
                 } else if (XF32) {
+                    // unaligned / tail pieces: element loads, predicated by an out-of-range offset (no branches)
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         const bool ok = (uint32_t)(t.px + e) < t.hw;
-                        xr[i][e >> 2][e & 3] = ok ? __builtin_amdgcn_raw_buffer_load_b32(t.xr, t.x_voff + 4 * e, soff, 0) : 0u;
+                        xr[i][e >> 2][e & 3] = __builtin_amdgcn_raw_buffer_load_b32(t.xp, ok ? t.x_voff + 4 * e : SPX_OOB, soff, 0);
                     }
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const uint32_t lo = ((uint32_t)(t.px + 2 * e) < t.hw) ? buf_load_u16(t.xr, t.x_voff + 4 * e, soff) : 0u;
-                        const uint32_t hi = ((uint32_t)(t.px + 2 * e + 1) < t.hw) ? buf_load_u16(t.xr, t.x_voff + 4 * e + 2, soff) : 0u;
+                        const uint32_t lo = buf_load_u16(t.xp, ((uint32_t)(t.px + 2 * e) < t.hw) ? t.x_voff + 4 * e : SPX_OOB, soff);
+                        const uint32_t hi = buf_load_u16(t.xp, ((uint32_t)(t.px + 2 * e + 1) < t.hw) ? t.x_voff + 4 * e + 2 : SPX_OOB, soff);
                         xr[i][0][e] = lo | (hi << 16);
                     }
                 }

@@ -158,12 +158,11 @@ class _ProtoHeadFn(torch.autograd.Function):
         pp = C.byref(plan)
         dev = x.device
         xd = _x_dtype_code(x)
-        HWp = (HW + 7) & ~7
-        rows = lib.spx_gpad_rows(pp)
+        scr = lib.spx_bwd_scratch_bytes(pp, B, HW)
         need_head = need_head and gl is not None
         dx = torch.empty_like(x) if need_x else None
-        g_scr = torch.empty((rows, B * HWp), dtype=torch.bfloat16, device=dev) if need_bank else None
-        a_scr = torch.empty((rows, B * HWp), dtype=torch.bfloat16, device=dev) if need_head else None
+        g_scr = torch.empty(scr, dtype=torch.uint8, device=dev) if need_bank else None
+        a_scr = torch.empty(scr, dtype=torch.uint8, device=dev) if need_head else None
         s = _lib.stream_ptr()
         with _timed("spx_dist_bwd"):
             _lib.check(
