@@ -24,14 +24,16 @@ static int check_plan(const spx_plan* pl) {
     if (pl->npanels < 1 || pl->npanels > SPX_MAX_PANELS) return fail("plan: npanels %d out of range", pl->npanels);
     if (pl->npb < 1 || pl->npb > 6) return fail("plan: npb %d out of range", pl->npb);
     if (pl->ncb < 1 || pl->ncb > 5) return fail("plan: ncb %d out of range", pl->ncb);
-    if (pl->kc != 16 && pl->kc != 32) return fail("plan: kc %d", pl->kc);
-    if (pl->channels_per_scale % pl->kc) return fail("plan: Cs %d not a multiple of kc", pl->channels_per_scale);
+    if (pl->kc != 32) return fail("plan: kc %d", pl->kc);
+    if (pl->npb != 2 && pl->npb != 4 && pl->npb != 6) return fail("plan: npb %d (must be 2, 4 or 6)", pl->npb);
+    if (pl->ncb != 1 && pl->ncb != 5) return fail("plan: ncb %d (must be 1 or 5)", pl->ncb);
     return 0;
 }
 static int x_vec_ok(const void* x, int x_dtype, int HW) {
     const uintptr_t p = (uintptr_t)x;
     if (p & 15) return 0;
-    return x_dtype == 1 ? (HW % 4 == 0) : (HW % 8 == 0);
+    (void)x_dtype;
+    return HW % 8 == 0;   /* staging pieces are 8 pixels: they must be wholly inside or outside an image row */
 }
 
 extern "C" {
@@ -49,8 +51,8 @@ int spx_make_plan(int32_t P, int32_t K, int32_t S, int32_t Cs, const int32_t* lo
     out->num_classes = K;
     out->num_scales = S;
     out->channels_per_scale = Cs;
-    out->kc = (Cs % 32 == 0) ? 32 : 16;
-    out->ncb = (K + 31) / 32;
+    out->kc = 32;                              /* chunks of 32 channels; a 16-channel tail is zero-filled */
+    out->ncb = (K <= 32) ? 1 : 5;              /* the kernels are specialised for 1 or 5 class blocks */
     int per_max = 1, covered = 0;
     for (int s = 0; s < S; ++s) {
         const int n = hi[s] - lo[s];
@@ -64,7 +66,7 @@ int spx_make_plan(int32_t P, int32_t K, int32_t S, int32_t Cs, const int32_t* lo
     }
     // the reference's F.linear rejects a distance map narrower than the head (P % S != 0): same here
     if (covered != P) return fail("spx_make_plan: scale table covers %d prototypes but the bank has %d (reference needs P %% S == 0)", covered, P);
-    out->npb = (per_max + 31) / 32;
+    out->npb = ((per_max + 63) / 64) * 2;      /* panel height in 32-prototype blocks: 2, 4 or 6 */
     const int cap = out->npb * 32;
     int q = 0;
     for (int s = 0; s < S; ++s) {
@@ -84,7 +86,7 @@ int spx_make_plan(int32_t P, int32_t K, int32_t S, int32_t Cs, const int32_t* lo
 size_t spx_bwd_scratch_bytes(const spx_plan* pl, int32_t B, int32_t HW) { return spx_bwd_scratch_elems(*pl, B, HW) * 2; }
 
 size_t spx_packed_bank_bytes(const spx_plan* pl) {
-    return (size_t)pl->npanels * pl->npb * 32 * pl->channels_per_scale * 2;
+    return (size_t)pl->npanels * pl->npb * 32 * (((pl->channels_per_scale + 31) / 32) * 32) * 2;
 }
 size_t spx_packed_bankT_bytes(const spx_plan* pl) {
     return (size_t)pl->npanels * pl->npb * 2 * ((pl->channels_per_scale + 31) / 32) * 1024;

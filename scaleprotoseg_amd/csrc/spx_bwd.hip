@@ -31,17 +31,17 @@
 #define SPX_T_ROW 528                     // fp32 transpose tile row: 128 px * 4 B + 16 B pad
 #define SPX_T_BYTES (32 * SPX_T_ROW)
 
-__host__ __device__ inline int spx_bwd_head_lds_bytes(const spx_plan& pl) {
-    const int b = pl.npb * pl.ncb * 2 * 2048;
-    return b <= 32768 ? b : 0;
-}
-__host__ __device__ inline int spx_bwd_region0_bytes(const spx_plan& pl) {
-    const int a = 2 * spx_stage_bytes(pl.kc, pl.npb);
-    const int b = 2 * SPX_BT_BYTES + 2 * SPX_T_BYTES;
+template <int NPB, int NCB>
+__host__ __device__ constexpr int spx_bwd_head_lds_bytes() { return NCB == 1 ? NPB * 2 * 2048 : 0; }
+template <int NPB>
+__host__ __device__ constexpr int spx_bwd_region0_bytes() {
+    constexpr int a = 2 * spx_stage_bytes(NPB);
+    constexpr int b = 2 * SPX_BT_BYTES + 2 * SPX_T_BYTES;
     return a > b ? a : b;
 }
-__host__ __device__ inline int spx_bwd_lds_bytes(const spx_plan& pl) {
-    return spx_bwd_region0_bytes(pl) + spx_bwd_head_lds_bytes(pl) + pl.npb * 32 * 4 + SPX_TILE_PX * 4;
+template <int NPB, int NCB>
+__host__ __device__ constexpr int spx_bwd_lds_bytes() {
+    return spx_bwd_region0_bytes<NPB>() + spx_bwd_head_lds_bytes<NPB, NCB>() + NPB * 32 * 4 + SPX_TILE_PX * 4;
 }
 // bf16 elements of one G (or a) scratch: [panel][tile][wave][pb][s2] fragments of 512 elements
 size_t spx_bwd_scratch_elems(const spx_plan& pl, int B, int HW) {
@@ -52,7 +52,7 @@ size_t spx_bwd_scratch_elems(const spx_plan& pl, int B, int HW) {
 // ------------------------------------------------------------------------------------------------
 // kernel 1: pixel side
 // ------------------------------------------------------------------------------------------------
-template <int NPB, int NCB, bool XF32, bool ACT_LOG>
+template <int NPB, int NCB, bool XF32, bool VEC>
 __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const spx_plan& pl = a.plan;
@@ -68,22 +68,21 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
     const int C = pl.num_scales * Cs;
     const int P = pl.num_prototypes, K = pl.num_classes;
     const int nchb = (Cs + 31) / 32;
-    const int ncstep = pl.ncb * 2;
+    constexpr int ncstep = NCB * 2;
     const uint32_t HW = (uint32_t)a.HW;
     constexpr int ESZ = XF32 ? 4 : 2;
+    using Stager = SpxStager<NPB, XF32, VEC>;
 
     const char* x_img = (const char*)a.x + (size_t)b * C * a.HW * ESZ;
-    const SpxTileCtx tc = SpxStager<NPB, XF32>::make_ctx(x_img, a.packed_bank, a.HW, px0, a.vec_ok, tid);
+    const SpxTileCtx tc = Stager::make_ctx(x_img, a.HW, px0, tid);
 
-    const int stage = spx_stage_bytes(pl.kc, pl.npb);
-    const int xs_bytes = pl.kc * SPX_XROW * 2;
-    const int nchunks = Cs / pl.kc;
-    const int nks = pl.kc >> 4;
-    const uint32_t chunk_bytes = (uint32_t)(pl.npb * nks * 1024);
-    const int head_lds = spx_bwd_head_lds_bytes(pl);
-    char* const hlds = smem + spx_bwd_region0_bytes(pl);
+    constexpr int stage = spx_stage_bytes(NPB);
+    constexpr int chunk_bytes = NPB * 2 * 1024;
+    constexpr int head_lds = spx_bwd_head_lds_bytes<NPB, NCB>();
+    const int nchunks = (Cs + SPX_KC - 1) / SPX_KC;
+    char* const hlds = smem + spx_bwd_region0_bytes<NPB>();
     float* const p2s = (float*)(hlds + head_lds);
-    float* const rss = p2s + pl.npb * 32;
+    float* const rss = p2s + NPB * 32;
 
     const int px = px0 + 32 * wave + r;
     const bool px_ok = px < a.HW;
@@ -103,7 +102,7 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int cls = c * 16 + 8 * h + j;
-                const float v = buf_load_f32(lr, (c < ncstep && cls < K) ? voff_l : SPX_OOB, (uint32_t)((c * 16 + j) * 4));
+                const float v = buf_load_f32(lr, cls < K ? voff_l : SPX_OOB, (uint32_t)((c * 16 + j) * 4));
                 __bf16 hi, lo;
                 split_bf16(v, hi, lo);
                 dlhi[c][j] = hi;
@@ -112,7 +111,7 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
         }
     }
 
-    SpxStager<NPB, XF32> stA, stB;
+    Stager stA, stB;
     f32x16 acc[NPB];
 #pragma unroll
     for (int pb = 0; pb < NPB; ++pb)
@@ -121,12 +120,15 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
     float x2part = 0.0f;
 
     auto stage_panel_consts = [&](int panel) {
-        if (a.d_logits && head_lds) {
-            const uint32_t so = (uint32_t)(panel * pl.npb * ncstep * 2048);
-            for (int off = tid * 16; off < head_lds; off += 256 * 16) *(u32x4*)(hlds + off) = buf_load_b128(htr, (uint32_t)off, so);
+        if (head_lds && a.d_logits) {
+#pragma unroll
+            for (int i = 0; i < head_lds / 4096; ++i)
+                *(u32x4*)(hlds + i * 4096 + tid * 16) = buf_load_b128(htr, (uint32_t)(i * 4096 + tid * 16), (uint32_t)(panel * head_lds));
         }
-        if (tid < pl.npb * 32) p2s[tid] = buf_load_f32(p2r, (uint32_t)tid * 4u, (uint32_t)(panel * pl.npb * 32 * 4));
+        if (tid < NPB * 32) p2s[tid] = buf_load_f32(p2r, (uint32_t)tid * 4u, (uint32_t)(panel * NPB * 32 * 4));
     };
+
+    const bool act_is_log = a.act_fn == 0;
 
     // ---------------- panel epilogue ----------------
     auto epilogue = [&](int panel) {
@@ -135,7 +137,7 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
         const int ch0 = pl.panel_ch0[panel];
         const int nv = (np + 31) >> 5;                   // prototype blocks holding >= 1 real prototype
         const size_t tile_g = (size_t)b * tiles_per_img + tile_i;
-        const size_t blob0 = (((size_t)panel * ntiles + tile_g) * 4) * pl.npb * 2 * 1024;   // bytes
+        const size_t blob0 = (((size_t)panel * ntiles + tile_g) * 4) * NPB * 2 * 1024;   // bytes
         const spx_rsrc gr = make_rsrc(a.g_out ? (const char*)a.g_out + blob0 : nullptr);
         const spx_rsrc ar = make_rsrc(a.a_out ? (const char*)a.a_out + blob0 : nullptr);
 
@@ -196,22 +198,20 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
                 for (int i = 0; i < 16; ++i) ga[i] = 0.0f;
                 if (a.d_logits) {
 #pragma unroll
-                    for (int c = 0; c < NCB * 2; ++c) {
-                        if (c < ncstep) {
-                            bf16x8 whi, wlo;
-                            if (head_lds) {
-                                const char* wf = hlds + (pb * ncstep + c) * 2048 + lane * 16;
-                                whi = *(const bf16x8*)wf;
-                                wlo = *(const bf16x8*)(wf + 1024);
-                            } else {
-                                const uint32_t so = (uint32_t)(((panel * pl.npb + pb) * ncstep + c) * 2048);
-                                whi = __builtin_bit_cast(bf16x8, buf_load_b128(htr, (uint32_t)lane * 16u, so));
-                                wlo = __builtin_bit_cast(bf16x8, buf_load_b128(htr, (uint32_t)lane * 16u, so + 1024u));
-                            }
-                            ga = mfma_bf16(whi, dlhi[c], ga);
-                            ga = mfma_bf16(wlo, dlhi[c], ga);
-                            ga = mfma_bf16(whi, dllo[c], ga);
+                    for (int c = 0; c < ncstep; ++c) {
+                        bf16x8 whi, wlo;
+                        if (head_lds) {
+                            const char* wf = hlds + (pb * ncstep + c) * 2048 + lane * 16;
+                            whi = *(const bf16x8*)wf;
+                            wlo = *(const bf16x8*)(wf + 1024);
+                        } else {
+                            const uint32_t so = (uint32_t)(((panel * NPB + pb) * ncstep + c) * 2048);
+                            whi = __builtin_bit_cast(bf16x8, buf_load_b128(htr, (uint32_t)lane * 16u, so));
+                            wlo = __builtin_bit_cast(bf16x8, buf_load_b128(htr, (uint32_t)lane * 16u, so + 1024u));
                         }
+                        ga = mfma_bf16(whi, dlhi[c], ga);
+                        ga = mfma_bf16(wlo, dlhi[c], ga);
+                        ga = mfma_bf16(whi, dllo[c], ga);
                     }
                 }
 #pragma unroll
@@ -223,8 +223,8 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
                         const bool valid = px_ok && (full || (pb * 32 + 8 * g4 + 4 * h + e < np));
                         const float d_raw = __builtin_fmaf(-2.0f, acc[0][reg], p2v[e]) + x2;
                         const float d = fmaxf(d_raw, 0.0f);
-                        const float dact = ACT_LOG ? act_log_grad(d, a.eps) : -1.0f;
-                        const float aval = ACT_LOG ? act_log(d, a.eps) : -d;
+                        const float dact = act_is_log ? act_log_grad(d, a.eps) : -1.0f;
+                        const float aval = act_is_log ? act_log(d, a.eps) : -d;
                         const float G = (valid && d_raw > 0.0f) ? ddc[reg] + (ga[reg] + dac[reg]) * dact : 0.0f;
                         rs += G;
                         // register reg = 8 s2 + j of the tile -> element j of k-step s2 of the B fragment
@@ -233,11 +233,11 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
                     }
                 }
             }
-            if (pb < pl.npb) {
+            {
                 // fragment dump for kernel 2 (wholly padded blocks are written as zeros: kernel 2 reads them)
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
-                    const uint32_t so = (uint32_t)(((wave * pl.npb + pb) * 2 + s2) * 1024);
+                    const uint32_t so = (uint32_t)(((wave * NPB + pb) * 2 + s2) * 1024);
                     if (a.g_out) buf_store_b128(__builtin_bit_cast(u32x4, gnew[s2]), gr, (uint32_t)lane * 16u, so);
                     if (a.a_out) buf_store_b128(__builtin_bit_cast(u32x4, anew[s2]), ar, (uint32_t)lane * 16u, so);
                 }
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
 #pragma unroll
             for (int i = 0; i < BTP; ++i) {
                 const int f = wave + 4 * i;
-                const uint32_t so = (uint32_t)((((panel * pl.npb) * 2 + f) * nchb + chb) * 1024);
+                const uint32_t so = (uint32_t)((((panel * NPB) * 2 + f) * nchb + chb) * 1024);
                 bt_reg[i] = buf_load_b128(btr, (f < 2 * nv) ? (uint32_t)lane * 16u : SPX_OOB, so);
             }
         };
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
             const spx_rsrc xir = make_rsrc_pred(x_img + (size_t)(ch0 + chb * 32) * a.HW * ESZ);
             const spx_rsrc dxr = make_rsrc_pred((char*)a.dx + ((size_t)b * C + ch0 + chb * 32) * a.HW * ESZ);
             float xv[16], pv[16];
-            if (a.vec_ok) {
+            if (VEC) {
 #pragma unroll
                 for (int v = 0; v < NV; ++v) {
                     const bool ok = ch_ok && (fpx + (v + 1) * PV <= a.HW);
@@ -372,7 +372,7 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
 #pragma unroll
                 for (int e = 0; e < 4; ++e) ov[4 * v + e] = pv[4 * v + e] + 2.0f * (rv[e] * xv[4 * v + e] - tv[e]);
             }
-            if (a.vec_ok) {
+            if (VEC) {
 #pragma unroll
                 for (int v = 0; v < NV; ++v) {
                     const bool ok = ch_ok && (fpx + (v + 1) * PV <= a.HW);
@@ -405,32 +405,30 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
         __syncthreads();   // T tiles / P^T stages are rewritten by the next panel's main loop
     };
 
-    // Software pipeline inside a panel: global loads run two K-chunks ahead of the MFMAs.  Nothing is kept in
-    // flight across the epilogue (its register budget is the binding one).
-    auto do_chunk = [&](int panel, int chunk, SpxStager<NPB, XF32>& far, SpxStager<NPB, XF32>& nxt) {
-        const uint32_t bank0 = (uint32_t)(panel * nchunks) * chunk_bytes;
-        if (chunk + 2 < nchunks)
-            far.load(tc, pl, bank0 + (uint32_t)(chunk + 2) * chunk_bytes, pl.panel_ch0[panel] + (chunk + 2) * pl.kc, tid);
+    // Software pipeline inside a panel (see spx_fwd.hip): branch-free body, global loads two chunks ahead.
+    // Nothing is kept in flight across the epilogue (its register budget is the binding one).
+    auto do_chunk = [&](const char* bank0, int ch0, int chunk, Stager& far, Stager& nxt) {
+        far.load(tc, bank0 + (size_t)(chunk + 2) * chunk_bytes, ch0 + (chunk + 2) * SPX_KC, Cs - (chunk + 2) * SPX_KC, tid);
         char* cur = smem + (chunk & 1) * stage;
-        spx_compute_chunk<NPB>(acc, x2part, pl, cur, cur + xs_bytes, lane, wave);
-        if (chunk + 1 < nchunks) {
-            char* dst = smem + ((chunk + 1) & 1) * stage;
-            nxt.write(pl, dst, dst + xs_bytes, tid);
-        }
+        spx_compute_chunk<NPB>(acc, x2part, cur, cur + SPX_STAGE_X_BYTES, lane, wave);
+        char* dst = smem + ((chunk + 1) & 1) * stage;
+        nxt.write(dst, dst + SPX_STAGE_X_BYTES, tid);
         __syncthreads();
     };
 
+    const int nch_even = (nchunks + 1) & ~1;      // chunk pairs; an odd tail chunk is all zeros
     for (int panel = 0; panel < pl.npanels; ++panel) {
-        const uint32_t bank0 = (uint32_t)(panel * nchunks) * chunk_bytes;
+        const char* bank0 = a.packed_bank + (size_t)(panel * nchunks) * chunk_bytes;
+        const int ch0 = pl.panel_ch0[panel];
         x2part = 0.0f;
         stage_panel_consts(panel);
-        stA.load(tc, pl, bank0, pl.panel_ch0[panel], tid);
-        if (nchunks > 1) stB.load(tc, pl, bank0 + chunk_bytes, pl.panel_ch0[panel] + pl.kc, tid);
-        stA.write(pl, smem, smem + xs_bytes, tid);
+        stA.load(tc, bank0, ch0, Cs, tid);
+        stB.load(tc, bank0 + chunk_bytes, ch0 + SPX_KC, Cs - SPX_KC, tid);
+        stA.write(smem, smem + SPX_STAGE_X_BYTES, tid);
         __syncthreads();
-        for (int chunk = 0; chunk < nchunks; chunk += 2) {
-            do_chunk(panel, chunk, stA, stB);
-            if (chunk + 1 < nchunks) do_chunk(panel, chunk + 1, stB, stA);
+        for (int chunk = 0; chunk < nch_even; chunk += 2) {
+            do_chunk(bank0, ch0, chunk, stA, stB);
+            do_chunk(bank0, ch0, chunk + 1, stB, stA);
         }
 #ifdef SPX_DIAG_SKIP_EPILOGUE
         if (a.eps > 1e30f) epilogue(panel);   // timing-only build: keeps the code alive, never runs it
@@ -443,13 +441,13 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
 }
 
 template <int NPB, int NCB>
-static hipError_t launch_bwd_x(const SpxBwdArgs& a, int x_dtype, dim3 grid, size_t lds, hipStream_t s) {
-    const bool lg = a.act_fn == 0;
+static hipError_t launch_bwd_x(const SpxBwdArgs& a, int x_dtype, dim3 grid, hipStream_t s) {
+    constexpr size_t lds = (size_t)spx_bwd_lds_bytes<NPB, NCB>();
     if (x_dtype == 1) {
-        if (lg) hipLaunchKernelGGL((spx_bwd_kernel<NPB, NCB, true, true>), grid, dim3(256), lds, s, a);
+        if (a.vec_ok) hipLaunchKernelGGL((spx_bwd_kernel<NPB, NCB, true, true>), grid, dim3(256), lds, s, a);
         else hipLaunchKernelGGL((spx_bwd_kernel<NPB, NCB, true, false>), grid, dim3(256), lds, s, a);
     } else {
-        if (lg) hipLaunchKernelGGL((spx_bwd_kernel<NPB, NCB, false, true>), grid, dim3(256), lds, s, a);
+        if (a.vec_ok) hipLaunchKernelGGL((spx_bwd_kernel<NPB, NCB, false, true>), grid, dim3(256), lds, s, a);
         else hipLaunchKernelGGL((spx_bwd_kernel<NPB, NCB, false, false>), grid, dim3(256), lds, s, a);
     }
     return hipGetLastError();
@@ -459,12 +457,14 @@ hipError_t spx_launch_bwd(const SpxBwdArgs& a, int x_dtype, hipStream_t s) {
     const spx_plan& pl = a.plan;
     const int tiles = (a.HW + SPX_TILE_PX - 1) / SPX_TILE_PX;
     dim3 grid((unsigned)(tiles * a.B));
-    const size_t lds = (size_t)spx_bwd_lds_bytes(pl);
-    if (pl.ncb <= 1) {
-        if (pl.npb <= 2) return launch_bwd_x<2, 1>(a, x_dtype, grid, lds, s);
-        return launch_bwd_x<6, 1>(a, x_dtype, grid, lds, s);
+    if (pl.ncb == 1) {
+        if (pl.npb == 2) return launch_bwd_x<2, 1>(a, x_dtype, grid, s);
+        if (pl.npb == 4) return launch_bwd_x<4, 1>(a, x_dtype, grid, s);
+        return launch_bwd_x<6, 1>(a, x_dtype, grid, s);
     }
-    return launch_bwd_x<6, 5>(a, x_dtype, grid, lds, s);
+    if (pl.npb == 2) return launch_bwd_x<2, 5>(a, x_dtype, grid, s);
+    if (pl.npb == 4) return launch_bwd_x<4, 5>(a, x_dtype, grid, s);
+    return launch_bwd_x<6, 5>(a, x_dtype, grid, s);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -10,42 +10,40 @@
 #define SPX_FWD_WAVES 2
 #endif
 
-// LDS carve (bytes): [stage 0][stage 1][head fragments of the current panel][|p|^2 of the panel]
-__host__ __device__ inline int spx_fwd_head_lds_bytes(const spx_plan& pl) {
-    const int b = pl.ncb * pl.npb * 4096;
-    return b <= 32768 ? b : 0;          // large heads (ADE: 5 class blocks) stream their fragments from L2 instead
-}
-__host__ __device__ inline int spx_fwd_lds_bytes(const spx_plan& pl) {
-    return 2 * spx_stage_bytes(pl.kc, pl.npb) + spx_fwd_head_lds_bytes(pl) + pl.npb * 32 * 4;
+// LDS carve (bytes): [stage 0][stage 1][head fragments of the current panel (NCB == 1 only)][|p|^2 of the panel]
+template <int NPB, int NCB>
+__host__ __device__ constexpr int spx_fwd_head_lds_bytes() { return NCB == 1 ? NPB * 4096 : 0; }
+template <int NPB, int NCB>
+__host__ __device__ constexpr int spx_fwd_lds_bytes() {
+    return 2 * spx_stage_bytes(NPB) + spx_fwd_head_lds_bytes<NPB, NCB>() + NPB * 32 * 4;
 }
 
-template <int NPB, int NCB, bool XF32, bool ACT_LOG>
+template <int NPB, int NCB, bool XF32, bool VEC>
 __global__ __launch_bounds__(256, SPX_FWD_WAVES) void spx_fwd_kernel(const SpxFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const spx_plan& pl = a.plan;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
     const int tiles_per_img = (a.HW + SPX_TILE_PX - 1) / SPX_TILE_PX;
     const int b = blockIdx.x / tiles_per_img;
     const int px0 = (blockIdx.x % tiles_per_img) * SPX_TILE_PX;
-    const int C = pl.num_scales * pl.channels_per_scale;
+    const int Cs = pl.channels_per_scale;
+    const int C = pl.num_scales * Cs;
     const int P = pl.num_prototypes, K = pl.num_classes;
     const uint32_t HW = (uint32_t)a.HW;
+    using Stager = SpxStager<NPB, XF32, VEC>;
 
-    const SpxTileCtx tc = SpxStager<NPB, XF32>::make_ctx(
-        (const char*)a.x + (size_t)b * C * a.HW * (XF32 ? 4 : 2), a.packed_bank, a.HW, px0, a.vec_ok, tid);
+    const SpxTileCtx tc = Stager::make_ctx((const char*)a.x + (size_t)b * C * a.HW * (XF32 ? 4 : 2), a.HW, px0, tid);
 
-    const int stage = spx_stage_bytes(pl.kc, pl.npb);
-    const int xs_bytes = pl.kc * SPX_XROW * 2;
-    const int nchunks = pl.channels_per_scale / pl.kc;
-    const int nks = pl.kc >> 4;
-    const uint32_t chunk_bytes = (uint32_t)(pl.npb * nks * 1024);
-    const int total = pl.npanels * nchunks;
-    const int head_lds = spx_fwd_head_lds_bytes(pl);
+    constexpr int stage = spx_stage_bytes(NPB);
+    constexpr int chunk_bytes = NPB * 2 * 1024;
+    constexpr int head_lds = spx_fwd_head_lds_bytes<NPB, NCB>();
+    const int nchunks = (Cs + SPX_KC - 1) / SPX_KC;
     char* const wlds = smem + 2 * stage;
     float* const p2s = (float*)(wlds + head_lds);
 
-    SpxStager<NPB, XF32> stA, stB;
+    Stager stA, stB;
     f32x16 acc[NPB];
     f32x16 accl[NCB];
 #pragma unroll
@@ -70,15 +68,12 @@ __global__ __launch_bounds__(256, SPX_FWD_WAVES) void spx_fwd_kernel(const SpxFw
 
     // panel prologue: head fragments + |p|^2 of the panel -> LDS (read in the epilogue, after >= 1 barrier)
     auto stage_panel_consts = [&](int panel) {
-        if (want_head && head_lds) {
-            const int per_cb = pl.npb * 4096;
-            for (int off = tid * 16; off < head_lds; off += 256 * 16) {
-                const int cb = off / per_cb, rem = off - cb * per_cb;
-                const uint32_t so = (uint32_t)((cb * pl.npanels + panel) * per_cb);
-                *(u32x4*)(wlds + off) = buf_load_b128(hr, (uint32_t)rem, so);
-            }
+        if (head_lds && want_head) {
+#pragma unroll
+            for (int i = 0; i < head_lds / 4096; ++i)
+                *(u32x4*)(wlds + i * 4096 + tid * 16) = buf_load_b128(hr, (uint32_t)(i * 4096 + tid * 16), (uint32_t)(panel * head_lds));
         }
-        if (tid < pl.npb * 32) p2s[tid] = buf_load_f32(p2r, (uint32_t)tid * 4u, (uint32_t)(panel * pl.npb * 32 * 4));
+        if (tid < NPB * 32) p2s[tid] = buf_load_f32(p2r, (uint32_t)tid * 4u, (uint32_t)(panel * NPB * 32 * 4));
     };
 
     // Panel epilogue as a ROLLED loop over the panel's 32-prototype blocks: the block being finished is always
@@ -88,7 +83,7 @@ __global__ __launch_bounds__(256, SPX_FWD_WAVES) void spx_fwd_kernel(const SpxFw
         const float x2 = x2part + __shfl_xor(x2part, 32);
         const int p0 = pl.panel_p0[panel], np = pl.panel_np[panel];
 #pragma unroll 1
-        for (int pb = 0; pb < pl.npb; ++pb) {
+        for (int pb = 0; pb < NPB; ++pb) {
             if (pb * 32 < np) {
                 const spx_rsrc dr = make_rsrc_pred(a.dist ? a.dist + ((size_t)b * P + p0 + pb * 32) * a.HW : nullptr);
                 const spx_rsrc ar = make_rsrc_pred(a.act ? a.act + (size_t)b * a.HW * P + p0 + pb * 32 : nullptr);
@@ -100,12 +95,14 @@ __global__ __launch_bounds__(256, SPX_FWD_WAVES) void spx_fwd_kernel(const SpxFw
                     // rows 8*g4 + 4h + (0..3) of the block <-> registers 4*g4..4*g4+3
                     const f32x4 p2v = *(const f32x4*)(p2s + pb * 32 + 8 * g4 + 4 * h);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int reg = 4 * g4 + e;
-                        const float d = fmaxf(__builtin_fmaf(-2.0f, acc[0][reg], p2v[e]) + x2, 0.0f);
-                        dv[reg] = d;
-                        av[reg] = ACT_LOG ? act_log(d, a.eps) : -d;
-                    }
+                    for (int e = 0; e < 4; ++e) dv[4 * g4 + e] = fmaxf(__builtin_fmaf(-2.0f, acc[0][4 * g4 + e], p2v[e]) + x2, 0.0f);
+                }
+                if (a.act_fn == 0) {
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) av[reg] = act_log(dv[reg], a.eps);
+                } else {
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) av[reg] = -dv[reg];
                 }
                 if (a.dist) {
 #pragma unroll
@@ -136,21 +133,19 @@ __global__ __launch_bounds__(256, SPX_FWD_WAVES) void spx_fwd_kernel(const SpxFw
                         }
 #pragma unroll
                         for (int cb = 0; cb < NCB; ++cb) {
-                            if (cb < pl.ncb) {
-                                bf16x8 whi, wlo;
-                                if (head_lds) {
-                                    const char* wf = wlds + ((cb * pl.npb + pb) * 2 + s2) * 2048 + lane * 16;
-                                    whi = *(const bf16x8*)wf;
-                                    wlo = *(const bf16x8*)(wf + 1024);
-                                } else {
-                                    const uint32_t so = (uint32_t)((((cb * pl.npanels + panel) * pl.npb + pb) * 2 + s2) * 2048);
-                                    whi = __builtin_bit_cast(bf16x8, buf_load_b128(hr, (uint32_t)lane * 16u, so));
-                                    wlo = __builtin_bit_cast(bf16x8, buf_load_b128(hr, (uint32_t)lane * 16u, so + 1024u));
-                                }
-                                accl[cb] = mfma_bf16(whi, ahi, accl[cb]);
-                                accl[cb] = mfma_bf16(wlo, ahi, accl[cb]);
-                                accl[cb] = mfma_bf16(whi, alo, accl[cb]);
+                            bf16x8 whi, wlo;
+                            if (head_lds) {
+                                const char* wf = wlds + ((cb * NPB + pb) * 2 + s2) * 2048 + lane * 16;
+                                whi = *(const bf16x8*)wf;
+                                wlo = *(const bf16x8*)(wf + 1024);
+                            } else {
+                                const uint32_t so = (uint32_t)((((cb * pl.npanels + panel) * NPB + pb) * 2 + s2) * 2048);
+                                whi = __builtin_bit_cast(bf16x8, buf_load_b128(hr, (uint32_t)lane * 16u, so));
+                                wlo = __builtin_bit_cast(bf16x8, buf_load_b128(hr, (uint32_t)lane * 16u, so + 1024u));
                             }
+                            accl[cb] = mfma_bf16(whi, ahi, accl[cb]);
+                            accl[cb] = mfma_bf16(wlo, ahi, accl[cb]);
+                            accl[cb] = mfma_bf16(whi, alo, accl[cb]);
                         }
                     }
                 }
@@ -163,42 +158,35 @@ __global__ __launch_bounds__(256, SPX_FWD_WAVES) void spx_fwd_kernel(const SpxFw
         }
     };
 
-    // One step of the software pipeline.  Global loads run two steps ahead of the MFMAs: while step i computes
-    // from LDS[i&1], the registers of `nxt` (loaded during step i-1) are written to LDS[(i+1)&1] and `far`
-    // issues the loads of step i+2.
-    auto do_step = [&](int step, SpxStager<NPB, XF32>& far, SpxStager<NPB, XF32>& nxt) {
-        const int panel = step / nchunks, chunk = step - panel * nchunks;
-        if (chunk == 0) {
-            x2part = 0.0f;
-            stage_panel_consts(panel);
-        }
-        if (step + 2 < total) {
-            const int np_ = (step + 2) / nchunks, nc_ = (step + 2) - np_ * nchunks;
-            far.load(tc, pl, (uint32_t)(step + 2) * chunk_bytes, pl.panel_ch0[np_] + nc_ * pl.kc, tid);
-        }
-        char* cur = smem + (step & 1) * stage;
-        spx_compute_chunk<NPB>(acc, x2part, pl, cur, cur + xs_bytes, lane, wave);
-        if (step + 1 < total) {
-            char* dst = smem + ((step + 1) & 1) * stage;
-            nxt.write(pl, dst, dst + xs_bytes, tid);
-        }
+    // One K-chunk of the software pipeline.  Global loads run two chunks ahead of the MFMAs: while chunk i
+    // computes from LDS[i&1], the registers of `nxt` (loaded during chunk i-1) are written to LDS[(i+1)&1] and
+    // `far` issues the loads of chunk i+2.  The body is branch-free (steps past the panel's last chunk load and
+    // stage zeros), so hipcc counts vmcnt exactly and the far loads stay in flight across the LDS write + barrier.
+    auto do_chunk = [&](const char* bank0, int ch0, int chunk, Stager& far, Stager& nxt) {
+        far.load(tc, bank0 + (size_t)(chunk + 2) * chunk_bytes, ch0 + (chunk + 2) * SPX_KC, Cs - (chunk + 2) * SPX_KC, tid);
+        char* cur = smem + (chunk & 1) * stage;
+        spx_compute_chunk<NPB>(acc, x2part, cur, cur + SPX_STAGE_X_BYTES, lane, wave);
+        char* dst = smem + ((chunk + 1) & 1) * stage;
+        nxt.write(dst, dst + SPX_STAGE_X_BYTES, tid);
         __syncthreads();
-        if (chunk == nchunks - 1) {
-            epilogue(panel);
-            if (step + 1 < total) __syncthreads();   // next panel's prologue overwrites the head / |p|^2 LDS
-        }
     };
 
-    stA.load(tc, pl, 0u, pl.panel_ch0[0], tid);
-    if (total > 1) {
-        const int np_ = 1 / nchunks, nc_ = 1 - np_ * nchunks;
-        stB.load(tc, pl, chunk_bytes, pl.panel_ch0[np_] + nc_ * pl.kc, tid);
-    }
-    stA.write(pl, smem, smem + xs_bytes, tid);
-    __syncthreads();
-    for (int step = 0; step < total; step += 2) {
-        do_step(step, stA, stB);
-        if (step + 1 < total) do_step(step + 1, stB, stA);
+    const int nch_even = (nchunks + 1) & ~1;      // chunk pairs; an odd tail chunk is all zeros
+    for (int panel = 0; panel < pl.npanels; ++panel) {
+        const char* bank0 = a.packed_bank + (size_t)(panel * nchunks) * chunk_bytes;
+        const int ch0 = pl.panel_ch0[panel];
+        x2part = 0.0f;
+        stage_panel_consts(panel);
+        stA.load(tc, bank0, ch0, Cs, tid);
+        stB.load(tc, bank0 + chunk_bytes, ch0 + SPX_KC, Cs - SPX_KC, tid);
+        stA.write(smem, smem + SPX_STAGE_X_BYTES, tid);
+        __syncthreads();
+        for (int chunk = 0; chunk < nch_even; chunk += 2) {
+            do_chunk(bank0, ch0, chunk, stA, stB);
+            do_chunk(bank0, ch0, chunk + 1, stB, stA);
+        }
+        epilogue(panel);
+        if (panel + 1 < pl.npanels) __syncthreads();   // next panel's prologue overwrites the head / |p|^2 / stage LDS
     }
 
     if (want_head) {
@@ -206,25 +194,23 @@ __global__ __launch_bounds__(256, SPX_FWD_WAVES) void spx_fwd_kernel(const SpxFw
         const uint32_t voff_l = px_ok ? ((uint32_t)px * (uint32_t)K + (uint32_t)(4 * h)) * 4u : SPX_OOB;   // [px][class]
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb) {
-            if (cb < pl.ncb) {
 #pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    const int cls = cb * 32 + acc_row(reg, h);
-                    buf_store_f32(accl[cb][reg], lr, cls < K ? voff_l : SPX_OOB, (uint32_t)((cb * 32 + (reg & 3) + 8 * (reg >> 2)) * 4));
-                }
+            for (int reg = 0; reg < 16; ++reg) {
+                const int cls = cb * 32 + acc_row(reg, h);
+                buf_store_f32(accl[cb][reg], lr, cls < K ? voff_l : SPX_OOB, (uint32_t)((cb * 32 + (reg & 3) + 8 * (reg >> 2)) * 4));
             }
         }
     }
 }
 
 template <int NPB, int NCB>
-static hipError_t launch_fwd_x(const SpxFwdArgs& a, int x_dtype, dim3 grid, size_t lds, hipStream_t s) {
-    const bool lg = a.act_fn == 0;
+static hipError_t launch_fwd_x(const SpxFwdArgs& a, int x_dtype, dim3 grid, hipStream_t s) {
+    constexpr size_t lds = (size_t)spx_fwd_lds_bytes<NPB, NCB>();
     if (x_dtype == 1) {
-        if (lg) hipLaunchKernelGGL((spx_fwd_kernel<NPB, NCB, true, true>), grid, dim3(256), lds, s, a);
+        if (a.vec_ok) hipLaunchKernelGGL((spx_fwd_kernel<NPB, NCB, true, true>), grid, dim3(256), lds, s, a);
         else hipLaunchKernelGGL((spx_fwd_kernel<NPB, NCB, true, false>), grid, dim3(256), lds, s, a);
     } else {
-        if (lg) hipLaunchKernelGGL((spx_fwd_kernel<NPB, NCB, false, true>), grid, dim3(256), lds, s, a);
+        if (a.vec_ok) hipLaunchKernelGGL((spx_fwd_kernel<NPB, NCB, false, true>), grid, dim3(256), lds, s, a);
         else hipLaunchKernelGGL((spx_fwd_kernel<NPB, NCB, false, false>), grid, dim3(256), lds, s, a);
     }
     return hipGetLastError();
@@ -234,11 +220,12 @@ hipError_t spx_launch_fwd(const SpxFwdArgs& a, int x_dtype, hipStream_t s) {
     const spx_plan& pl = a.plan;
     const int tiles = (a.HW + SPX_TILE_PX - 1) / SPX_TILE_PX;
     dim3 grid((unsigned)(tiles * a.B));
-    const size_t lds = (size_t)spx_fwd_lds_bytes(pl);
-    const bool small_p = pl.npb <= 2;
-    const bool small_k = pl.ncb <= 1;
-    if (small_p && small_k) return launch_fwd_x<2, 1>(a, x_dtype, grid, lds, s);
-    if (small_k) return launch_fwd_x<6, 1>(a, x_dtype, grid, lds, s);
-    if (small_p) return launch_fwd_x<2, 5>(a, x_dtype, grid, lds, s);
-    return launch_fwd_x<6, 5>(a, x_dtype, grid, lds, s);
+    if (pl.ncb == 1) {
+        if (pl.npb == 2) return launch_fwd_x<2, 1>(a, x_dtype, grid, s);
+        if (pl.npb == 4) return launch_fwd_x<4, 1>(a, x_dtype, grid, s);
+        return launch_fwd_x<6, 1>(a, x_dtype, grid, s);
+    }
+    if (pl.npb == 2) return launch_fwd_x<2, 5>(a, x_dtype, grid, s);
+    if (pl.npb == 4) return launch_fwd_x<4, 5>(a, x_dtype, grid, s);
+    return launch_fwd_x<6, 5>(a, x_dtype, grid, s);
 }

@@ -11,10 +11,10 @@ __device__ __forceinline__ int perm_row(int s2, int h, int j) { return 16 * s2 +
 __global__ void spx_pack_bank_kernel(const spx_plan pl, const float* __restrict__ bank, __bf16* __restrict__ pb_out,
                                      __bf16* __restrict__ pbT_out, float* __restrict__ p2_out) {
     const int Cs = pl.channels_per_scale;
-    const int nks = pl.kc >> 4, nchunks = Cs / pl.kc;
+    const int nks = 2, nchunks = (Cs + 31) / 32;
     const int nchb = (Cs + 31) / 32;
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    const int n_fwd = pl.npanels * pl.npb * 32 * Cs / 8;          // 8-element groups
+    const int n_fwd = pl.npanels * pl.npb * 32 * nchunks * 32 / 8;          // 8-element groups
     const int n_T = pl.npanels * pl.npb * 2 * nchb * 64;
     const int n_p2 = pl.npanels * pl.npb * 32;
     if (gid < n_fwd) {
@@ -25,12 +25,12 @@ __global__ void spx_pack_bank_kernel(const spx_plan pl, const float* __restrict_
         const int chunk = t % nchunks; t /= nchunks;
         const int panel = t;
         const int row = pb * 32 + (lane & 31);
-        const int c0 = chunk * pl.kc + ks * 16 + 8 * (lane >> 5);
+        const int c0 = chunk * 32 + ks * 16 + 8 * (lane >> 5);
         bf16x8 v;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             float f = 0.0f;
-            if (row < pl.panel_np[panel]) f = bank[(size_t)(pl.panel_p0[panel] + row) * Cs + c0 + j];
+            if (row < pl.panel_np[panel] && c0 + j < Cs) f = bank[(size_t)(pl.panel_p0[panel] + row) * Cs + c0 + j];
             v[j] = (__bf16)f;
         }
         *(bf16x8*)(pb_out + (size_t)gid * 8) = v;
@@ -124,7 +124,7 @@ __global__ void spx_pack_head_kernel(const spx_plan pl, const float* __restrict_
 
 hipError_t spx_launch_pack_bank(const spx_plan& pl, const float* bank, void* pb, void* pbT, float* p2, hipStream_t s) {
     const int Cs = pl.channels_per_scale, nchb = (Cs + 31) / 32;
-    int n = pl.npanels * pl.npb * 32 * Cs / 8;
+    int n = pl.npanels * pl.npb * 32 * (((Cs + 31) / 32) * 32) / 8;
     const int nT = pl.npanels * pl.npb * 2 * nchb * 64;
     if (nT > n) n = nT;
     const int np2 = pl.npanels * pl.npb * 32;
