@@ -1,0 +1,138 @@
+"""CPU checks of the drop-in modules' host logic against the reference-generated fixtures: constructor
+surface, state_dict keys / shapes, class tables, pruning, phase-1 -> phase-2 hand-off, label resize."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+import scaleprotoseg_amd as spx
+
+
+class _Backbone(nn.Module):
+    def __init__(self, ch):
+        super().__init__()
+        self.base = nn.Sequential(nn.Conv2d(3, ch, 1), nn.Conv2d(ch, ch, 1))
+
+    def __repr__(self):
+        return "MSC(standin)"
+
+    def forward(self, x):
+        return x
+
+
+def _proto(P, Cs, S, K, **kw):
+    return spx.PPNetMultiScale(_Backbone(Cs * S), 64, (P, Cs, 1, 1), [], K, add_on_layers_type="deeplab_simple",
+                               patch_classification=True, num_scales=S, **kw)
+
+
+@pytest.mark.parametrize("name", ["proto_ms_small", "proto_ms_city", "proto_s3", "proto_floor", "proto_s1_wide"])
+def test_state_dict_and_tables_match_reference(golden, name):
+    g = golden(name)
+    S = int(g["num_scales"])
+    P, K = g["class_identity"].shape
+    Cs = g["prototype_vectors"].shape[1]
+    net = _proto(P, Cs, S, K)
+    sd = {k: v for k, v in net.state_dict().items() if not k.startswith("features.")}
+    assert list(sd.keys()) == list(g["state_keys"])
+    assert [str(tuple(v.shape)) for v in sd.values()] == list(g["state_shapes"])
+    np.testing.assert_array_equal(net.prototype_class_identity.numpy(), g["class_identity"])
+    np.testing.assert_array_equal(np.array([net.scale_num_prototypes[s] for s in range(S)]), g["scale_ranges"])
+    assert net.num_prototypes == P and net.num_classes == K and tuple(net.prototype_shape) == (P, Cs, 1, 1)
+    assert not net.ones.requires_grad and net.prototype_vectors.requires_grad
+    # +1 / -0.5 last layer (model_multiscale.py:449-464)
+    w = net.last_layer.weight.detach()
+    ident = net.prototype_class_identity.t()
+    assert torch.equal(w, ident - 0.5 * (1 - ident))
+    # loading the reference's parameters works key for key
+    net.load_state_dict({"prototype_vectors": torch.from_numpy(g["prototype_vectors"]),
+                         "ones": torch.ones(P, Cs, 1, 1),
+                         "last_layer.weight": torch.from_numpy(g["last_layer_weight"])}, strict=False)
+
+
+def test_prune_matches_reference(golden):
+    g = golden("misc")
+    P, S, K = int(g["prune_P"]), int(g["prune_S"]), int(g["prune_K"])
+    net = spx.PPNetMultiScale(_Backbone(8 * S), 64, (P, 8, 1, 1), [], K, add_on_layers_type="deeplab_simple",
+                              patch_classification=True, num_scales=S)
+    with torch.no_grad():
+        net.prototype_vectors.copy_(torch.from_numpy(g["prune_before_protos"]))
+        net.last_layer.weight.copy_(torch.from_numpy(g["prune_before_last"]))
+    net.prune_prototypes([int(i) for i in g["prune_drop"]])
+    np.testing.assert_array_equal(net.prototype_vectors.detach().numpy(), g["prune_after_protos"])
+    np.testing.assert_array_equal(net.last_layer.weight.detach().numpy(), g["prune_after_last"])
+    np.testing.assert_array_equal(net.prototype_class_identity.numpy(), g["prune_after_identity"])
+    np.testing.assert_array_equal(np.array([net.scale_num_prototypes[s] for s in range(S)]), g["prune_after_ranges"])
+    assert tuple(net.ones.shape) == tuple(g["prune_after_ones_shape"])
+    assert net.last_layer.in_features == net.num_prototypes
+    # the kernel plan follows the re-packed scale table
+    lay = net._layout(K)
+    assert lay.scale_ranges == tuple(tuple(int(v) for v in r) for r in g["prune_after_ranges"])
+    from scaleprotoseg_amd import _lib
+
+    plan = _lib.make_plan(net.num_prototypes, K, S, 16, [r[0] for r in lay.scale_ranges], [r[1] for r in lay.scale_ranges])
+    assert [plan.panel_np[q] for q in range(plan.npanels)] == [hi - lo for lo, hi in lay.scale_ranges]
+
+
+def test_group_phase_surface(golden):
+    g = golden("group_ms_small")
+    S, G = int(g["num_scales"]), int(g["num_groups"])
+    P, K = g["class_identity"].shape
+    Cs = g["prototype_vectors"].shape[1]
+    old = _proto(P, Cs, S, K)
+    net = spx.PPNetMultiScaleGroup(_Backbone(Cs * S), 64, (P, Cs, 1, 1), [], K, add_on_layers_type="deeplab_simple",
+                                   patch_classification=True, num_scales=S, num_groups=G)
+    sd = {k: v for k, v in net.state_dict().items() if not k.startswith("features.")}
+    assert list(sd.keys()) == list(g["state_keys"])
+    assert [str(tuple(v.shape)) for v in sd.values()] == list(g["state_shapes"])
+    # phase-1 -> phase-2 hand-off (finetune_wandb_group.py:76): strict=False, last_layer is the only stranger
+    res = net.load_state_dict(old.state_dict(), strict=False)
+    assert list(res.unexpected_keys) == list(g["unexpected_keys"])
+    assert sorted(res.missing_keys) == sorted(g["missing_keys"])
+    np.testing.assert_array_equal(net.group_class_identity.numpy(), g["group_class_identity"])
+    for gp in net.group_projection:   # simplex rows after init (model_multiscale_group.py:516-517)
+        w = gp.weight.detach()
+        assert (w >= 0).all() and torch.allclose(w.sum(1), torch.ones(G), atol=1e-5)
+    gi = net.group_class_identity.t()
+    assert torch.equal(net.last_layer_group.weight.detach(), gi + net.incorrect_strength * (1 - gi))
+    # dense form of the grouping head == per-class gather + linear (compute_group), on CPU tensors
+    act = torch.rand(7, P)
+    dense = torch.exp(act @ net._dense_group_matrix().t())
+    np.testing.assert_allclose(dense.detach().numpy(), torch.cat(net.compute_group(act), dim=-1).detach().numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_single_scale_ppnet(golden):
+    g = golden("ppnet_single")
+    P, K = g["class_identity"].shape
+    net = spx.PPNet(_Backbone(32), 64, (P, 32, 1, 1), [], K, add_on_layers_type="deeplab_simple", patch_classification=True)
+    np.testing.assert_array_equal(net.prototype_class_identity.numpy(), g["class_identity"])
+    assert net.num_prototypes_per_class == P // K and net.num_scales == 1
+
+
+def test_reference_error_behaviour():
+    net = _proto(40, 16, 4, 5)
+    net.patch_classification = False
+    with pytest.raises(Exception, match="Original Prototype Network Implementation"):
+        net.forward_from_conv_features(torch.zeros(1, 64, 4, 4))     # model_multiscale.py:387-388
+    with pytest.raises(Exception, match="base_architecture NOT implemented"):
+        spx.PPNetMultiScale(nn.Linear(2, 2), 64, (8, 16, 1, 1), [], 2)   # :171
+    net = _proto(40, 16, 4, 5)
+    with pytest.raises(spx.SpxError, match="no CPU fallback"):
+        net.forward_from_conv_features(torch.zeros(1, 64, 4, 4))
+
+
+def test_resize_label_and_simplex(golden):
+    g = golden("push_argmin")
+    for w, h in g["resize_sizes"]:
+        np.testing.assert_array_equal(spx.resize_label(g["label_full"], (int(w), int(h))).numpy(), g[f"resized_{w}x{h}"])
+    m = golden("misc")
+    np.testing.assert_allclose(spx.projection_simplex_sort(torch.from_numpy(m["simplex_in"])).numpy(), m["simplex_out"], atol=1e-6)
+
+
+def test_resize_label_matches_pil_sampling():
+    PIL = pytest.importorskip("PIL.Image")
+    rng = np.random.default_rng(3)
+    for _ in range(60):
+        hi, wi, ho, wo = (int(v) for v in rng.integers(1, 300, 4))
+        lab = rng.integers(0, 20, (hi, wi))
+        ref = np.asarray(PIL.fromarray(lab.astype(float)).resize((wo, ho), resample=PIL.NEAREST)).astype(np.int64)
+        np.testing.assert_array_equal(spx.resize_label(lab, (wo, ho)).numpy(), ref)
