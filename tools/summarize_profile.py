@@ -1,0 +1,39 @@
+"""Condense rocprofv3 CSV output (kernel stats + PMC passes) into one markdown summary for profiles/."""
+import collections
+import csv
+import glob
+import json
+import sys
+
+root = sys.argv[1]
+print(f"# rocprofv3 summary ({root})\n")
+print("Command: `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline` "
+      "(PMC counters: separate `--pmc` passes of the same command)\n")
+for f in glob.glob(root + "/trace/*/*kernel_stats.csv"):
+    print("## Kernel stats (all calls incl. warm-up)\n")
+    print("| kernel | calls | avg µs | total ms | % |")
+    print("|---|---|---|---|---|")
+    for r in csv.DictReader(open(f)):
+        name = r["Name"].split("(")[0].replace("void ", "")[:60]
+        if float(r["Percentage"]) < 0.3:
+            continue
+        print(f"| `{name}` | {r['Calls']} | {float(r['AverageNs'])/1e3:.1f} | {float(r['TotalDurationNs'])/1e6:.2f} | {float(r['Percentage']):.1f} |")
+    print()
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(root + "/pmc_*/*/*counter_collection.csv"):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "")[:60]
+        if "spx_" in k:
+            agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+if agg:
+    print("## PMC counters per launch (mean over launches)\n")
+    print("FETCH_SIZE / WRITE_SIZE are in KiB as reported; on gfx950 FETCH_SIZE counts a wide coalesced read stream "
+          "at half its bytes (MI355X_MICROARCH.md §HBM), so `hbm_read_MB_corrected = 2 x FETCH_SIZE`.\n")
+    for k, v in agg.items():
+        m = {c: sum(x) / len(x) for c, x in v.items()}
+        line = {c: round(val) for c, val in m.items()}
+        if "FETCH_SIZE" in m:
+            line["hbm_read_MB_corrected"] = round(2 * m["FETCH_SIZE"] * 1024 / 1e6, 1)
+        if "WRITE_SIZE" in m:
+            line["hbm_write_MB"] = round(m["WRITE_SIZE"] * 1024 / 1e6, 1)
+        print(f"* `{k}`: {json.dumps(line)}")
