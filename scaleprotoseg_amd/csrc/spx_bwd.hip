@@ -303,12 +303,27 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
                 if (f < 2 * NPB) *(u32x4*)(bt + buf * SPX_BT_BYTES + f * 1024 + lane * 16) = bt_reg[i];
             }
         };
+        // x (and the previous partial dX) of a finish segment, as raw 16-B vectors; loaded one block ahead
+        u32x4 xw[VEC ? NV : 1], pw[VEC ? NV : 1];
+        auto x_load = [&](int chb) {
+            if (VEC) {
+                const bool ch_ok = chb * 32 + frow < Cs;
+                const spx_rsrc xir = make_rsrc_pred(x_img + (size_t)(ch0 + chb * 32) * a.HW * ESZ);
+                const spx_rsrc dxr = make_rsrc_pred((char*)a.dx + ((size_t)b * C + ch0 + chb * 32) * a.HW * ESZ);
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    const bool ok = ch_ok && (fpx + (v + 1) * PV <= a.HW);
+                    xw[v] = buf_load_b128(xir, ok ? fvo + 16u * v : SPX_OOB, 0);
+                    // first panel of a scale: nothing to accumulate onto (dropped load returns 0)
+                    pw[v] = buf_load_b128(dxr, (ok && !first_of_scale) ? fvo + 16u * v : SPX_OOB, 0);
+                }
+            }
+        };
         bt_load(0);
+        x_load(0);
         bt_write(0);
         __syncthreads();
         for (int chb = 0; chb < nchb; ++chb) {
-            if (chb + 1 < nchb) bt_load(chb + 1);
-            // x (and the previous partial dX) of this thread's finish segment: in flight across MFMAs + barrier
             const bool ch_ok = chb * 32 + frow < Cs;
             const spx_rsrc xir = make_rsrc_pred(x_img + (size_t)(ch0 + chb * 32) * a.HW * ESZ);
             const spx_rsrc dxr = make_rsrc_pred((char*)a.dx + ((size_t)b * C + ch0 + chb * 32) * a.HW * ESZ);
@@ -316,20 +331,16 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
             if (VEC) {
 #pragma unroll
                 for (int v = 0; v < NV; ++v) {
-                    const bool ok = ch_ok && (fpx + (v + 1) * PV <= a.HW);
-                    const u32x4 xw = buf_load_b128(xir, ok ? fvo + 16u * v : SPX_OOB, 0);
-                    u32x4 pw = {0u, 0u, 0u, 0u};
-                    if (!first_of_scale) pw = buf_load_b128(dxr, ok ? fvo + 16u * v : SPX_OOB, 0);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         if (XF32) {
-                            xv[4 * v + e] = __uint_as_float(xw[e]);
-                            pv[4 * v + e] = __uint_as_float(pw[e]);
+                            xv[4 * v + e] = __uint_as_float(xw[v][e]);
+                            pv[4 * v + e] = __uint_as_float(pw[v][e]);
                         } else {
-                            xv[8 * v + 2 * e] = __uint_as_float(xw[e] << 16);
-                            xv[8 * v + 2 * e + 1] = __uint_as_float(xw[e] & 0xffff0000u);
-                            pv[8 * v + 2 * e] = __uint_as_float(pw[e] << 16);
-                            pv[8 * v + 2 * e + 1] = __uint_as_float(pw[e] & 0xffff0000u);
+                            xv[8 * v + 2 * e] = __uint_as_float(xw[v][e] << 16);
+                            xv[8 * v + 2 * e + 1] = __uint_as_float(xw[v][e] & 0xffff0000u);
+                            pv[8 * v + 2 * e] = __uint_as_float(pw[v][e] << 16);
+                            pv[8 * v + 2 * e + 1] = __uint_as_float(pw[v][e] & 0xffff0000u);
                         }
                     }
                 }
@@ -346,6 +357,9 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
                     }
                 }
             }
+            // next block's operands: P^T fragments and x, in flight across this block's MFMAs, barrier and finish
+            bt_load(chb + 1 < nchb ? chb + 1 : chb);
+            x_load(chb + 1 < nchb ? chb + 1 : chb);
             f32x16 accx;
 #pragma unroll
             for (int i = 0; i < 16; ++i) accx[i] = 0.0f;
@@ -362,7 +376,7 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg)
                 *(float*)(T + acc_row(reg, h) * SPX_T_ROW + (32 * wave + r) * 4) = accx[reg];
-            if (chb + 1 < nchb) bt_write((chb + 1) & 1);
+            bt_write((chb + 1) & 1);
             __syncthreads();
             float ov[16];
 #pragma unroll
@@ -473,9 +487,11 @@ hipError_t spx_launch_bwd(const SpxBwdArgs& a, int x_dtype, hipStream_t s) {
 #define SPX_BK_PX 64          // pixels per K-chunk (half a kernel-1 tile)
 #define SPX_BK_ROW 144        // LDS row stride of the [channel][px] images (128 + 16: conflict-free ds_read_b128)
 
-// row stride of the [px][prototype] images: the 4 pixel rows of a transposed read must fall on disjoint
-// 64-B bank windows -> stride = 64 or 192 (mod 256)
-__host__ __device__ inline int spx_bk_grow(int npb) { return npb * 64 + ((npb & 1) ? 0 : 64); }
+// row stride of the [px][prototype] images.  Each image is WRITTEN with one ds_write_b64 per lane, all lanes at
+// the same column of 32 different pixel rows: a stride of 8 (mod 128) spreads them over all banks (a stride of
+// 64 mod 256, ideal for the transposed reads, made these writes 8-way conflicted: 90 M conflict cycles per
+// launch in profiles/r1).  The transposed reads are then 2-way on part of the banks.
+__host__ __device__ inline int spx_bk_grow(int npb) { return npb * 64 + 8; }
 
 __host__ __device__ inline int spx_bk_wstride(const spx_plan& pl) {
     return ((pl.channels_per_scale + 31) / 32) * 32 + pl.ncb * 32 + 32;   // [dP cols | dW cols | colsum + pad]
