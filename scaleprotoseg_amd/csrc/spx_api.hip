@@ -7,6 +7,7 @@
 #include "spx_args.h"
 
 static thread_local char g_err[512] = "";
+static unsigned long long* g_dbg = nullptr;   // diagnostic builds: see spx_set_debug_buffer
 
 static int fail(const char* fmt, ...) {
     va_list ap;
@@ -39,6 +40,8 @@ static int x_vec_ok(const void* x, int x_dtype, int HW) {
 extern "C" {
 
 int spx_version(void) { return SPX_ABI_VERSION; }
+/* Not part of the product ABI (absent from spx_hip.h): profiling hook of SPX_DIAG_STAMPS builds. */
+void spx_diag_set_debug_buffer(void* p) { g_dbg = (unsigned long long*)p; }
 const char* spx_last_error(void) { return g_err; }
 
 int spx_make_plan(int32_t P, int32_t K, int32_t S, int32_t Cs, const int32_t* lo, const int32_t* hi, spx_plan* out) {
@@ -134,6 +137,7 @@ int spx_dist_fwd(const spx_plan* pl, const void* x, int32_t x_dtype, int32_t B, 
     a.vec_ok = x_vec_ok(x, x_dtype, HW);
     a.eps = epsilon;
     a.act_fn = act_fn;
+    a.dbg = g_dbg;
     return hip_status(spx_launch_fwd(a, x_dtype, (hipStream_t)stream), "spx_dist_fwd");
 }
 
@@ -166,6 +170,7 @@ int spx_dist_bwd(const spx_plan* pl, const void* x, int32_t x_dtype, int32_t B, 
     a.vec_ok = x_vec_ok(x, x_dtype, HW);
     a.eps = epsilon;
     a.act_fn = act_fn;
+    a.dbg = g_dbg;
     return hip_status(spx_launch_bwd(a, x_dtype, (hipStream_t)stream), "spx_dist_bwd");
 }
 

@@ -14,6 +14,7 @@ struct SpxFwdArgs {
     int B, HW, vec_ok;
     float eps;
     int act_fn;
+    unsigned long long* dbg;   // diagnostic builds only (SPX_DIAG_STAMPS): per-workgroup phase clocks
 };
 struct SpxBwdArgs {
     spx_plan plan;
@@ -31,6 +32,7 @@ struct SpxBwdArgs {
     int B, HW, vec_ok;
     float eps;
     int act_fn;
+    unsigned long long* dbg;
 };
 struct SpxBankBwdArgs {
     spx_plan plan;

@@ -26,23 +26,37 @@
 #ifndef SPX_BWD_WAVES
 #define SPX_BWD_WAVES 2
 #endif
+#ifndef SPX_BWD_XRING
+#define SPX_BWD_XRING(xf32) 2
+#endif
 
-#define SPX_BT_BYTES 12288                // one P^T stage: fragments of one 32-channel block, <= 6 blocks x 2 k-steps x 1 KiB
 #define SPX_T_ROW 528                     // fp32 transpose tile row: 128 px * 4 B + 16 B pad
 #define SPX_T_BYTES (32 * SPX_T_ROW)
 
+// LDS carve of the pixel kernel (two workgroups per CU need <= 80 KiB each):
+//   region 0: main loop: 2 stages            | phase 2: 2 P^T stages (NPB * 2 KiB each) + transpose tile 0
+//   region 1: head^T fragments (phase 1 only) | phase 2: transpose tile 1
+//   |p|^2 of the panel, rowsum(G) of the tile
+template <int NPB>
+__host__ __device__ constexpr int spx_bwd_bt_bytes() { return NPB * 2 * 1024; }
 template <int NPB, int NCB>
 __host__ __device__ constexpr int spx_bwd_head_lds_bytes() { return NCB == 1 ? NPB * 2 * 2048 : 0; }
 template <int NPB>
 __host__ __device__ constexpr int spx_bwd_region0_bytes() {
     constexpr int a = 2 * spx_stage_bytes(NPB);
-    constexpr int b = 2 * SPX_BT_BYTES + 2 * SPX_T_BYTES;
+    constexpr int b = 2 * spx_bwd_bt_bytes<NPB>() + SPX_T_BYTES;
     return a > b ? a : b;
 }
 template <int NPB, int NCB>
-__host__ __device__ constexpr int spx_bwd_lds_bytes() {
-    return spx_bwd_region0_bytes<NPB>() + spx_bwd_head_lds_bytes<NPB, NCB>() + NPB * 32 * 4 + SPX_TILE_PX * 4;
+__host__ __device__ constexpr int spx_bwd_region1_bytes() {
+    constexpr int h = spx_bwd_head_lds_bytes<NPB, NCB>();
+    return h > SPX_T_BYTES ? h : SPX_T_BYTES;
 }
+template <int NPB, int NCB>
+__host__ __device__ constexpr int spx_bwd_lds_bytes() {
+    return spx_bwd_region0_bytes<NPB>() + spx_bwd_region1_bytes<NPB, NCB>() + NPB * 32 * 4 + SPX_TILE_PX * 4;
+}
+static_assert(spx_bwd_lds_bytes<6, 1>() <= 80 * 1024, "pixel kernel must fit two workgroups per CU");
 // bf16 elements of one G (or a) scratch: [panel][tile][wave][pb][s2] fragments of 512 elements
 size_t spx_bwd_scratch_elems(const spx_plan& pl, int B, int HW) {
     const size_t tiles = (size_t)B * ((HW + SPX_TILE_PX - 1) / SPX_TILE_PX);
@@ -71,17 +85,18 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
     constexpr int ncstep = NCB * 2;
     const uint32_t HW = (uint32_t)a.HW;
     constexpr int ESZ = XF32 ? 4 : 2;
-    using Stager = SpxStager<NPB, XF32, VEC>;
+    constexpr int XR = SPX_BWD_XRING(XF32);
+    using Pipe = SpxPipeline<NPB, XF32, VEC, XR>;
 
     const char* x_img = (const char*)a.x + (size_t)b * C * a.HW * ESZ;
-    const SpxTileCtx tc = Stager::make_ctx(x_img, a.HW, px0, tid);
+    const SpxTileCtx tc = SpxXStager<XF32, VEC>::make_ctx(x_img, a.HW, px0, tid);
 
     constexpr int stage = spx_stage_bytes(NPB);
     constexpr int chunk_bytes = NPB * 2 * 1024;
     constexpr int head_lds = spx_bwd_head_lds_bytes<NPB, NCB>();
     const int nchunks = (Cs + SPX_KC - 1) / SPX_KC;
     char* const hlds = smem + spx_bwd_region0_bytes<NPB>();
-    float* const p2s = (float*)(hlds + head_lds);
+    float* const p2s = (float*)(hlds + spx_bwd_region1_bytes<NPB, NCB>());
     float* const rss = p2s + NPB * 32;
 
     const int px = px0 + 32 * wave + r;
@@ -91,6 +106,8 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
     const spx_rsrc htr = make_rsrc(a.packed_headT);
     const spx_rsrc btr = make_rsrc_pred(a.packed_bankT);
     const spx_rsrc p2r = make_rsrc(a.p2);
+    const spx_rsrc htp = make_rsrc_pred(a.packed_headT);
+    const spx_rsrc p2p = make_rsrc_pred(a.p2);
 
     // dLogits of this lane's pixel as split-bf16 B fragments: element j of k-step c <-> class 16c + 8h + j
     bf16x8 dlhi[NCB * 2], dllo[NCB * 2];
@@ -111,7 +128,7 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
         }
     }
 
-    Stager stA, stB;
+    Pipe pipe;
     f32x16 acc[NPB];
 #pragma unroll
     for (int pb = 0; pb < NPB; ++pb)
@@ -119,16 +136,25 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
         for (int i = 0; i < 16; ++i) acc[pb][i] = 0.0f;
     float x2part = 0.0f;
 
-    auto stage_panel_consts = [&](int panel) {
-        if (head_lds && a.d_logits) {
+    constexpr int HPASS = head_lds / 4096;
+    u32x4 hreg[HPASS > 0 ? HPASS : 1];
+    float p2reg = 0.0f;
+    auto consts_issue = [&](int panel) {
 #pragma unroll
-            for (int i = 0; i < head_lds / 4096; ++i)
-                *(u32x4*)(hlds + i * 4096 + tid * 16) = buf_load_b128(htr, (uint32_t)(i * 4096 + tid * 16), (uint32_t)(panel * head_lds));
-        }
-        if (tid < NPB * 32) p2s[tid] = buf_load_f32(p2r, (uint32_t)tid * 4u, (uint32_t)(panel * NPB * 32 * 4));
+        for (int i = 0; i < HPASS; ++i)
+            hreg[i] = buf_load_b128(htp, a.d_logits ? (uint32_t)(i * 4096 + tid * 16) : SPX_OOB, (uint32_t)(panel * head_lds));
+        p2reg = buf_load_f32(p2p, tid < NPB * 32 ? (uint32_t)tid * 4u : SPX_OOB, (uint32_t)(panel * NPB * 32 * 4));
+    };
+    auto consts_commit = [&]() {
+#pragma unroll
+        for (int i = 0; i < HPASS; ++i) *(u32x4*)(hlds + i * 4096 + tid * 16) = hreg[i];
+        if (tid < NPB * 32) p2s[tid] = p2reg;
     };
 
     const bool act_is_log = a.act_fn == 0;
+#ifdef SPX_DIAG_STAMPS
+    unsigned long long dg_t2 = 0;
+#endif
 
     // ---------------- panel epilogue ----------------
     auto epilogue = [&](int panel) {
@@ -256,6 +282,9 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
                 }
             }
         }
+#ifdef SPX_DIAG_STAMPS
+        dg_t2 = __builtin_amdgcn_s_memtime();
+#endif
         auto g_frag = [&](int pb, int s2) -> bf16x8 {
             u32x4 w;
 #pragma unroll
@@ -276,8 +305,10 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
         const float rs_tot = rs + __shfl_xor(rs, 32);
         if (h == 0) rss[32 * wave + r] = rs_tot;
         const bool first_of_scale = (panel == 0) || (pl.panel_ch0[panel - 1] != ch0);
-        char* const bt = smem;                               // 2 x SPX_BT_BYTES  (P^T fragments of one channel block)
-        char* const tt = smem + 2 * SPX_BT_BYTES;            // 2 x SPX_T_BYTES   (fp32 transpose tiles)
+        constexpr int BT = spx_bwd_bt_bytes<NPB>();
+        char* const bt = smem;                               // 2 x BT  (P^T fragments of one channel block)
+        char* const tt0 = smem + 2 * BT;                     // fp32 transpose tile 0
+        char* const tt1 = hlds;                              // fp32 transpose tile 1 (the head^T image is dead in phase 2)
         const int frow = tid >> 3, fseg = tid & 7;           // finish mapping: channel row, 16-px segment
         const int fpx = px0 + fseg * 16;
         // this thread's segment inside a 32-channel block (resources are re-based per block: offsets < 2 GiB)
@@ -300,7 +331,7 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
 #pragma unroll
             for (int i = 0; i < BTP; ++i) {
                 const int f = wave + 4 * i;
-                if (f < 2 * NPB) *(u32x4*)(bt + buf * SPX_BT_BYTES + f * 1024 + lane * 16) = bt_reg[i];
+                if (f < 2 * NPB) *(u32x4*)(bt + buf * BT + f * 1024 + lane * 16) = bt_reg[i];
             }
         };
         // x (and the previous partial dX) of a finish segment, as raw 16-B vectors; loaded one block ahead
@@ -363,7 +394,7 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
             f32x16 accx;
 #pragma unroll
             for (int i = 0; i < 16; ++i) accx[i] = 0.0f;
-            const char* cur = bt + (chb & 1) * SPX_BT_BYTES + lane * 16;
+            const char* cur = bt + (chb & 1) * BT + lane * 16;
 #pragma unroll
             for (int pb = 0; pb < NPB; ++pb) {
                 if (pb < nv) {
@@ -372,7 +403,7 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
                         accx = mfma_bf16(*(const bf16x8*)(cur + (pb * 2 + s2) * 1024), g_frag(pb, s2), accx);
                 }
             }
-            char* T = tt + (chb & 1) * SPX_T_BYTES;
+            char* T = (chb & 1) ? tt1 : tt0;
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg)
                 *(float*)(T + acc_row(reg, h) * SPX_T_ROW + (32 * wave + r) * 4) = accx[reg];
@@ -419,31 +450,19 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
         __syncthreads();   // T tiles / P^T stages are rewritten by the next panel's main loop
     };
 
-    // Software pipeline inside a panel (see spx_fwd.hip): branch-free body, global loads two chunks ahead.
-    // Nothing is kept in flight across the epilogue (its register budget is the binding one).
-    auto do_chunk = [&](const char* bank0, int ch0, int chunk, Stager& far, Stager& nxt) {
-        far.load(tc, bank0 + (size_t)(chunk + 2) * chunk_bytes, ch0 + (chunk + 2) * SPX_KC, Cs - (chunk + 2) * SPX_KC, tid);
-        char* cur = smem + (chunk & 1) * stage;
-        spx_compute_chunk<NPB>(acc, x2part, cur, cur + SPX_STAGE_X_BYTES, lane, wave);
-        char* dst = smem + ((chunk + 1) & 1) * stage;
-        nxt.write(dst, dst + SPX_STAGE_X_BYTES, tid);
-        __syncthreads();
-    };
-
-    const int nch_even = (nchunks + 1) & ~1;      // chunk pairs; an odd tail chunk is all zeros
+    // Software pipeline inside a panel: SpxPipeline (spx_mainloop.h).  Nothing is kept in flight across the
+    // epilogue (its register budget is the binding one).
+#ifdef SPX_DIAG_STAMPS
+    unsigned long long t0 = __builtin_amdgcn_s_memtime(), t1 = 0, t3 = 0;
+#endif
     for (int panel = 0; panel < pl.npanels; ++panel) {
         const char* bank0 = a.packed_bank + (size_t)(panel * nchunks) * chunk_bytes;
-        const int ch0 = pl.panel_ch0[panel];
         x2part = 0.0f;
-        stage_panel_consts(panel);
-        stA.load(tc, bank0, ch0, Cs, tid);
-        stB.load(tc, bank0 + chunk_bytes, ch0 + SPX_KC, Cs - SPX_KC, tid);
-        stA.write(smem, smem + SPX_STAGE_X_BYTES, tid);
-        __syncthreads();
-        for (int chunk = 0; chunk < nch_even; chunk += 2) {
-            do_chunk(bank0, ch0, chunk, stA, stB);
-            do_chunk(bank0, ch0, chunk + 1, stB, stA);
-        }
+        pipe.run_panel(acc, x2part, tc, smem, bank0, pl.panel_ch0[panel], Cs, lane, wave, tid,
+                       [&]() { consts_issue(panel); }, consts_commit);
+#ifdef SPX_DIAG_STAMPS
+        t1 = __builtin_amdgcn_s_memtime();
+#endif
 #ifdef SPX_DIAG_SKIP_EPILOGUE
         if (a.eps > 1e30f) epilogue(panel);   // timing-only build: keeps the code alive, never runs it
         else { float s = x2part; for (int pb = 0; pb < NPB; ++pb) for (int i = 0; i < 16; ++i) { s += acc[pb][i]; acc[pb][i] = 0.0f; } if (s == 1.2345f) rss[0] = s; }
@@ -452,6 +471,13 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
 #endif
         __syncthreads();     // the epilogue re-uses the staging LDS and the head / |p|^2 images
     }
+#ifdef SPX_DIAG_STAMPS
+    if (a.dbg && tid == 0) {
+        t3 = __builtin_amdgcn_s_memtime();
+        unsigned long long* d = a.dbg + (size_t)blockIdx.x * 4;
+        d[0] = t0; d[1] = t1; d[2] = dg_t2; d[3] = t3;
+    }
+#endif
 }
 
 template <int NPB, int NCB>

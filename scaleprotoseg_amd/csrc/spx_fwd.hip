@@ -9,6 +9,10 @@
 #ifndef SPX_FWD_WAVES
 #define SPX_FWD_WAVES 2
 #endif
+// X chunks in flight per workgroup (register ring): 4 for bf16 features (8 VGPRs each), 2 for fp32 (16 each)
+#ifndef SPX_FWD_XRING
+#define SPX_FWD_XRING(xf32) ((xf32) ? 2 : 4)
+#endif
 
 // LDS carve (bytes): [stage 0][stage 1][head fragments of the current panel (NCB == 1 only)][|p|^2 of the panel]
 template <int NPB, int NCB>
@@ -32,9 +36,10 @@ __global__ __launch_bounds__(256, SPX_FWD_WAVES) void spx_fwd_kernel(const SpxFw
     const int C = pl.num_scales * Cs;
     const int P = pl.num_prototypes, K = pl.num_classes;
     const uint32_t HW = (uint32_t)a.HW;
-    using Stager = SpxStager<NPB, XF32, VEC>;
+    constexpr int XR = SPX_FWD_XRING(XF32);
+    using Pipe = SpxPipeline<NPB, XF32, VEC, XR>;
 
-    const SpxTileCtx tc = Stager::make_ctx((const char*)a.x + (size_t)b * C * a.HW * (XF32 ? 4 : 2), a.HW, px0, tid);
+    const SpxTileCtx tc = SpxXStager<XF32, VEC>::make_ctx((const char*)a.x + (size_t)b * C * a.HW * (XF32 ? 4 : 2), a.HW, px0, tid);
 
     constexpr int stage = spx_stage_bytes(NPB);
     constexpr int chunk_bytes = NPB * 2 * 1024;
@@ -43,7 +48,7 @@ __global__ __launch_bounds__(256, SPX_FWD_WAVES) void spx_fwd_kernel(const SpxFw
     char* const wlds = smem + 2 * stage;
     float* const p2s = (float*)(wlds + head_lds);
 
-    Stager stA, stB;
+    Pipe pipe;
     f32x16 acc[NPB];
     f32x16 accl[NCB];
 #pragma unroll
@@ -63,17 +68,23 @@ __global__ __launch_bounds__(256, SPX_FWD_WAVES) void spx_fwd_kernel(const SpxFw
     // rides on wave-uniform SGPR offsets
     const uint32_t voff_d = px_ok ? ((uint32_t)(4 * h) * HW + (uint32_t)px) * 4u : SPX_OOB;                 // [row][px]
     const uint32_t voff_a = px_ok ? ((uint32_t)px * (uint32_t)P + (uint32_t)(4 * h)) * 4u : SPX_OOB;        // [px][row]
-    const spx_rsrc hr = make_rsrc(a.packed_head);
-    const spx_rsrc p2r = make_rsrc(a.p2);
+    const spx_rsrc hr = make_rsrc_pred(a.packed_head);
+    const spx_rsrc p2r = make_rsrc_pred(a.p2);
 
     // panel prologue: head fragments + |p|^2 of the panel -> LDS (read in the epilogue, after >= 1 barrier)
-    auto stage_panel_consts = [&](int panel) {
-        if (head_lds && want_head) {
+    constexpr int HPASS = head_lds / 4096;
+    u32x4 hreg[HPASS > 0 ? HPASS : 1];
+    float p2reg = 0.0f;
+    auto consts_issue = [&](int panel) {
 #pragma unroll
-            for (int i = 0; i < head_lds / 4096; ++i)
-                *(u32x4*)(wlds + i * 4096 + tid * 16) = buf_load_b128(hr, (uint32_t)(i * 4096 + tid * 16), (uint32_t)(panel * head_lds));
-        }
-        if (tid < NPB * 32) p2s[tid] = buf_load_f32(p2r, (uint32_t)tid * 4u, (uint32_t)(panel * NPB * 32 * 4));
+        for (int i = 0; i < HPASS; ++i)
+            hreg[i] = buf_load_b128(hr, want_head ? (uint32_t)(i * 4096 + tid * 16) : SPX_OOB, (uint32_t)(panel * head_lds));
+        p2reg = buf_load_f32(p2r, tid < NPB * 32 ? (uint32_t)tid * 4u : SPX_OOB, (uint32_t)(panel * NPB * 32 * 4));
+    };
+    auto consts_commit = [&]() {
+#pragma unroll
+        for (int i = 0; i < HPASS; ++i) *(u32x4*)(wlds + i * 4096 + tid * 16) = hreg[i];
+        if (tid < NPB * 32) p2s[tid] = p2reg;
     };
 
     // Panel epilogue as a ROLLED loop over the panel's 32-prototype blocks: the block being finished is always
@@ -158,34 +169,21 @@ __global__ __launch_bounds__(256, SPX_FWD_WAVES) void spx_fwd_kernel(const SpxFw
         }
     };
 
-    // One K-chunk of the software pipeline.  Global loads run two chunks ahead of the MFMAs: while chunk i
-    // computes from LDS[i&1], the registers of `nxt` (loaded during chunk i-1) are written to LDS[(i+1)&1] and
-    // `far` issues the loads of chunk i+2.  The body is branch-free (steps past the panel's last chunk load and
-    // stage zeros), so hipcc counts vmcnt exactly and the far loads stay in flight across the LDS write + barrier.
-    auto do_chunk = [&](const char* bank0, int ch0, int chunk, Stager& far, Stager& nxt) {
-        far.load(tc, bank0 + (size_t)(chunk + 2) * chunk_bytes, ch0 + (chunk + 2) * SPX_KC, Cs - (chunk + 2) * SPX_KC, tid);
-        char* cur = smem + (chunk & 1) * stage;
-        spx_compute_chunk<NPB>(acc, x2part, cur, cur + SPX_STAGE_X_BYTES, lane, wave);
-        char* dst = smem + ((chunk + 1) & 1) * stage;
-        nxt.write(dst, dst + SPX_STAGE_X_BYTES, tid);
-        __syncthreads();
-    };
-
-    const int nch_even = (nchunks + 1) & ~1;      // chunk pairs; an odd tail chunk is all zeros
+#ifdef SPX_DIAG_STAMPS
+    unsigned long long t0 = __builtin_amdgcn_s_memtime(), t1 = 0, t2 = 0;
+#endif
     for (int panel = 0; panel < pl.npanels; ++panel) {
         const char* bank0 = a.packed_bank + (size_t)(panel * nchunks) * chunk_bytes;
-        const int ch0 = pl.panel_ch0[panel];
         x2part = 0.0f;
-        stage_panel_consts(panel);
-        stA.load(tc, bank0, ch0, Cs, tid);
-        stB.load(tc, bank0 + chunk_bytes, ch0 + SPX_KC, Cs - SPX_KC, tid);
-        stA.write(smem, smem + SPX_STAGE_X_BYTES, tid);
-        __syncthreads();
-        for (int chunk = 0; chunk < nch_even; chunk += 2) {
-            do_chunk(bank0, ch0, chunk, stA, stB);
-            do_chunk(bank0, ch0, chunk + 1, stB, stA);
-        }
+        pipe.run_panel(acc, x2part, tc, smem, bank0, pl.panel_ch0[panel], Cs, lane, wave, tid,
+                       [&]() { consts_issue(panel); }, consts_commit);
+#ifdef SPX_DIAG_STAMPS
+        t1 = __builtin_amdgcn_s_memtime();
+#endif
         epilogue(panel);
+#ifdef SPX_DIAG_STAMPS
+        t2 = __builtin_amdgcn_s_memtime();
+#endif
         if (panel + 1 < pl.npanels) __syncthreads();   // next panel's prologue overwrites the head / |p|^2 / stage LDS
     }
 
@@ -201,6 +199,15 @@ __global__ __launch_bounds__(256, SPX_FWD_WAVES) void spx_fwd_kernel(const SpxFw
             }
         }
     }
+#ifdef SPX_DIAG_STAMPS
+    if (a.dbg && tid == 0) {
+        unsigned long long t3 = __builtin_amdgcn_s_memtime();
+        unsigned long long* d = a.dbg + (size_t)blockIdx.x * 4;
+        d[0] = t0; d[1] = t1; d[2] = t2; d[3] = t3;
+        unsigned long long* e = a.dbg + (size_t)gridDim.x * 4 + (size_t)blockIdx.x * 4;
+        e[0] = pipe.dg_compute; e[1] = pipe.dg_write; e[2] = pipe.dg_barrier; e[3] = 0;
+    }
+#endif
 }
 
 template <int NPB, int NCB>
