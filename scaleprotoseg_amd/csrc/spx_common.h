@@ -62,6 +62,32 @@ __device__ __forceinline__ void buf_store_b64(u32x2 v, spx_rsrc r, uint32_t voff
 // (cdna guide §3: row = (reg&3) + 8*(reg>>2) + 4*(lane>>5), col = lane&31).
 __device__ __forceinline__ int acc_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
 
+// Runtime-indexed access to a register array of accumulator tiles: a wave-uniform branch chain over static indices.
+// (A dynamically indexed ext_vector array goes to scratch, and hipcc turns a plain select chain back into one; the
+// empty asm statements keep the cases as separate basic blocks.  Rotating the array instead costs 16*(N-1) moves.)
+#define SPX_TILE_CASE(K)                         \
+    if (N > K && i == K) {                       \
+        v = t[N > K ? K : 0];                    \
+        asm volatile("; tile case " #K ::: );   \
+    }
+template <int N>
+__device__ __forceinline__ f32x16 tile_get(const f32x16 (&t)[N], int i) {
+    f32x16 v = t[0];
+    SPX_TILE_CASE(1) SPX_TILE_CASE(2) SPX_TILE_CASE(3) SPX_TILE_CASE(4) SPX_TILE_CASE(5)
+    return v;
+}
+#undef SPX_TILE_CASE
+#define SPX_TILE_CASE(K)                         \
+    if (N > K && i == K) {                       \
+        t[N > K ? K : 0] = v;                    \
+        asm volatile("; tile case " #K ::: );   \
+    }
+template <int N>
+__device__ __forceinline__ void tile_set(f32x16 (&t)[N], int i, const f32x16& v) {
+    SPX_TILE_CASE(0) SPX_TILE_CASE(1) SPX_TILE_CASE(2) SPX_TILE_CASE(3) SPX_TILE_CASE(4) SPX_TILE_CASE(5)
+}
+#undef SPX_TILE_CASE
+
 __device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }

@@ -9,14 +9,20 @@
 #ifndef SPX_FWD_WAVES
 #define SPX_FWD_WAVES 2
 #endif
-// X chunks in flight per workgroup (register ring): 4 for bf16 features (8 VGPRs each), 2 for fp32 (16 each)
+// X chunks in flight per workgroup (register ring).  A/B on MI355X: 2 beats 4 (0.74 vs 0.78 ms): the loads are not
+// what the loop waits for (in-kernel stamps: < 200 cycles per chunk), the extra registers only cost scheduling freedom
 #ifndef SPX_FWD_XRING
-#define SPX_FWD_XRING(xf32) ((xf32) ? 2 : 4)
+#define SPX_FWD_XRING(xf32) 2
 #endif
 
 // LDS carve (bytes): [stage 0][stage 1][head fragments of the current panel (NCB == 1 only)][|p|^2 of the panel]
+#ifdef SPX_FWD_HEAD_L2
+template <int NPB, int NCB>
+__host__ __device__ constexpr int spx_fwd_head_lds_bytes() { return 0; }   // experiment: head fragments straight from L2
+#else
 template <int NPB, int NCB>
 __host__ __device__ constexpr int spx_fwd_head_lds_bytes() { return NCB == 1 ? NPB * 4096 : 0; }
+#endif
 template <int NPB, int NCB>
 __host__ __device__ constexpr int spx_fwd_lds_bytes() {
     return 2 * spx_stage_bytes(NPB) + spx_fwd_head_lds_bytes<NPB, NCB>() + NPB * 32 * 4;
@@ -87,14 +93,15 @@ __global__ __launch_bounds__(256, SPX_FWD_WAVES) void spx_fwd_kernel(const SpxFw
         if (tid < NPB * 32) p2s[tid] = p2reg;
     };
 
-    // Panel epilogue as a ROLLED loop over the panel's 32-prototype blocks: the block being finished is always
-    // acc[0] and the accumulator array is rotated after each block (NPB-1 register-tile moves), so the body is
-    // compiled once with a small, fixed register footprint instead of NPB unrolled copies.
+    // Panel epilogue as a ROLLED loop over the panel's 32-prototype blocks (the body is compiled once, with a
+    // small fixed register footprint, instead of NPB unrolled copies); the block's accumulator tile is fetched
+    // with a wave-uniform select over static register indices and cleared for the next panel.
     auto epilogue = [&](int panel) {
         const float x2 = x2part + __shfl_xor(x2part, 32);
         const int p0 = pl.panel_p0[panel], np = pl.panel_np[panel];
 #pragma unroll 1
         for (int pb = 0; pb < NPB; ++pb) {
+            const f32x16 tile = tile_get<NPB>(acc, pb);
             if (pb * 32 < np) {
                 const spx_rsrc dr = make_rsrc_pred(a.dist ? a.dist + ((size_t)b * P + p0 + pb * 32) * a.HW : nullptr);
                 const spx_rsrc ar = make_rsrc_pred(a.act ? a.act + (size_t)b * a.HW * P + p0 + pb * 32 : nullptr);
@@ -106,7 +113,7 @@ __global__ __launch_bounds__(256, SPX_FWD_WAVES) void spx_fwd_kernel(const SpxFw
                     // rows 8*g4 + 4h + (0..3) of the block <-> registers 4*g4..4*g4+3
                     const f32x4 p2v = *(const f32x4*)(p2s + pb * 32 + 8 * g4 + 4 * h);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) dv[4 * g4 + e] = fmaxf(__builtin_fmaf(-2.0f, acc[0][4 * g4 + e], p2v[e]) + x2, 0.0f);
+                    for (int e = 0; e < 4; ++e) dv[4 * g4 + e] = fmaxf(__builtin_fmaf(-2.0f, tile[4 * g4 + e], p2v[e]) + x2, 0.0f);
                 }
                 if (a.act_fn == 0) {
 #pragma unroll
@@ -161,12 +168,12 @@ __global__ __launch_bounds__(256, SPX_FWD_WAVES) void spx_fwd_kernel(const SpxFw
                     }
                 }
             }
-            // rotate: next block -> acc[0]; the vacated slot is zero (= the next panel's initial accumulator)
-#pragma unroll
-            for (int i = 0; i + 1 < NPB; ++i) acc[i] = acc[i + 1];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[NPB - 1][i] = 0.0f;
         }
+        // the next panel accumulates from zero
+#pragma unroll
+        for (int pb = 0; pb < NPB; ++pb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[pb][i] = 0.0f;
     };
 
 #ifdef SPX_DIAG_STAMPS
