@@ -84,6 +84,7 @@ def main():
     ap.add_argument("--x-dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--grads", default="logits,dist", help="diagnostic only: which output gradients flow back")
+    ap.add_argument("--outputs", default="logits,dist", help="diagnostic only: 'logits' = logits-only forward (no fp32 distance map)")
     ap.add_argument("--freeze", default="", help="diagnostic only: comma list of x,bank,head to exclude from the backward")
     args = ap.parse_args()
 
@@ -134,11 +135,12 @@ def main():
         x.grad = None
         bank.grad = None
         head.grad = None
-        logits, dmap, _ = spx.proto_head_forward(x, bank, head, layout, want_distances=True)
+        want_d = "dist" in args.outputs
+        logits, dmap, _ = spx.proto_head_forward(x, bank, head, layout, want_distances=want_d)
         outs, gouts = [], []
         if "logits" in args.grads:
             outs.append(logits); gouts.append(g_logits)
-        if "dist" in args.grads:
+        if "dist" in args.grads and want_d:
             outs.append(dmap); gouts.append(g_dist)
         torch.autograd.backward(outs, gouts)
         if world > 1:
@@ -220,6 +222,16 @@ def main():
             # algorithmic bytes of the operator (for the backward: of the whole backward, charged to its pixel-side
             # kernel; the parameter-side reduction moves no algorithmic bytes, its time shows in roofline_step)
             ach = op_bytes[dominant] / (dom_ms * 1e-3) / 1e9 if op_bytes.get(dominant) else (fwd_b + bwd_b) * M / (dom_ms * 1e-3) / 1e9
+            # HBM bytes per launch of the dominant kernel from the PMC passes (FETCH_SIZE x2 + WRITE_SIZE, see
+            # profiles/ and tools/summarize_profile.py); only valid for the default workload / dtype
+            traffic = None
+            tfile = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(tfile) and args.workload == "cityscapes_1024x2048_c256_p190_s1" and args.x_dtype == "bf16" \
+                    and args.outputs == "logits,dist" and args.grads == "logits,dist" and not args.freeze:
+                try:
+                    traffic = json.load(open(tfile)).get(dominant)
+                except Exception:
+                    traffic = None
             out["roofline"] = {
                 "kernel": dominant,
                 "bound": "hbm",
@@ -227,7 +239,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBS, 4),
-                "traffic": None,
+                "traffic": traffic,
             }
             step_gbs = (fwd_b + bwd_b) * M / (ms_per_step * 1e-3) / 1e9
             out["roofline_step"] = {

@@ -183,24 +183,30 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
         // frees (16 registers), so after NPB iterations acc[i] holds block i's fragments and no second register
         // array is needed.
         float rs = 0.0f;
-        float ddn[16];              // dDist of the NEXT block: its loads run one block ahead
-        auto load_ddist = [&](int pb) {
+        float ddA[16], ddB[16];     // dDist of the current / next block (double-buffered: the loop is unrolled by 2)
+        auto load_ddist = [&](int pb, float (&dst)[16]) {
             const spx_rsrc ddr = make_rsrc_pred(a.d_dist + ((size_t)b * P + p0 + pb * 32) * a.HW);
-            const bool full = pb * 32 + 32 <= np;
+            if (pb * 32 + 32 <= np) {     // wave-uniform: whole block real, no row predication
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int rb = (reg & 3) + 8 * (reg >> 2);
-                ddn[reg] = buf_load_f32(ddr, (full || (pb * 32 + rb + 4 * h < np)) ? voff_d : SPX_OOB, (uint32_t)rb * HW * 4u);
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int rb = (reg & 3) + 8 * (reg >> 2);
+                    dst[reg] = buf_load_f32(ddr, voff_d, (uint32_t)rb * HW * 4u);
+                }
+            } else {
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int rb = (reg & 3) + 8 * (reg >> 2);
+                    dst[reg] = buf_load_f32(ddr, (pb * 32 + rb + 4 * h < np) ? voff_d : SPX_OOB, (uint32_t)rb * HW * 4u);
+                }
             }
         };
-        if (a.d_dist) {
-            load_ddist(0);
-        } else {
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) ddn[reg] = 0.0f;
-        }
-#pragma unroll 1
-        for (int pb = 0; pb < NPB; ++pb) {
+        for (int reg = 0; reg < 16; ++reg) ddA[reg] = ddB[reg] = 0.0f;
+        if (a.d_dist) load_ddist(0, ddA);
+        const bool tile_full = px0 + SPX_TILE_PX <= a.HW;      // wave-uniform: every pixel of the tile is real
+
+        // one prototype block: always acc[0] (the array is rotated afterwards); ddc = its dDist, ddnext = prefetch target
+        auto block = [&](int pb, float (&ddc)[16], float (&ddnext)[16]) {
             bf16x8 gnew[2], anew[2];
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2)
@@ -210,23 +216,8 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
                     anew[s2][j] = (__bf16)0.0f;
                 }
             if (pb < nv) {
-                float ddc[16];
-#pragma unroll
-                for (int i = 0; i < 16; ++i) ddc[i] = ddn[i];
-                if (a.d_dist && pb + 1 < nv) load_ddist(pb + 1);
+                if (a.d_dist && pb + 1 < nv) load_ddist(pb + 1, ddnext);
                 const bool full = pb * 32 + 32 <= np;
-                float dac[16];
-                if (a.d_act) {
-                    const spx_rsrc dar = make_rsrc_pred(a.d_act + (size_t)b * a.HW * P + p0 + pb * 32);
-#pragma unroll
-                    for (int reg = 0; reg < 16; ++reg) {
-                        const int rb = (reg & 3) + 8 * (reg >> 2);
-                        dac[reg] = buf_load_f32(dar, (full || (pb * 32 + rb + 4 * h < np)) ? voff_a : SPX_OOB, (uint32_t)(rb * 4));
-                    }
-                } else {
-#pragma unroll
-                    for (int reg = 0; reg < 16; ++reg) dac[reg] = 0.0f;
-                }
                 f32x16 ga;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) ga[i] = 0.0f;
@@ -248,23 +239,57 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
                         ga = mfma_bf16(whi, dllo[c], ga);
                     }
                 }
+                if (a.d_act) {   // group phase only: gradient arriving on the activations
+                    const spx_rsrc dar = make_rsrc_pred(a.d_act + (size_t)b * a.HW * P + p0 + pb * 32);
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        const int rb = (reg & 3) + 8 * (reg >> 2);
+                        ga[reg] += buf_load_f32(dar, (full || (pb * 32 + rb + 4 * h < np)) ? voff_a : SPX_OOB, (uint32_t)(rb * 4));
+                    }
+                }
+                // straight-line element math, no per-element control flow: d, act'(d) [and a], then G
+                float dr[16], dact[16], av[16];
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
                     const f32x4 p2v = *(const f32x4*)(p2s + pb * 32 + 8 * g4 + 4 * h);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int reg = 4 * g4 + e;
-                        const bool valid = px_ok && (full || (pb * 32 + 8 * g4 + 4 * h + e < np));
-                        const float d_raw = __builtin_fmaf(-2.0f, acc[0][reg], p2v[e]) + x2;
-                        const float d = fmaxf(d_raw, 0.0f);
-                        const float dact = act_is_log ? act_log_grad(d, a.eps) : -1.0f;
-                        const float aval = act_is_log ? act_log(d, a.eps) : -d;
-                        const float G = (valid && d_raw > 0.0f) ? ddc[reg] + (ga[reg] + dac[reg]) * dact : 0.0f;
-                        rs += G;
-                        // register reg = 8 s2 + j of the tile -> element j of k-step s2 of the B fragment
-                        gnew[g4 >> 1][4 * (g4 & 1) + e] = (__bf16)G;
-                        anew[g4 >> 1][4 * (g4 & 1) + e] = (__bf16)(valid ? aval : 0.0f);
+                    for (int e = 0; e < 4; ++e) dr[4 * g4 + e] = __builtin_fmaf(-2.0f, acc[0][4 * g4 + e], p2v[e]) + x2;
+                }
+                if (act_is_log) {
+                    const float c1 = -(1.0f - a.eps);
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        const float d = fmaxf(dr[reg], 0.0f);
+                        const float t1 = d + 1.0f, t2 = d + a.eps;
+                        const float rp = __builtin_amdgcn_rcpf(t1 * t2);          // 1 / ((d+1)(d+eps))
+                        dact[reg] = c1 * rp;                                       // act'(d)
+                        av[reg] = __builtin_amdgcn_logf(t1 * t1 * rp) * 0.69314718056f;   // log((d+1)/(d+eps))
                     }
+                } else {
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        dact[reg] = -1.0f;
+                        av[reg] = -fmaxf(dr[reg], 0.0f);
+                    }
+                }
+                float gv[16];
+                if (full && tile_full) {
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) gv[reg] = dr[reg] > 0.0f ? __builtin_fmaf(ga[reg], dact[reg], ddc[reg]) : 0.0f;
+                } else {
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        const bool valid = px_ok && (pb * 32 + acc_row(reg, h) < np);
+                        gv[reg] = (valid && dr[reg] > 0.0f) ? __builtin_fmaf(ga[reg], dact[reg], ddc[reg]) : 0.0f;
+                        av[reg] = valid ? av[reg] : 0.0f;
+                    }
+                }
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    rs += gv[reg];
+                    // register reg = 8 s2 + j of the tile -> element j of k-step s2 of the B fragment
+                    gnew[reg >> 3][reg & 7] = (__bf16)gv[reg];
+                    anew[reg >> 3][reg & 7] = (__bf16)av[reg];
                 }
             }
             {
@@ -290,6 +315,13 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
                     acc[NPB - 1][12 + i] = 0.0f;
                 }
             }
+        };
+        // ROLLED loop, two blocks per iteration (static dDist buffers); exactly NPB block steps, so the rotation
+        // ends aligned: acc[i] = block i's G fragments
+#pragma unroll 1
+        for (int pb = 0; pb < NPB; pb += 2) {
+            block(pb, ddA, ddB);
+            block(pb + 1, ddB, ddA);
         }
 #ifdef SPX_DIAG_STAMPS
         dg_t2 = __builtin_amdgcn_s_memtime();
@@ -485,6 +517,7 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
         t3 = __builtin_amdgcn_s_memtime();
         unsigned long long* d = a.dbg + (size_t)blockIdx.x * 4;
         d[0] = t0; d[1] = t1; d[2] = dg_t2; d[3] = t3;
+
     }
 #endif
 }
