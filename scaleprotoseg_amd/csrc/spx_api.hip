@@ -135,6 +135,7 @@ int spx_dist_fwd(const spx_plan* pl, const void* x, int32_t x_dtype, int32_t B, 
     a.B = B;
     a.HW = HW;
     a.vec_ok = x_vec_ok(x, x_dtype, HW);
+    a.dist_vec = distances && ((uintptr_t)distances & 15) == 0 && HW % 4 == 0;
     a.eps = epsilon;
     a.act_fn = act_fn;
     a.dbg = g_dbg;

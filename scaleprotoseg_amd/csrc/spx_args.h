@@ -12,6 +12,7 @@ struct SpxFwdArgs {
     float* act;
     float* logits;
     int B, HW, vec_ok;
+    int dist_vec;              // distances 16-B aligned and HW % 4 == 0: 16-B stores of 4 pixels of a row
     float eps;
     int act_fn;
     unsigned long long* dbg;   // diagnostic builds only (SPX_DIAG_STAMPS): per-workgroup phase clocks

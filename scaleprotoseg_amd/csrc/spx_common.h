@@ -48,8 +48,13 @@ __device__ __forceinline__ void buf_store_u16(uint16_t v, spx_rsrc r, uint32_t v
 __device__ __forceinline__ u32x4 buf_load_b128(spx_rsrc r, uint32_t voff, uint32_t soff) {
     return __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
 }
+// 16-B store.  The wave-uniform offset is ADDED INTO the VGPR offset, soffset stays the literal 0: with an SGPR
+// soffset hipcc (ROCm 7.2) assumes a >64-bit buffer store has no "VALU overwrites vdata right after issue" hazard
+// and may re-use the first data register in the very next instruction; on gfx950 the store then intermittently
+// writes that new value for its late lane groups (seen as small integers in dword 0 of lanes 12-15/28-31/...).
+// With a literal soffset the hazard recognizer pads the two wait states itself.  SPX_OOB + soff stays out of range.
 __device__ __forceinline__ void buf_store_b128(u32x4 v, spx_rsrc r, uint32_t voff, uint32_t soff) {
-    __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, voff + soff, 0, 0);
 }
 __device__ __forceinline__ u32x2 buf_load_b64(spx_rsrc r, uint32_t voff, uint32_t soff) {
     return __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);

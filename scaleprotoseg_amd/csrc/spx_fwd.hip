@@ -11,10 +11,17 @@
 #endif
 // X chunks in flight per workgroup (register ring).  A/B on MI355X: 2 beats 4 (0.74 vs 0.78 ms): the loads are not
 // what the loop waits for (in-kernel stamps: < 200 cycles per chunk), the extra registers only cost scheduling freedom
+#ifndef SPX_FWD_SPLIT
+#define SPX_FWD_SPLIT 1
+#endif
 #ifndef SPX_FWD_XRING
 #define SPX_FWD_XRING(xf32) 2
 #endif
 
+// per-wave LDS scratch of the epilogue's distance-tile turn: 32 prototype rows x 32 pixels fp32, 160-B rows (the
+// two half-waves land 32 banks apart: conflict-free writes); aliases the main-loop stages, free after the loop
+#define SPX_FWD_TROW 40
+#define SPX_FWD_TSCRATCH (32 * SPX_FWD_TROW * 4)
 // LDS carve (bytes): [stage 0][stage 1][head fragments of the current panel (NCB == 1 only)][|p|^2 of the panel]
 #ifdef SPX_FWD_HEAD_L2
 template <int NPB, int NCB>
@@ -23,17 +30,30 @@ __host__ __device__ constexpr int spx_fwd_head_lds_bytes() { return 0; }   // ex
 template <int NPB, int NCB>
 __host__ __device__ constexpr int spx_fwd_head_lds_bytes() { return NCB == 1 ? NPB * 4096 : 0; }
 #endif
-template <int NPB, int NCB>
+// region 0 = the two main-loop stages, re-used after the loop as the waves' epilogue scratch
+template <int NPB, int SPLIT>
+__host__ __device__ constexpr int spx_fwd_region0_bytes() {
+    return 2 * spx_stage_bytes(NPB) > 4 * SPLIT * SPX_FWD_TSCRATCH ? 2 * spx_stage_bytes(NPB) : 4 * SPLIT * SPX_FWD_TSCRATCH;
+}
+template <int NPB, int NCB, int SPLIT>
 __host__ __device__ constexpr int spx_fwd_lds_bytes() {
-    return 2 * spx_stage_bytes(NPB) + spx_fwd_head_lds_bytes<NPB, NCB>() + NPB * 32 * 4;
+    return spx_fwd_region0_bytes<NPB, SPLIT>() + spx_fwd_head_lds_bytes<NPB, NCB>() + NPB * 32 * 4;
 }
 
-template <int NPB, int NCB, bool XF32, bool VEC>
-__global__ __launch_bounds__(256, SPX_FWD_WAVES) void spx_fwd_kernel(const SpxFwdArgs a) {
+// SPLIT = waves per 32-pixel group.  SPLIT 1: 4 waves, each with all NPB blocks of its pixels (<= 256 VGPRs, two
+// waves per SIMD).  SPLIT 2: 8 waves, wave (pg = w & 3, ph = w >> 2) accumulates blocks [ph*NPB/2, (ph+1)*NPB/2) of
+// pixel group pg in <= 128 VGPRs: four waves per SIMD instead of two hide the LDS / HBM / transcendental latencies
+// that a two-wave SIMD leaves exposed (the kernel was issue-stalled, not bandwidth-bound: MFMA 17 % + VALU ~42 %
+// busy); the two halves' logits partials meet in LDS at the end.
+template <int NPB, int NCB, bool XF32, bool VEC, int SPLIT>
+__global__ __launch_bounds__(256 * SPLIT, SPX_FWD_WAVES * SPLIT) void spx_fwd_kernel(const SpxFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NT = 256 * SPLIT, NH = NPB / SPLIT;
+    static_assert(NPB % SPLIT == 0, "blocks must split evenly over the waves of a pixel group");
     const spx_plan& pl = a.plan;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pg = wave & 3, ph = wave >> 2;       // pixel group, prototype half
     const int r = lane & 31, h = lane >> 5;
     const int tiles_per_img = (a.HW + SPX_TILE_PX - 1) / SPX_TILE_PX;
     const int b = blockIdx.x / tiles_per_img;
@@ -43,53 +63,65 @@ __global__ __launch_bounds__(256, SPX_FWD_WAVES) void spx_fwd_kernel(const SpxFw
     const int P = pl.num_prototypes, K = pl.num_classes;
     const uint32_t HW = (uint32_t)a.HW;
     constexpr int XR = SPX_FWD_XRING(XF32);
-    using Pipe = SpxPipeline<NPB, XF32, VEC, XR>;
+    using Pipe = SpxPipeline<NPB, XF32, VEC, XR, NT, NH>;
 
-    const SpxTileCtx tc = SpxXStager<XF32, VEC>::make_ctx((const char*)a.x + (size_t)b * C * a.HW * (XF32 ? 4 : 2), a.HW, px0, tid);
+#ifdef SPX_DIAG_STAGGER
+    // experiment: de-phase the two workgroups that share a CU (blocks i and i+256 of the first dispatch round)
+    if (blockIdx.x >= 256 && blockIdx.x < 512)
+        for (int i = 0; i < SPX_DIAG_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+#endif
+    const SpxTileCtx tc = SpxXStager<XF32, VEC, NT>::make_ctx((const char*)a.x + (size_t)b * C * a.HW * (XF32 ? 4 : 2), a.HW, px0, tid);
 
-    constexpr int stage = spx_stage_bytes(NPB);
     constexpr int chunk_bytes = NPB * 2 * 1024;
     constexpr int head_lds = spx_fwd_head_lds_bytes<NPB, NCB>();
+    constexpr int region0 = spx_fwd_region0_bytes<NPB, SPLIT>();
     const int nchunks = (Cs + SPX_KC - 1) / SPX_KC;
-    char* const wlds = smem + 2 * stage;
+    char* const wlds = smem + region0;
     float* const p2s = (float*)(wlds + head_lds);
 
     Pipe pipe;
-    f32x16 acc[NPB];
+    f32x16 acc[NH];
     f32x16 accl[NCB];
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
         for (int i = 0; i < 16; ++i) accl[cb][i] = 0.0f;
 #pragma unroll
-    for (int pb = 0; pb < NPB; ++pb)
+    for (int pb = 0; pb < NH; ++pb)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[pb][i] = 0.0f;
     float x2part = 0.0f;
 
-    const int px = px0 + 32 * wave + r;        // this lane's pixel
+    const int px = px0 + 32 * pg + r;          // this lane's pixel
     const bool px_ok = px < a.HW;
     const bool want_head = a.logits != nullptr;
     // per-lane byte offsets, fixed for the whole kernel (SPX_OOB = access dropped); row / block selection
     // rides on wave-uniform SGPR offsets
     const uint32_t voff_d = px_ok ? ((uint32_t)(4 * h) * HW + (uint32_t)px) * 4u : SPX_OOB;                 // [row][px]
+    // wide distance stores: lane = (row lane>>3 of an 8-row group, 4 pixels 4*(lane&7)..+3 of the wave's 32)
+    const int pxw = px0 + 32 * pg + 4 * (lane & 7);
+    const uint32_t voff_dw = pxw < a.HW ? ((uint32_t)(lane >> 3) * HW + (uint32_t)pxw) * 4u : SPX_OOB;
     const uint32_t voff_a = px_ok ? ((uint32_t)px * (uint32_t)P + (uint32_t)(4 * h)) * 4u : SPX_OOB;        // [px][row]
     const spx_rsrc hr = make_rsrc_pred(a.packed_head);
     const spx_rsrc p2r = make_rsrc_pred(a.p2);
 
     // panel prologue: head fragments + |p|^2 of the panel -> LDS (read in the epilogue, after >= 1 barrier)
-    constexpr int HPASS = head_lds / 4096;
+    constexpr int HPB = NT * 16;                        // bytes per pass of the whole workgroup
+    constexpr int HPASS = (head_lds + HPB - 1) / HPB;
+    static_assert(head_lds % HPB == 0 || head_lds < HPB, "head fragments: whole passes, or one partial pass");
+    const bool h_in = head_lds >= HPB || tid * 16 < head_lds;
     u32x4 hreg[HPASS > 0 ? HPASS : 1];
     float p2reg = 0.0f;
     auto consts_issue = [&](int panel) {
 #pragma unroll
         for (int i = 0; i < HPASS; ++i)
-            hreg[i] = buf_load_b128(hr, want_head ? (uint32_t)(i * 4096 + tid * 16) : SPX_OOB, (uint32_t)(panel * head_lds));
+            hreg[i] = buf_load_b128(hr, (want_head && h_in) ? (uint32_t)(i * HPB + tid * 16) : SPX_OOB, (uint32_t)(panel * head_lds));
         p2reg = buf_load_f32(p2r, tid < NPB * 32 ? (uint32_t)tid * 4u : SPX_OOB, (uint32_t)(panel * NPB * 32 * 4));
     };
     auto consts_commit = [&]() {
 #pragma unroll
-        for (int i = 0; i < HPASS; ++i) *(u32x4*)(wlds + i * 4096 + tid * 16) = hreg[i];
+        for (int i = 0; i < HPASS; ++i)
+            if (h_in) *(u32x4*)(wlds + i * HPB + tid * 16) = hreg[i];
         if (tid < NPB * 32) p2s[tid] = p2reg;
     };
 
@@ -100,8 +132,9 @@ __global__ __launch_bounds__(256, SPX_FWD_WAVES) void spx_fwd_kernel(const SpxFw
         const float x2 = x2part + __shfl_xor(x2part, 32);
         const int p0 = pl.panel_p0[panel], np = pl.panel_np[panel];
 #pragma unroll 1
-        for (int pb = 0; pb < NPB; ++pb) {
-            const f32x16 tile = tile_get<NPB>(acc, pb);
+        for (int pbl = 0; pbl < NH; ++pbl) {
+            const int pb = ph * NH + pbl;              // block index inside the panel
+            const f32x16 tile = tile_get<NH>(acc, pbl);
             if (pb * 32 < np) {
                 const spx_rsrc dr = make_rsrc_pred(a.dist ? a.dist + ((size_t)b * P + p0 + pb * 32) * a.HW : nullptr);
                 const spx_rsrc ar = make_rsrc_pred(a.act ? a.act + (size_t)b * a.HW * P + p0 + pb * 32 : nullptr);
@@ -122,7 +155,20 @@ __global__ __launch_bounds__(256, SPX_FWD_WAVES) void spx_fwd_kernel(const SpxFw
 #pragma unroll
                     for (int reg = 0; reg < 16; ++reg) av[reg] = -dv[reg];
                 }
-                if (a.dist) {
+                if (a.dist && a.dist_vec) {
+                    // store-issue is what bounds this epilogue (one VMEM instruction per 256 B with a pixel per
+                    // lane): turn the tile through the wave's LDS scratch so a lane owns 4 consecutive pixels of
+                    // one prototype row -> 4 16-B stores per block instead of 16 dword stores, same bytes
+                    float* const sc = (float*)(smem + wave * SPX_FWD_TSCRATCH);
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) sc[((reg & 3) + 8 * (reg >> 2) + 4 * h) * SPX_FWD_TROW + r] = dv[reg];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 v = *(const f32x4*)(sc + (8 * q + (lane >> 3)) * SPX_FWD_TROW + 4 * (lane & 7));
+                        const uint32_t vo = (full || (pb * 32 + 8 * q + (lane >> 3) < np)) ? voff_dw : SPX_OOB;
+                        buf_store_b128(__builtin_bit_cast(u32x4, v), dr, vo, (uint32_t)(8 * q) * HW * 4u);
+                    }
+                } else if (a.dist) {
 #pragma unroll
                     for (int reg = 0; reg < 16; ++reg) {
                         const int rb = (reg & 3) + 8 * (reg >> 2);
@@ -171,7 +217,7 @@ __global__ __launch_bounds__(256, SPX_FWD_WAVES) void spx_fwd_kernel(const SpxFw
         }
         // the next panel accumulates from zero
 #pragma unroll
-        for (int pb = 0; pb < NPB; ++pb)
+        for (int pb = 0; pb < NH; ++pb)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[pb][i] = 0.0f;
     };
@@ -194,7 +240,22 @@ __global__ __launch_bounds__(256, SPX_FWD_WAVES) void spx_fwd_kernel(const SpxFw
         if (panel + 1 < pl.npanels) __syncthreads();   // next panel's prologue overwrites the head / |p|^2 / stage LDS
     }
 
-    if (want_head) {
+    if (want_head && SPLIT == 2) {
+        // the upper prototype half hands its logits partial to the lower one through its own scratch tile
+        // (wave-private until here: its last transposed reads were issued before, LDS serves a wave in order)
+        float* const sc = (float*)(smem + (4 + pg) * SPX_FWD_TSCRATCH);
+        static_assert(NCB == 1 || SPLIT == 1, "the split kernel carries one class block");
+        if (ph == 1) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) sc[reg * 64 + lane] = accl[0][reg];
+        }
+        __syncthreads();
+        if (ph == 0) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) accl[0][reg] += sc[reg * 64 + lane];
+        }
+    }
+    if (want_head && ph == 0) {
         const spx_rsrc lr = make_rsrc_pred(a.logits + (size_t)b * a.HW * K);
         const uint32_t voff_l = px_ok ? ((uint32_t)px * (uint32_t)K + (uint32_t)(4 * h)) * 4u : SPX_OOB;   // [px][class]
 #pragma unroll
@@ -212,20 +273,21 @@ __global__ __launch_bounds__(256, SPX_FWD_WAVES) void spx_fwd_kernel(const SpxFw
         unsigned long long* d = a.dbg + (size_t)blockIdx.x * 4;
         d[0] = t0; d[1] = t1; d[2] = t2; d[3] = t3;
         unsigned long long* e = a.dbg + (size_t)gridDim.x * 4 + (size_t)blockIdx.x * 4;
-        e[0] = pipe.dg_compute; e[1] = pipe.dg_write; e[2] = pipe.dg_barrier; e[3] = 0;
+        e[0] = pipe.dg_compute; e[1] = pipe.dg_write; e[2] = pipe.dg_barrier; e[3] = pipe.dg_issue;
     }
 #endif
 }
 
-template <int NPB, int NCB>
+template <int NPB, int NCB, int SPLIT>
 static hipError_t launch_fwd_x(const SpxFwdArgs& a, int x_dtype, dim3 grid, hipStream_t s) {
-    constexpr size_t lds = (size_t)spx_fwd_lds_bytes<NPB, NCB>();
+    constexpr size_t lds = (size_t)spx_fwd_lds_bytes<NPB, NCB, SPLIT>();
+    const dim3 blk(256 * SPLIT);
     if (x_dtype == 1) {
-        if (a.vec_ok) hipLaunchKernelGGL((spx_fwd_kernel<NPB, NCB, true, true>), grid, dim3(256), lds, s, a);
-        else hipLaunchKernelGGL((spx_fwd_kernel<NPB, NCB, true, false>), grid, dim3(256), lds, s, a);
+        if (a.vec_ok) hipLaunchKernelGGL((spx_fwd_kernel<NPB, NCB, true, true, SPLIT>), grid, blk, lds, s, a);
+        else hipLaunchKernelGGL((spx_fwd_kernel<NPB, NCB, true, false, SPLIT>), grid, blk, lds, s, a);
     } else {
-        if (a.vec_ok) hipLaunchKernelGGL((spx_fwd_kernel<NPB, NCB, false, true>), grid, dim3(256), lds, s, a);
-        else hipLaunchKernelGGL((spx_fwd_kernel<NPB, NCB, false, false>), grid, dim3(256), lds, s, a);
+        if (a.vec_ok) hipLaunchKernelGGL((spx_fwd_kernel<NPB, NCB, false, true, SPLIT>), grid, blk, lds, s, a);
+        else hipLaunchKernelGGL((spx_fwd_kernel<NPB, NCB, false, false, SPLIT>), grid, blk, lds, s, a);
     }
     return hipGetLastError();
 }
@@ -235,11 +297,16 @@ hipError_t spx_launch_fwd(const SpxFwdArgs& a, int x_dtype, hipStream_t s) {
     const int tiles = (a.HW + SPX_TILE_PX - 1) / SPX_TILE_PX;
     dim3 grid((unsigned)(tiles * a.B));
     if (pl.ncb == 1) {
-        if (pl.npb == 2) return launch_fwd_x<2, 1>(a, x_dtype, grid, s);
-        if (pl.npb == 4) return launch_fwd_x<4, 1>(a, x_dtype, grid, s);
-        return launch_fwd_x<6, 1>(a, x_dtype, grid, s);
+        // SPX_FWD_SPLIT 2 = 8-wave workgroups (4 waves per SIMD).  Measured on MI355X at the north-star shape:
+        // 0.84 ms against 0.72 ms for SPLIT 1 -- the kernel is bound by VALU issue throughput (one wave64 VALU
+        // instruction per 4 SIMD cycles, ~2300 of them per wave-tile) plus the MFMA pipe, not by exposed latency,
+        // so more waves per SIMD only add barrier and staging overhead.
+        if (pl.npb == 2) return launch_fwd_x<2, 1, SPX_FWD_SPLIT>(a, x_dtype, grid, s);
+        if (pl.npb == 4) return launch_fwd_x<4, 1, SPX_FWD_SPLIT>(a, x_dtype, grid, s);
+        return launch_fwd_x<6, 1, SPX_FWD_SPLIT>(a, x_dtype, grid, s);
     }
-    if (pl.npb == 2) return launch_fwd_x<2, 5>(a, x_dtype, grid, s);
-    if (pl.npb == 4) return launch_fwd_x<4, 5>(a, x_dtype, grid, s);
-    return launch_fwd_x<6, 5>(a, x_dtype, grid, s);
+    // up to 160 classes: 80 logits accumulators per lane, one wave per pixel group
+    if (pl.npb == 2) return launch_fwd_x<2, 5, 1>(a, x_dtype, grid, s);
+    if (pl.npb == 4) return launch_fwd_x<4, 5, 1>(a, x_dtype, grid, s);
+    return launch_fwd_x<6, 5, 1>(a, x_dtype, grid, s);
 }

@@ -26,31 +26,29 @@
 
 struct SpxTileCtx {
     const char* x_img;    // features of image b, channel 0, pixel 0
-    uint32_t x_voff;      // this thread's byte offset inside a 16-row pass: (row0 * HW + px) * esz, or SPX_OOB
+    uint32_t x_voff;      // this thread's byte offset inside a pass: (row0 * HW + px) * esz, or SPX_OOB
     uint32_t hw;          // pixels per image
     int px;               // first of this thread's 8 staged pixels
-    int row0;             // this thread's row inside a 16-row pass
+    int row0;             // this thread's row inside a pass of NT/16 rows
 };
 
-// One staged K-chunk: acc[pb] += Bank_chunk[pb] . X_chunk, x2 += |x|^2 partial (this lane's k-half).
-template <int NPB>
-__device__ __forceinline__ void spx_compute_chunk(f32x16 (&acc)[NPB], float& x2part, const char* xs, const char* as,
-                                                  int lane, int wave) {
+// One staged K-chunk: acc[i] += Bank_chunk[pb0 + i] . X_chunk (i < NH: the wave's share of the panel's NPB blocks),
+// x2 += |x|^2 partial (this lane's k-half).  pg = the wave's 32-pixel group inside the 128-pixel tile.
+template <int NPB, int NH>
+__device__ __forceinline__ void spx_compute_chunk(f32x16 (&acc)[NH], float& x2part, const char* xs, const char* as,
+                                                  int lane, int pg, int pb0) {
     constexpr int NKS = SPX_KC / 16;
     const int g = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
-    // transposed-read address of this lane: row 8*(g>>1)+q of the k-step, 4 pixels at 32*wave+16*(g&1)+4*pp
-    const char* xb = xs + ((8 * (g >> 1) + q) * SPX_XROW + 32 * wave + 16 * (g & 1) + 4 * pp) * 2;
-    const char* ab = as + lane * 16;
+    // transposed-read address of this lane: row 8*(g>>1)+q of the k-step, 4 pixels at 32*pg+16*(g&1)+4*pp
+    const char* xb = xs + ((8 * (g >> 1) + q) * SPX_XROW + 32 * pg + 16 * (g & 1) + 4 * pp) * 2;
+    const char* ab = as + lane * 16 + pb0 * (NKS * 1024);
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
         const s16x4 t0 = lds_tr_read(xb + ks * (16 * SPX_XROW * 2));
         const s16x4 t1 = lds_tr_read(xb + ks * (16 * SPX_XROW * 2) + 4 * SPX_XROW * 2);
-        bf16x8 bfrag;
-        {
-            const bf16x4 b0 = __builtin_bit_cast(bf16x4, t0);
-            const bf16x4 b1 = __builtin_bit_cast(bf16x4, t1);
-            bfrag = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
-        }
+        const bf16x4 b0 = __builtin_bit_cast(bf16x4, t0);
+        const bf16x4 b1 = __builtin_bit_cast(bf16x4, t1);
+        const bf16x8 bfrag = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             bf16x2 p2v;
@@ -58,18 +56,21 @@ __device__ __forceinline__ void spx_compute_chunk(f32x16 (&acc)[NPB], float& x2p
             p2v[1] = bfrag[2 * e + 1];
             x2part = __builtin_amdgcn_fdot2_f32_bf16(p2v, p2v, x2part, false);
         }
+        // (issuing every fragment read of the chunk up front was measured: no gain, +48 VGPRs)
 #pragma unroll
-        for (int pb = 0; pb < NPB; ++pb) {
+        for (int pb = 0; pb < NH; ++pb) {
             const bf16x8 afrag = *(const bf16x8*)(ab + (pb * NKS + ks) * 1024);
             acc[pb] = mfma_bf16(afrag, bfrag, acc[pb]);
         }
     }
 }
 
-// X stager: the registers of one 32-channel chunk of the tile (2 passes of 16 rows x 8 px per thread)
-template <bool XF32, bool VEC>
+// X stager: the registers of one 32-channel chunk of the tile (XPASS passes of NT/16 rows x 8 px per thread;
+// NT = threads of the workgroup, 256 or 512)
+template <bool XF32, bool VEC, int NT = 256>
 struct SpxXStager {
-    static constexpr int XPASS = SPX_KC / 16;
+    static constexpr int RPP = NT / 16;           // rows per pass
+    static constexpr int XPASS = SPX_KC / RPP;
     static constexpr int ESZ = XF32 ? 4 : 2;
     u32x4 xr[XPASS][XF32 ? 2 : 1];
 
@@ -91,8 +92,8 @@ struct SpxXStager {
         const spx_rsrc xr_ = make_rsrc_pred(t.x_img + (size_t)ch_first * t.hw * ESZ);
 #pragma unroll
         for (int i = 0; i < XPASS; ++i) {
-            const uint32_t soff = (uint32_t)(16 * i) * t.hw * ESZ;
-            const bool row_ok = t.row0 + 16 * i < ch_left;
+            const uint32_t soff = (uint32_t)(RPP * i) * t.hw * ESZ;
+            const bool row_ok = t.row0 + RPP * i < ch_left;
             if (VEC) {
                 const uint32_t vo = row_ok ? t.x_voff : SPX_OOB;
                 xr[i][0] = buf_load_b128(xr_, vo, soff);
@@ -130,18 +131,22 @@ struct SpxXStager {
             } else {
                 v = xr[i][0];
             }
-            *(u32x4*)(xs + (row0 + 16 * i) * (SPX_XROW * 2) + piece * 16) = v;
+            *(u32x4*)(xs + (row0 + RPP * i) * (SPX_XROW * 2) + piece * 16) = v;
         }
     }
 };
 
 // bank stager: the panel's A fragments of one chunk (NPB * 2 KiB, lane-linear), copied verbatim
-template <int NPB>
+template <int NPB, int NT = 256>
 struct SpxAStager {
     static constexpr int ABYTES = NPB * (SPX_KC / 16) * 1024;
-    static constexpr int APASS = ABYTES / 4096;
+    static constexpr int PASS_BYTES = NT * 16;
+    static constexpr int APASS = (ABYTES + PASS_BYTES - 1) / PASS_BYTES;
     static_assert(ABYTES % 4096 == 0, "panel height must be even");
     u32x4 ar[APASS];
+
+    // the last pass may cover only part of the workgroup (12 KiB over 512 threads): per-thread predicate
+    __device__ __forceinline__ static bool in_range(int i, int tid) { return (i + 1) * PASS_BYTES <= ABYTES || i * PASS_BYTES + tid * 16 < ABYTES; }
 
     __device__ __forceinline__ void load(const char* bank_chunk, bool real, int tid) {
         const spx_rsrc br_ = make_rsrc_pred(bank_chunk);
@@ -152,11 +157,12 @@ struct SpxAStager {
         const uint32_t bvo = real ? (uint32_t)(tid * 16) : SPX_OOB;
 #endif
 #pragma unroll
-        for (int i = 0; i < APASS; ++i) ar[i] = buf_load_b128(br_, bvo, (uint32_t)(i * 4096));
+        for (int i = 0; i < APASS; ++i) ar[i] = buf_load_b128(br_, in_range(i, tid) ? bvo : SPX_OOB, (uint32_t)(i * PASS_BYTES));
     }
     __device__ __forceinline__ void write(char* as, int tid) {
 #pragma unroll
-        for (int i = 0; i < APASS; ++i) *(u32x4*)(as + i * 4096 + tid * 16) = ar[i];
+        for (int i = 0; i < APASS; ++i)
+            if (in_range(i, tid)) *(u32x4*)(as + i * PASS_BYTES + tid * 16) = ar[i];
     }
 };
 
@@ -165,15 +171,17 @@ struct SpxAStager {
 // Chunk c computes from LDS[c & 1]; at its end chunk c+1 is written to LDS[(c+1) & 1]; one barrier per chunk.
 // The body is branch-free and unrolled by XR with static ring indices, so hipcc counts vmcnt exactly; chunk
 // indices past the panel's last real chunk load and stage zeros.
-template <int NPB, bool XF32, bool VEC, int XR>
+// NT threads per workgroup; each wave accumulates NH of the panel's NPB blocks (NT = 256: NH = NPB, one wave per
+// 32-pixel group; NT = 512: NH = NPB / 2, two waves per pixel group, each with half of the prototype blocks).
+template <int NPB, bool XF32, bool VEC, int XR, int NT = 256, int NH = NPB>
 struct SpxPipeline {
-    SpxXStager<XF32, VEC> xs[XR];
-    SpxAStager<NPB> as_[2];
+    SpxXStager<XF32, VEC, NT> xs[XR];
+    SpxAStager<NPB, NT> as_[2];
     static constexpr int CHUNK_BYTES = NPB * 2 * 1024;
     static constexpr int STAGE = SPX_STAGE_X_BYTES + CHUNK_BYTES;
 
     template <int I>
-    __device__ __forceinline__ void step(f32x16 (&acc)[NPB], float& x2part, const SpxTileCtx& tc, char* smem,
+    __device__ __forceinline__ void step(f32x16 (&acc)[NH], float& x2part, const SpxTileCtx& tc, char* smem,
                                          const char* bank0, int ch0, int Cs, int c, int lane, int wave, int tid) {
         // c = chunk index, I = c mod XR (static)
 #ifdef SPX_DIAG_STAMPS
@@ -182,8 +190,13 @@ struct SpxPipeline {
         xs[I % XR].load(tc, ch0 + (c + XR) * SPX_KC, Cs - (c + XR) * SPX_KC);
         as_[I % 2].load(bank0 + (size_t)(c + 2) * CHUNK_BYTES, Cs - (c + 2) * SPX_KC > 0, tid);
         __builtin_amdgcn_sched_barrier(0);   // the loads issue HERE, not below the MFMAs
+#ifdef SPX_DIAG_STAMPS
+        const unsigned long long s0b = __builtin_amdgcn_s_memtime();
+        __builtin_amdgcn_sched_barrier(0);
+        dg_issue += s0b - s0;
+#endif
         char* cur = smem + (I % 2) * STAGE;
-        spx_compute_chunk<NPB>(acc, x2part, cur, cur + SPX_STAGE_X_BYTES, lane, wave);
+        spx_compute_chunk<NPB, NH>(acc, x2part, cur, cur + SPX_STAGE_X_BYTES, lane, wave & 3, (wave >> 2) * NH);
 #ifdef SPX_DIAG_STAMPS
         __builtin_amdgcn_sched_barrier(0);
         const unsigned long long s1 = __builtin_amdgcn_s_memtime();
@@ -204,14 +217,14 @@ struct SpxPipeline {
 #endif
     }
 #ifdef SPX_DIAG_STAMPS
-    unsigned long long dg_compute = 0, dg_write = 0, dg_barrier = 0;
+    unsigned long long dg_compute = 0, dg_write = 0, dg_barrier = 0, dg_issue = 0;
 #endif
 
     // consts_issue / consts_commit stage the panel's epilogue constants (head fragments, |p|^2) into LDS: the
     // loads are issued behind the pipeline's prologue loads and committed after the first barrier, so they share
     // the fill latency instead of adding a serial round trip in front of it.
     template <typename F, typename G>
-    __device__ __forceinline__ void run_panel(f32x16 (&acc)[NPB], float& x2part, const SpxTileCtx& tc, char* smem,
+    __device__ __forceinline__ void run_panel(f32x16 (&acc)[NH], float& x2part, const SpxTileCtx& tc, char* smem,
                                               const char* bank0, int ch0, int Cs, int lane, int wave, int tid,
                                               F consts_issue, G consts_commit) {
         const int nchunks = (Cs + SPX_KC - 1) / SPX_KC;

@@ -1,0 +1,13 @@
+#!/bin/bash
+# scratch: A/B several prebuilt libspx_hip.so variants with the default bench (run on the GPU box)
+for v in "$@"; do
+  cp tools/scratch/libs/libspx_$v.so scaleprotoseg_amd/libspx_hip.so
+  echo "== $v"
+  timeout -k 10 200 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "
+import sys, json
+for l in sys.stdin:
+    if l.startswith('{'):
+        j = json.loads(l); k = j['kernels']
+        print('step %.3f ms | fwd %.3f  K1 %.3f  K2 %.3f' % (j['ms_per_step'], k['spx_dist_fwd']['ms'], k['spx_dist_bwd']['ms'], k['spx_bank_bwd']['ms']))
+"
+done
