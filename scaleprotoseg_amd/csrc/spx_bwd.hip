@@ -22,6 +22,7 @@
 // Per-workgroup fp32 partial slabs, summed in a fixed order by kernel 3 (no float atomics).
 #include "spx_args.h"
 #include "spx_mainloop.h"
+#include <type_traits>
 
 #ifndef SPX_BWD_WAVES
 #define SPX_BWD_WAVES 2
@@ -117,6 +118,8 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
     const spx_rsrc htp = make_rsrc_pred(a.packed_headT);
     const spx_rsrc p2p = make_rsrc_pred(a.p2);
 
+    const bool act_is_log = a.act_fn == 0;
+    const float act_c1 = act_is_log ? -(1.0f - a.eps) : -1.0f;
     // dLogits of this lane's pixel as split-bf16 B fragments: element j of k-step c <-> class 16c + 8h + j
     bf16x8 dlhi[NCB * 2], dllo[NCB * 2];
     {
@@ -127,7 +130,9 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int cls = c * 16 + 8 * h + j;
-                const float v = buf_load_f32(lr, cls < K ? voff_l : SPX_OOB, (uint32_t)((c * 16 + j) * 4));
+                // pre-scaled by the constant factor of act'(d) (log: -(1-eps) / ((d+1)(d+eps)); linear: -1), so the
+                // element loop multiplies by 1/((d+1)(d+eps)) only
+                const float v = act_c1 * buf_load_f32(lr, cls < K ? voff_l : SPX_OOB, (uint32_t)((c * 16 + j) * 4));
                 __bf16 hi, lo;
                 split_bf16(v, hi, lo);
                 dlhi[c][j] = hi;
@@ -159,7 +164,6 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
         if (tid < NPB * 32) p2s[tid] = p2reg;
     };
 
-    const bool act_is_log = a.act_fn == 0;
 #ifdef SPX_DIAG_STAMPS
     unsigned long long dg_t2 = 0;
 #endif
@@ -205,20 +209,22 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
         if (a.d_dist) load_ddist(0, ddA);
         const bool tile_full = px0 + SPX_TILE_PX <= a.HW;      // wave-uniform: every pixel of the tile is real
 
-        // one prototype block: always acc[0] (the array is rotated afterwards); ddc = its dDist, ddnext = prefetch target
-        auto block = [&](int pb, float (&ddc)[16], float (&ddnext)[16]) {
-            bf16x8 gnew[2], anew[2];
+        // one prototype block, read from accumulator slot SLOT (static); ddc = its dDist, ddnext = prefetch target;
+        // gout = its packed G fragments (k-steps 0 / 1)
+        auto block = [&](int pb, auto slot_c, float (&ddc)[16], float (&ddnext)[16], bf16x8 (&gout)[2]) {
+            constexpr int SLOT = decltype(slot_c)::value;
+            bf16x8 anew[2];
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    gnew[s2][j] = (__bf16)0.0f;
+                    gout[s2][j] = (__bf16)0.0f;
                     anew[s2][j] = (__bf16)0.0f;
                 }
             if (pb < nv) {
                 if (a.d_dist && pb + 1 < nv) load_ddist(pb + 1, ddnext);
                 const bool full = pb * 32 + 32 <= np;
-                f32x16 ga;
+                f32x16 ga;        // (dAct + dLogits.W) * c1, c1 = the constant factor of act'(d)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) ga[i] = 0.0f;
                 if (a.d_logits) {
@@ -244,43 +250,42 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
 #pragma unroll
                     for (int reg = 0; reg < 16; ++reg) {
                         const int rb = (reg & 3) + 8 * (reg >> 2);
-                        ga[reg] += buf_load_f32(dar, (full || (pb * 32 + rb + 4 * h < np)) ? voff_a : SPX_OOB, (uint32_t)(rb * 4));
+                        ga[reg] = __builtin_fmaf(act_c1, buf_load_f32(dar, (full || (pb * 32 + rb + 4 * h < np)) ? voff_a : SPX_OOB, (uint32_t)(rb * 4)), ga[reg]);
                     }
                 }
-                // straight-line element math, no per-element control flow: d, act'(d) [and a], then G
-                float dr[16], dact[16], av[16];
+                // straight-line element math, no per-element control flow: d, 1/((d+1)(d+eps)), a / ln 2, then G
+                float dr[16], rpv[16], av[16];
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
                     const f32x4 p2v = *(const f32x4*)(p2s + pb * 32 + 8 * g4 + 4 * h);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) dr[4 * g4 + e] = __builtin_fmaf(-2.0f, acc[0][4 * g4 + e], p2v[e]) + x2;
+                    for (int e = 0; e < 4; ++e) dr[4 * g4 + e] = __builtin_fmaf(-2.0f, acc[SLOT][4 * g4 + e], p2v[e]) + x2;
                 }
                 if (act_is_log) {
-                    const float c1 = -(1.0f - a.eps);
 #pragma unroll
                     for (int reg = 0; reg < 16; ++reg) {
                         const float d = fmaxf(dr[reg], 0.0f);
                         const float t1 = d + 1.0f, t2 = d + a.eps;
                         const float rp = __builtin_amdgcn_rcpf(t1 * t2);          // 1 / ((d+1)(d+eps))
-                        dact[reg] = c1 * rp;                                       // act'(d)
-                        av[reg] = __builtin_amdgcn_logf(t1 * t1 * rp) * 0.69314718056f;   // log((d+1)/(d+eps))
+                        rpv[reg] = rp;
+                        av[reg] = __builtin_amdgcn_logf(t1 * t1 * rp);            // log2((d+1)/(d+eps)): the blob is a / ln 2
                     }
                 } else {
 #pragma unroll
                     for (int reg = 0; reg < 16; ++reg) {
-                        dact[reg] = -1.0f;
-                        av[reg] = -fmaxf(dr[reg], 0.0f);
+                        rpv[reg] = 1.0f;
+                        av[reg] = -1.44269504089f * fmaxf(dr[reg], 0.0f);
                     }
                 }
                 float gv[16];
                 if (full && tile_full) {
 #pragma unroll
-                    for (int reg = 0; reg < 16; ++reg) gv[reg] = dr[reg] > 0.0f ? __builtin_fmaf(ga[reg], dact[reg], ddc[reg]) : 0.0f;
+                    for (int reg = 0; reg < 16; ++reg) gv[reg] = dr[reg] > 0.0f ? __builtin_fmaf(ga[reg], rpv[reg], ddc[reg]) : 0.0f;
                 } else {
 #pragma unroll
                     for (int reg = 0; reg < 16; ++reg) {
                         const bool valid = px_ok && (pb * 32 + acc_row(reg, h) < np);
-                        gv[reg] = (valid && dr[reg] > 0.0f) ? __builtin_fmaf(ga[reg], dact[reg], ddc[reg]) : 0.0f;
+                        gv[reg] = (valid && dr[reg] > 0.0f) ? __builtin_fmaf(ga[reg], rpv[reg], ddc[reg]) : 0.0f;
                         av[reg] = valid ? av[reg] : 0.0f;
                     }
                 }
@@ -288,40 +293,41 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
                 for (int reg = 0; reg < 16; ++reg) {
                     rs += gv[reg];
                     // register reg = 8 s2 + j of the tile -> element j of k-step s2 of the B fragment
-                    gnew[reg >> 3][reg & 7] = (__bf16)gv[reg];
+                    gout[reg >> 3][reg & 7] = (__bf16)gv[reg];
                     anew[reg >> 3][reg & 7] = (__bf16)av[reg];
                 }
             }
-            {
-                // fragment dump for kernel 2 (wholly padded blocks are written as zeros: kernel 2 reads them)
+            // fragment dump for kernel 2 (wholly padded blocks are written as zeros: kernel 2 reads them)
 #pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
-                    const uint32_t so = (uint32_t)(((wave * NPB + pb) * 2 + s2) * 1024);
-                    const uint32_t vo = spx_blob_slot(r, h, s2) * 16u;
-                    if (a.g_out) buf_store_b128(__builtin_bit_cast(u32x4, gnew[s2]), gr, vo, so);
-                    if (a.a_out) buf_store_b128(__builtin_bit_cast(u32x4, anew[s2]), ar, vo, so);
-                }
-            }
-            // rotate: next block -> acc[0]; this block's G fragments enter the vacated slot
-#pragma unroll
-            for (int i = 0; i + 1 < NPB; ++i) acc[i] = acc[i + 1];
-            {
-                const u32x4 g0 = __builtin_bit_cast(u32x4, gnew[0]), g1 = __builtin_bit_cast(u32x4, gnew[1]);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    acc[NPB - 1][i] = __uint_as_float(g0[i]);
-                    acc[NPB - 1][4 + i] = __uint_as_float(g1[i]);
-                    acc[NPB - 1][8 + i] = 0.0f;
-                    acc[NPB - 1][12 + i] = 0.0f;
-                }
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const uint32_t so = (uint32_t)(((wave * NPB + pb) * 2 + s2) * 1024);
+                const uint32_t vo = spx_blob_slot(r, h, s2) * 16u;
+                if (a.g_out) buf_store_b128(__builtin_bit_cast(u32x4, gout[s2]), gr, vo, so);
+                if (a.a_out) buf_store_b128(__builtin_bit_cast(u32x4, anew[s2]), ar, vo, so);
             }
         };
-        // ROLLED loop, two blocks per iteration (static dDist buffers); exactly NPB block steps, so the rotation
-        // ends aligned: acc[i] = block i's G fragments
+        auto put_g = [&](f32x16& dst, const bf16x8 (&g)[2]) {
+            const u32x4 g0 = __builtin_bit_cast(u32x4, g[0]), g1 = __builtin_bit_cast(u32x4, g[1]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                dst[i] = __uint_as_float(g0[i]);
+                dst[4 + i] = __uint_as_float(g1[i]);
+                dst[8 + i] = 0.0f;
+                dst[12 + i] = 0.0f;
+            }
+        };
+        // ROLLED loop, two blocks per iteration from the static slots 0 and 1 (static dDist buffers too), then one
+        // rotation by two: the next pair moves to the front, the pair's packed G fragments enter the two vacated
+        // slots.  NPB / 2 iterations, so the rotation ends aligned: acc[i] = block i's G fragments.
 #pragma unroll 1
         for (int pb = 0; pb < NPB; pb += 2) {
-            block(pb, ddA, ddB);
-            block(pb + 1, ddB, ddA);
+            bf16x8 gA[2], gB[2];
+            block(pb, std::integral_constant<int, 0>{}, ddA, ddB, gA);
+            block(pb + 1, std::integral_constant<int, 1>{}, ddB, ddA, gB);
+#pragma unroll
+            for (int i = 0; i + 2 < NPB; ++i) acc[i] = acc[i + 2];
+            put_g(acc[NPB - 2], gA);
+            put_g(acc[NPB - 1], gB);
         }
 #ifdef SPX_DIAG_STAMPS
         dg_t2 = __builtin_amdgcn_s_memtime();
@@ -861,7 +867,7 @@ __global__ void spx_bank_reduce_kernel(const SpxBankBwdArgs a) {
         const float ct = (cs[0] + cs[1]) + (cs[2] + cs[3]);
         a.d_bank[(size_t)p * Cs + col] = 2.0f * (a.bank[(size_t)p * Cs + col] * ct - st);
     } else {
-        a.d_W[(size_t)(col - Cs) * P + p] = st;
+        a.d_W[(size_t)(col - Cs) * P + p] = 0.69314718056f * st;     // kernel 1's activation blob holds a / ln 2
     }
 }
 
