@@ -828,7 +828,10 @@ __global__ __launch_bounds__(SPX_BK_THREADS, 2) void spx_bank_bwd_kernel(const S
 // kernel 3: fixed-order sum of the slabs, + the p * colsum(G) term.  Four independent partial sums per output
 // (slab j goes to partial j & 3) keep several loads in flight per thread; the order is fixed, so results are
 // run-to-run identical.
-__global__ void spx_bank_reduce_kernel(const SpxBankBwdArgs a) {
+#define SPX_RED_ELEMS 32     // output elements per workgroup
+#define SPX_RED_PARTS 8      // slab ranges summed in parallel per element (256 threads)
+__global__ __launch_bounds__(SPX_RED_ELEMS * SPX_RED_PARTS) void spx_bank_reduce_kernel(const SpxBankBwdArgs a) {
+    __shared__ float red_s[SPX_RED_PARTS][SPX_RED_ELEMS], red_c[SPX_RED_PARTS][SPX_RED_ELEMS];
     const spx_plan& pl = a.plan;
     const int Cs = pl.channels_per_scale, K = pl.num_classes, P = pl.num_prototypes;
     const int nchb = (Cs + 31) / 32;
@@ -836,35 +839,49 @@ __global__ void spx_bank_reduce_kernel(const SpxBankBwdArgs a) {
     const int ws = spx_bk_wstride(pl);
     const int ncols = Cs + K;
     const long long n = (long long)pl.npanels * rows * ncols;
-    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= n) return;
-    const int col = (int)(gid % ncols);
-    const int row = (int)((gid / ncols) % rows);
-    const int q = (int)(gid / ((long long)ncols * rows));
-    if (row >= pl.panel_np[q]) return;
-    const int p = pl.panel_p0[q] + row;
+    const int el = threadIdx.x % SPX_RED_ELEMS, part = threadIdx.x / SPX_RED_ELEMS;
+    const long long gid = (long long)blockIdx.x * SPX_RED_ELEMS + el;
+    const bool in = gid < n;
+    const int col = in ? (int)(gid % ncols) : 0;
+    const int row = in ? (int)((gid / ncols) % rows) : 0;
+    const int q = in ? (int)(gid / ((long long)ncols * rows)) : 0;
+    const bool is_p = col < Cs;
+    const bool live = in && row < pl.panel_np[q] && (is_p ? a.d_bank != nullptr : a.d_W != nullptr);
     const size_t slab_stride = (size_t)pl.npanels * rows * ws;
     const float* base = a.workspace + ((size_t)q * rows + row) * ws;
-    const bool is_p = col < Cs;
-    if (is_p ? !a.d_bank : !a.d_W) return;
     const int c0 = is_p ? col : nchb * 32 + (col - Cs);
     const int c1 = nchb * 32 + pl.ncb * 32;          // colsum column
+    // this thread's slab range; inside it slab j goes to partial (j - j0) & 3: a fixed order, so results are
+    // run-to-run identical
+    const int per = (a.nsplit + SPX_RED_PARTS - 1) / SPX_RED_PARTS;
+    const int j0 = part * per, j1 = min(a.nsplit, j0 + per);
     float s[4] = {0.f, 0.f, 0.f, 0.f}, cs[4] = {0.f, 0.f, 0.f, 0.f};
-    int j = 0;
-    for (; j + 4 <= a.nsplit; j += 4) {
+    if (live) {
+        int j = j0;
+        for (; j + 4 <= j1; j += 4) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            s[u] += base[(size_t)(j + u) * slab_stride + c0];
-            if (is_p) cs[u] += base[(size_t)(j + u) * slab_stride + c1];
+            for (int u = 0; u < 4; ++u) {
+                s[u] += base[(size_t)(j + u) * slab_stride + c0];
+                if (is_p) cs[u] += base[(size_t)(j + u) * slab_stride + c1];
+            }
+        }
+        for (; j < j1; ++j) {
+            s[(j - j0) & 3] += base[(size_t)j * slab_stride + c0];
+            if (is_p) cs[(j - j0) & 3] += base[(size_t)j * slab_stride + c1];
         }
     }
-    for (; j < a.nsplit; ++j) {
-        s[j & 3] += base[(size_t)j * slab_stride + c0];
-        if (is_p) cs[j & 3] += base[(size_t)j * slab_stride + c1];
+    red_s[part][el] = (s[0] + s[1]) + (s[2] + s[3]);
+    red_c[part][el] = (cs[0] + cs[1]) + (cs[2] + cs[3]);
+    __syncthreads();
+    if (part != 0 || !live) return;
+    float st = 0.0f, ct = 0.0f;
+#pragma unroll
+    for (int i = 0; i < SPX_RED_PARTS; ++i) {
+        st += red_s[i][el];
+        ct += red_c[i][el];
     }
-    const float st = (s[0] + s[1]) + (s[2] + s[3]);
+    const int p = pl.panel_p0[q] + row;
     if (is_p) {
-        const float ct = (cs[0] + cs[1]) + (cs[2] + cs[3]);
         a.d_bank[(size_t)p * Cs + col] = 2.0f * (a.bank[(size_t)p * Cs + col] * ct - st);
     } else {
         a.d_W[(size_t)(col - Cs) * P + p] = 0.69314718056f * st;     // kernel 1's activation blob holds a / ln 2
@@ -895,6 +912,7 @@ hipError_t spx_launch_bank_bwd(const SpxBankBwdArgs& a, int x_dtype, hipStream_t
         e = pl.npb == 2 ? launch_bank_x<2, 5>(a, x_dtype, grid, s) : pl.npb == 4 ? launch_bank_x<4, 5>(a, x_dtype, grid, s) : launch_bank_x<6, 5>(a, x_dtype, grid, s);
     if (e != hipSuccess) return e;
     const long long n = (long long)pl.npanels * rows * (pl.channels_per_scale + pl.num_classes);
-    hipLaunchKernelGGL(spx_bank_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(spx_bank_reduce_kernel, dim3((unsigned)((n + SPX_RED_ELEMS - 1) / SPX_RED_ELEMS)),
+                       dim3(SPX_RED_ELEMS * SPX_RED_PARTS), 0, s, a);
     return hipGetLastError();
 }
