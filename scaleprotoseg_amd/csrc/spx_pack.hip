@@ -53,17 +53,21 @@ __global__ void spx_pack_bank_kernel(const spx_plan pl, const float* __restrict_
         }
         *(bf16x8*)(pbT_out + (size_t)gid * 8) = v;
     }
-    if (gid < n_p2) {
-        const int panel = gid / (pl.npb * 32), row = gid - panel * pl.npb * 32;
+    // |p|^2: one wave per padded prototype row (lane-strided channels, fixed-order butterfly sum)
+    const int wid = gid >> 6, lane = gid & 63;
+    if (wid < n_p2) {
+        const int panel = wid / (pl.npb * 32), row = wid - panel * pl.npb * 32;
         float s = 0.0f;
         if (row < pl.panel_np[panel]) {
             const float* src = bank + (size_t)(pl.panel_p0[panel] + row) * Cs;
-            for (int c = 0; c < Cs; ++c) {
+            for (int c = lane; c < Cs; c += 64) {
                 const float f = (float)(__bf16)src[c];   // |p|^2 of the prototype the MFMA actually sees
                 s = __builtin_fmaf(f, f, s);
             }
         }
-        p2_out[gid] = s;
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
+        if (lane == 0) p2_out[wid] = s;
     }
 }
 
@@ -127,7 +131,7 @@ hipError_t spx_launch_pack_bank(const spx_plan& pl, const float* bank, void* pb,
     int n = pl.npanels * pl.npb * 32 * (((Cs + 31) / 32) * 32) / 8;
     const int nT = pl.npanels * pl.npb * 2 * nchb * 64;
     if (nT > n) n = nT;
-    const int np2 = pl.npanels * pl.npb * 32;
+    const int np2 = pl.npanels * pl.npb * 32 * 64;     // one wave per row
     if (np2 > n) n = np2;
     hipLaunchKernelGGL(spx_pack_bank_kernel, dim3((n + 255) / 256), dim3(256), 0, s, pl, bank, (__bf16*)pb,
                        (__bf16*)pbT, p2);
