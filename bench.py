@@ -84,7 +84,8 @@ def main():
     ap.add_argument("--x-dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--grads", default="logits,dist", help="diagnostic only: which output gradients flow back")
-    ap.add_argument("--outputs", default="logits,dist", help="diagnostic only: 'logits' = logits-only forward (no fp32 distance map)")
+    ap.add_argument("--outputs", default="logits,dist", help="diagnostic only: 'logits' = logits-only forward (no fp32 distance map); "
+                    "'logits,class_dist' = class-gathered distances (SURVEY 8f-1: what the fused KLD consumes) instead of the P-wide map")
     ap.add_argument("--freeze", default="", help="diagnostic only: comma list of x,bank,head to exclude from the backward")
     args = ap.parse_args()
 
@@ -131,16 +132,27 @@ def main():
         {"x": x, "bank": bank, "head": head}[name].requires_grad_(False)
     bucket = FlatGradBucket([p for p in (bank, head) if p.requires_grad] or [bank.requires_grad_(True)])
 
+    gather = None
+    if "class_dist" in args.outputs.split(","):
+        keys, J, table = spx.class_gather_table(layout, ident, dev)
+        # piecewise-constant label map (segmentation masks are): 64x64-px patches of one class each
+        patches = torch.randint(0, K, (1, (H + 63) // 64, (W + 63) // 64), device=dev, generator=g, dtype=torch.int32)
+        labels0 = patches.repeat_interleave(64, 1).repeat_interleave(64, 2)[:, :H, :W].reshape(1, H * W).contiguous()
+        gather = spx.ClassGather(labels=labels0, keys=keys, width=J, table=table)
+        g_cls = torch.randn(1, J, H * W, device=dev, generator=g) * 1e-3
+
     def step():
         x.grad = None
         bank.grad = None
         head.grad = None
-        want_d = "dist" in args.outputs
-        logits, dmap, _ = spx.proto_head_forward(x, bank, head, layout, want_distances=want_d)
+        want_d = "dist" in args.outputs.split(",")
+        logits, dmap, _ = spx.proto_head_forward(x, bank, head, layout, want_distances=want_d, class_gather=gather)
         outs, gouts = [], []
         if "logits" in args.grads:
             outs.append(logits); gouts.append(g_logits)
-        if "dist" in args.grads and want_d:
+        if "dist" in args.grads and gather is not None:
+            outs.append(dmap); gouts.append(g_cls)
+        elif "dist" in args.grads and want_d:
             outs.append(dmap); gouts.append(g_dist)
         torch.autograd.backward(outs, gouts)
         if world > 1:
@@ -175,6 +187,12 @@ def main():
     op_ms = {k: sum(v) / len(v) for k, v in per_op.items()}
     M = H * W
     fwd_b, bwd_b = algorithmic_bytes_per_px(C, P, K)
+    if gather is not None:      # the P-wide fp32 map and its gradient are replaced by J entries per pixel
+        fwd_b += 4 * gather.width + 4 - 4 * P
+        bwd_b += 4 * gather.width + 4 - 4 * P
+    elif "dist" not in args.outputs.split(","):
+        fwd_b -= 4 * P
+        bwd_b -= 4 * P
     nb = P * Cs  # sum_s Cs * Ps
     op_bytes = {"spx_dist_fwd": fwd_b * M, "spx_dist_bwd": bwd_b * M, "spx_bank_bwd": 0}
     op_flops = {"spx_dist_fwd": 2 * nb * M, "spx_dist_bwd": 2 * nb * M, "spx_bank_bwd": 2 * nb * M}
@@ -212,7 +230,8 @@ def main():
                 "scales": S,
                 "classes": K,
                 "features_dtype": args.x_dtype,
-                "outputs": "logits + fp32 distance map (reference forward contract); grads dX, dPrototypes, dLastLayer",
+                "outputs": ("logits + fp32 distance map (reference forward contract); grads dX, dPrototypes, dLastLayer"
+                            if args.outputs == "logits,dist" else f"DIAGNOSTIC outputs={args.outputs} grads={args.grads}"),
                 "parallelism": f"dp{world}" if world > 1 else "single",
             },
             "kernels": kernels,

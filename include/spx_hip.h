@@ -35,7 +35,7 @@ extern "C" {
 #endif
 
 #define SPX_MAX_PANELS 64   /* (scale, <=192-prototype block) work units per pixel tile */
-#define SPX_ABI_VERSION 1
+#define SPX_ABI_VERSION 2
 
 /* How the prototype bank is cut into MFMA panels.  Filled by spx_make_plan(). */
 typedef struct spx_plan {
@@ -100,6 +100,29 @@ int spx_dist_bwd(const spx_plan* plan, const void* x, int32_t x_dtype, int32_t B
                  const float* d_dist, const float* d_act, const float* d_logits,
                  void* dx, void* g_out, void* a_out,
                  float epsilon, int32_t act_fn, void* stream);
+
+/* Class-gathered variants: instead of the P-wide distance map, every pixel keeps only the
+ * distances to the prototypes of ITS OWN class - the only entries KLDLoss reads for that pixel
+ * (segmentation/model/loss.py:89-107; caller segmentation/model/module_multiscale.py:239-242) - so the fp32 map
+ * and its gradient never cross HBM.
+ *   labels     int32 [B, HW]: class 0..K-1 of the pixel; any other value = no class (its row is not written)
+ *   proto_key  uint32 [npanels * 32*npb], in the plan's padded row order: (class << 16) | slot, slot < J =
+ *              rank of the prototype among its class's prototypes (ascending index); 0xFFFFFFFF = none / padding
+ *   class_distances fp32 [B, J, HW] (slot planes): entry (slot, px) = distance of pixel px to prototype `slot` of class
+ *              labels[px]; entries that no prototype maps to are not written (the caller zero-fills).
+ * Everything else as in spx_dist_fwd / spx_dist_bwd. */
+int spx_dist_fwd_cls(const spx_plan* plan, const void* x, int32_t x_dtype, int32_t B, int32_t HW,
+                     const void* packed_bank, const float* packed_p2, const void* packed_head,
+                     const int32_t* labels, const uint32_t* proto_key, int32_t J,
+                     float* class_distances, float* activations, float* logits,
+                     float epsilon, int32_t act_fn, void* stream);
+int spx_dist_bwd_cls(const spx_plan* plan, const void* x, int32_t x_dtype, int32_t B, int32_t HW,
+                     const void* packed_bank, const void* packed_bankT, const float* packed_p2,
+                     const void* packed_headT,
+                     const int32_t* labels, const uint32_t* proto_key, int32_t J,
+                     const float* d_class_distances, const float* d_act, const float* d_logits,
+                     void* dx, void* g_out, void* a_out,
+                     float epsilon, int32_t act_fn, void* stream);
 
 /* Bytes of the g_out (and of the a_out) scratch of spx_dist_bwd. */
 size_t spx_bwd_scratch_bytes(const spx_plan* plan, int32_t B, int32_t HW);

@@ -347,6 +347,41 @@ def case_misc(ms, utils, name):
     )
 
 
+def case_kld(lossmod, ms, name):
+    """KLDLoss of the reference (segmentation/model/loss.py:51-146) on small distance maps: value + gradient."""
+    out = {}
+    cases = {
+        # tag: (B, S, K, P, H, W)
+        "a": (2, 4, 5, 40, 9, 11),      # 2 prototypes per (class, scale): one pair each
+        "b": (1, 1, 4, 16, 8, 9),       # 4 prototypes per class: six pairs
+        "c": (1, 2, 3, 16, 4, 5),       # floor semantics: 2 prototypes per scale without a class
+    }
+    for tag, (B, S, K, P, H, W) in cases.items():
+        torch.manual_seed(SEED + 40 + ord(tag))
+        net = _make_proto_phase(ms, P=P, Cs=16, S=S, K=K)
+        ident = net.prototype_class_identity.clone()
+        ranges = {s: tuple(net.scale_num_prototypes[s]) for s in range(S)}
+        d = (torch.rand(B, P, H, W) * 6.0).requires_grad_(True)
+        target = torch.randint(0, K + 1, (B, H, W))          # 0 = void
+        target[target == K] = 0                              # class K-1 absent
+        target[0, 0, 0] = K                                  # ... except ONE pixel (len < 2: its pairs are skipped)
+        loss = lossmod.KLDLoss(ident, S, ranges)(prototype_distances=d, target_labels=target)
+        loss.backward()
+        out[f"{tag}_dist"] = _np(d)
+        out[f"{tag}_target"] = target.numpy().astype(np.int64)
+        out[f"{tag}_ident"] = _np(ident)
+        out[f"{tag}_ranges"] = np.array([ranges[s] for s in range(S)], dtype=np.int64)
+        out[f"{tag}_S"] = np.int64(S)
+        out[f"{tag}_loss"] = _np(loss)
+        out[f"{tag}_grad"] = _np(d.grad)
+    # no valid term at all -> 0.0 (loss.py:143-144)
+    net = _make_proto_phase(ms, P=8, Cs=16, S=1, K=4)
+    t0 = torch.zeros(1, 3, 3, dtype=torch.long)
+    l0 = lossmod.KLDLoss(net.prototype_class_identity, 1, {0: (0, 8)})(prototype_distances=torch.rand(1, 8, 3, 3), target_labels=t0)
+    out["empty_loss"] = _np(l0)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+
+
 def main():
     _install_stubs()
     sys.path.insert(0, REF)
@@ -357,6 +392,7 @@ def main():
     import segmentation.utils as utils
     import segmentation.data.dataset as dsmod
     import segmentation.push_multiscale_optimization as push
+    import segmentation.model.loss as lossmod
 
     torch.set_num_threads(1)
     case_proto_phase(ms, "proto_ms_small", B=2, S=4, Cs=16, K=5, P=40, H=9, W=11)
@@ -369,6 +405,7 @@ def main():
     case_single_scale(m1, "ppnet_single", B=2, Cs=32, K=5, P=20, H=7, W=9)
     case_push(push, dsmod, ms, "push_argmin")
     case_misc(ms, utils, "misc")
+    case_kld(lossmod, ms, "kld_loss")
     print("golden fixtures written to", os.path.normpath(OUT))
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

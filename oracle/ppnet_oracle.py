@@ -270,6 +270,79 @@ def prune_state(
 
 
 # --------------------------------------------------------------------------- #
+# KLD loss over the distance map and its class-gathered form
+# --------------------------------------------------------------------------- #
+def kld_loss(
+    prototype_distances: torch.Tensor,
+    target_labels: torch.Tensor,
+    class_identity: torch.Tensor,
+    num_scales: int,
+    scale_ranges: Dict[int, Tuple[int, int]],
+) -> torch.Tensor:
+    """segmentation/model/loss.py:57-146 (KLDLoss.forward), loop for loop.
+
+    prototype_distances [B,P,H,W]; target_labels [B,H,W] with 0 = void, 1..K = class (the loss subtracts 1,
+    loss.py:73).  Per (image, class present, scale): log_softmax over the class's pixels of every prototype of
+    that class and scale, symmetric KL between every pair, exp(-kld), mean over all terms (0.0 when none)."""
+    tl = target_labels.reshape(target_labels.shape[0], -1) - 1
+    d = prototype_distances.permute(0, 2, 3, 1)
+    d = d.reshape(d.shape[0], -1, d.shape[-1])
+    terms = []
+    for b in range(tl.shape[0]):
+        for c in torch.unique(tl[b]).tolist():
+            if c < 0 or c >= class_identity.shape[1]:
+                continue
+            protos = torch.nonzero(class_identity[:, c]).flatten().tolist()
+            if len(protos) == 0:
+                continue
+            mask = tl[b] == c
+            for s in range(num_scales):
+                ps = [p for p in protos if scale_ranges[s][0] <= p < scale_ranges[s][1]]
+                logp = [F.log_softmax(torch.masked_select(d[b, :, p], mask), dim=0) for p in ps]
+                if len(ps) < 2:
+                    continue
+                for j in range(len(ps)):
+                    if len(logp[j]) < 2:
+                        continue
+                    for k in range(j + 1, len(ps)):
+                        if len(logp[k]) < 2:
+                            continue
+                        k1 = F.kl_div(logp[j], logp[k], log_target=True, reduction="sum")
+                        k2 = F.kl_div(logp[k], logp[j], log_target=True, reduction="sum")
+                        terms.append((k1 + k2) / 2.0)
+    if not terms:
+        return torch.tensor(0.0)
+    return torch.exp(-torch.stack(terms)).mean()
+
+
+def class_slot_table(class_identity: torch.Tensor) -> torch.Tensor:
+    """table [K, J]: prototype index of (class, slot), slot = rank among the class's prototypes (ascending), -1 = none."""
+    P, K = class_identity.shape
+    per = [torch.nonzero(class_identity[:, c]).flatten().tolist() for c in range(K)]
+    J = max(1, max(len(x) for x in per))
+    table = torch.full((K, J), -1, dtype=torch.long)
+    for c in range(K):
+        for j, p in enumerate(per[c]):
+            table[c, j] = p
+    return table
+
+
+def gather_class_distances(prototype_distances: torch.Tensor, labels0: torch.Tensor, class_identity: torch.Tensor) -> torch.Tensor:
+    """[B, H*W, J]: entry (px, j) = distance of px to prototype j of class labels0[px] (0..K-1; other = no class -> 0).
+    Exactly the entries loss.py:89-107 selects with masked_select for that pixel."""
+    B, P = prototype_distances.shape[:2]
+    table = class_slot_table(class_identity)
+    K, J = table.shape
+    d = prototype_distances.reshape(B, P, -1).permute(0, 2, 1)          # [B, HW, P]
+    lab = labels0.reshape(B, -1)
+    ok = (lab >= 0) & (lab < K)
+    idx = table[lab.clamp(0, K - 1)]                                     # [B, HW, J]
+    valid = ok.unsqueeze(-1) & (idx >= 0)
+    out = torch.gather(d, 2, idx.clamp(min=0))
+    return torch.where(valid, out, torch.zeros_like(out))
+
+
+# --------------------------------------------------------------------------- #
 # helpers used by tests / bench
 # --------------------------------------------------------------------------- #
 def bf16_representable(t: torch.Tensor) -> torch.Tensor:

@@ -7,10 +7,20 @@ Public surface mirrors the reference's module/function names for this path:
     compute_distances, min_across_dataset, global_min, push_prototypes_multiscale
                                                     (segmentation/push_multiscale_optimization.py)
     projection_simplex_sort, resize_label           (segmentation/utils.py, segmentation/data/dataset.py)
+    KLDLoss                                         (segmentation/model/loss.py; also takes the class-gathered
+                                                     ClassDistances of forward_from_conv_features(target_labels=...))
 Arithmetic runs in libspx_hip.so (hand-written gfx950 HIP); there is no CPU fallback.
 """
 from ._lib import SpxError, load as load_library  # noqa: F401
-from .functional import BankLayout, argmin_over_images, proto_head_forward, push_masked_argmin  # noqa: F401
+from .functional import (  # noqa: F401
+    BankLayout,
+    ClassGather,
+    argmin_over_images,
+    class_gather_table,
+    proto_head_forward,
+    push_masked_argmin,
+)
+from .loss import ClassDistances, KLDLoss  # noqa: F401
 from .model import PPNet  # noqa: F401
 from .model_multiscale import PPNetMultiScale, construct_PPNet  # noqa: F401
 from .model_multiscale_group import PPNetMultiScaleGroup, construct_PPNet_Group  # noqa: F401

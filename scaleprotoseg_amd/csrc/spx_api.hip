@@ -110,9 +110,10 @@ int spx_pack_head(const spx_plan* pl, const float* W, void* ph, void* phT, void*
     return hip_status(spx_launch_pack_head(*pl, W, ph, phT, (hipStream_t)stream), "spx_pack_head");
 }
 
-int spx_dist_fwd(const spx_plan* pl, const void* x, int32_t x_dtype, int32_t B, int32_t HW, const void* packed_bank,
-                 const float* packed_p2, const void* packed_head, float* distances, float* activations,
-                 float* logits, float epsilon, int32_t act_fn, void* stream) {
+static int dist_fwd_impl(const spx_plan* pl, const void* x, int32_t x_dtype, int32_t B, int32_t HW,
+                         const void* packed_bank, const float* packed_p2, const void* packed_head, float* distances,
+                         const int32_t* labels, const uint32_t* proto_key, int32_t J, float* cls_dist,
+                         float* activations, float* logits, float epsilon, int32_t act_fn, void* stream) {
     if (check_plan(pl)) return 1;
     if (!x || !packed_bank || !packed_p2) return fail("spx_dist_fwd: NULL operand");
     if (x_dtype != 0 && x_dtype != 1) return fail("spx_dist_fwd: x_dtype %d (0 = bf16, 1 = fp32)", x_dtype);
@@ -135,6 +136,10 @@ int spx_dist_fwd(const spx_plan* pl, const void* x, int32_t x_dtype, int32_t B, 
     a.B = B;
     a.HW = HW;
     a.vec_ok = x_vec_ok(x, x_dtype, HW);
+    a.labels = labels;
+    a.proto_key = proto_key;
+    a.cls_dist = cls_dist;
+    a.J = J;
     a.dist_vec = distances && ((uintptr_t)distances & 15) == 0 && HW % 4 == 0;
     a.eps = epsilon;
     a.act_fn = act_fn;
@@ -142,10 +147,36 @@ int spx_dist_fwd(const spx_plan* pl, const void* x, int32_t x_dtype, int32_t B, 
     return hip_status(spx_launch_fwd(a, x_dtype, (hipStream_t)stream), "spx_dist_fwd");
 }
 
-int spx_dist_bwd(const spx_plan* pl, const void* x, int32_t x_dtype, int32_t B, int32_t HW, const void* packed_bank,
-                 const void* packed_bankT, const float* packed_p2, const void* packed_headT, const float* d_dist,
-                 const float* d_act, const float* d_logits, void* dx, void* g_out, void* a_out, float epsilon,
-                 int32_t act_fn, void* stream) {
+int spx_dist_fwd(const spx_plan* pl, const void* x, int32_t x_dtype, int32_t B, int32_t HW, const void* packed_bank,
+                 const float* packed_p2, const void* packed_head, float* distances, float* activations,
+                 float* logits, float epsilon, int32_t act_fn, void* stream) {
+    return dist_fwd_impl(pl, x, x_dtype, B, HW, packed_bank, packed_p2, packed_head, distances, nullptr, nullptr, 0,
+                         nullptr, activations, logits, epsilon, act_fn, stream);
+}
+
+static int check_cls(const char* who, const int32_t* labels, const uint32_t* proto_key, int32_t J, int32_t HW) {
+    if (!labels || !proto_key) return fail("%s: NULL labels / proto_key", who);
+    if (J < 1 || J > 0xFFFF) return fail("%s: J %d out of range", who, J);
+    if ((long long)HW * J >= (1LL << 29)) return fail("%s: HW*J too large for 32-bit offsets", who);
+    return 0;
+}
+
+int spx_dist_fwd_cls(const spx_plan* pl, const void* x, int32_t x_dtype, int32_t B, int32_t HW,
+                     const void* packed_bank, const float* packed_p2, const void* packed_head,
+                     const int32_t* labels, const uint32_t* proto_key, int32_t J, float* class_distances,
+                     float* activations, float* logits, float epsilon, int32_t act_fn, void* stream) {
+    if (check_cls("spx_dist_fwd_cls", labels, proto_key, J, HW)) return 1;
+    if (!class_distances) return fail("spx_dist_fwd_cls: NULL class_distances");
+    return dist_fwd_impl(pl, x, x_dtype, B, HW, packed_bank, packed_p2, packed_head, nullptr, labels, proto_key, J,
+                         class_distances, activations, logits, epsilon, act_fn, stream);
+}
+
+static int dist_bwd_impl(const spx_plan* pl, const void* x, int32_t x_dtype, int32_t B, int32_t HW,
+                         const void* packed_bank, const void* packed_bankT, const float* packed_p2,
+                         const void* packed_headT, const float* d_dist, const int32_t* labels,
+                         const uint32_t* proto_key, int32_t J, const float* d_cls_dist, const float* d_act,
+                         const float* d_logits, void* dx, void* g_out, void* a_out, float epsilon, int32_t act_fn,
+                         void* stream) {
     if (check_plan(pl)) return 1;
     if (!x || !packed_bank || !packed_p2) return fail("spx_dist_bwd: NULL operand");
     if (x_dtype != 0 && x_dtype != 1) return fail("spx_dist_bwd: x_dtype %d", x_dtype);
@@ -163,6 +194,10 @@ int spx_dist_bwd(const spx_plan* pl, const void* x, int32_t x_dtype, int32_t B, 
     a.d_dist = d_dist;
     a.d_act = d_act;
     a.d_logits = d_logits;
+    a.labels = labels;
+    a.proto_key = proto_key;
+    a.d_cls_dist = d_cls_dist;
+    a.J = J;
     a.dx = dx;
     a.g_out = (uint16_t*)g_out;
     a.a_out = (uint16_t*)a_out;
@@ -173,6 +208,26 @@ int spx_dist_bwd(const spx_plan* pl, const void* x, int32_t x_dtype, int32_t B, 
     a.act_fn = act_fn;
     a.dbg = g_dbg;
     return hip_status(spx_launch_bwd(a, x_dtype, (hipStream_t)stream), "spx_dist_bwd");
+}
+
+int spx_dist_bwd(const spx_plan* pl, const void* x, int32_t x_dtype, int32_t B, int32_t HW, const void* packed_bank,
+                 const void* packed_bankT, const float* packed_p2, const void* packed_headT, const float* d_dist,
+                 const float* d_act, const float* d_logits, void* dx, void* g_out, void* a_out, float epsilon,
+                 int32_t act_fn, void* stream) {
+    return dist_bwd_impl(pl, x, x_dtype, B, HW, packed_bank, packed_bankT, packed_p2, packed_headT, d_dist, nullptr,
+                         nullptr, 0, nullptr, d_act, d_logits, dx, g_out, a_out, epsilon, act_fn, stream);
+}
+
+int spx_dist_bwd_cls(const spx_plan* pl, const void* x, int32_t x_dtype, int32_t B, int32_t HW,
+                     const void* packed_bank, const void* packed_bankT, const float* packed_p2,
+                     const void* packed_headT, const int32_t* labels, const uint32_t* proto_key, int32_t J,
+                     const float* d_class_distances, const float* d_act, const float* d_logits, void* dx,
+                     void* g_out, void* a_out, float epsilon, int32_t act_fn, void* stream) {
+    if (check_cls("spx_dist_bwd_cls", labels, proto_key, J, HW)) return 1;
+    // d_class_distances may be NULL (no gradient reaches the gathered distances)
+    return dist_bwd_impl(pl, x, x_dtype, B, HW, packed_bank, packed_bankT, packed_p2, packed_headT, nullptr,
+                         d_class_distances ? labels : nullptr, proto_key, J, d_class_distances, d_act, d_logits, dx,
+                         g_out, a_out, epsilon, act_fn, stream);
 }
 
 size_t spx_bank_bwd_workspace_bytes(const spx_plan* pl, int32_t B, int32_t HW) {

@@ -13,6 +13,11 @@ struct SpxFwdArgs {
     float* logits;
     int B, HW, vec_ok;
     int dist_vec;              // distances 16-B aligned and HW % 4 == 0: 16-B stores of 4 pixels of a row
+    // class-gathered distances (spx_dist_fwd_cls): every pixel keeps only the distances to its own class's prototypes
+    const int32_t* labels;     // [B, HW] class per pixel (anything outside 0..0xFFFD = none)
+    const uint32_t* proto_key; // [npanels][32 npb] (class << 16) | slot per padded prototype row, 0xFFFFFFFF = none
+    float* cls_dist;           // [B, J, HW] slot planes
+    int J;
     float eps;
     int act_fn;
     unsigned long long* dbg;   // diagnostic builds only (SPX_DIAG_STAMPS): per-workgroup phase clocks
@@ -27,6 +32,10 @@ struct SpxBwdArgs {
     const float* d_dist;
     const float* d_act;
     const float* d_logits;
+    const int32_t* labels;      // class-gathered mode (spx_dist_bwd_cls): see SpxFwdArgs
+    const uint32_t* proto_key;
+    const float* d_cls_dist;    // [B, J, HW]
+    int J;
     void* dx;
     uint16_t* g_out;
     uint16_t* a_out;
@@ -47,7 +56,7 @@ struct SpxBankBwdArgs {
     float* workspace;
     int B, HW, vec_ok, nsplit;
 };
-hipError_t spx_launch_fwd(const SpxFwdArgs& a, int x_dtype, hipStream_t s);
+hipError_t spx_launch_fwd(const SpxFwdArgs& a, int x_dtype, hipStream_t s);        // a.labels != NULL: class-gathered variant
 hipError_t spx_launch_bwd(const SpxBwdArgs& a, int x_dtype, hipStream_t s);
 hipError_t spx_launch_bank_bwd(const SpxBankBwdArgs& a, int x_dtype, hipStream_t s);
 int spx_bank_bwd_nsplit(const spx_plan& pl, int B, int HW);

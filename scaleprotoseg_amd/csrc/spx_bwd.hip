@@ -55,7 +55,7 @@ __host__ __device__ constexpr int spx_bwd_region1_bytes() {
 }
 template <int NPB, int NCB>
 __host__ __device__ constexpr int spx_bwd_lds_bytes() {
-    return spx_bwd_region0_bytes<NPB>() + spx_bwd_region1_bytes<NPB, NCB>() + NPB * 32 * 4 + SPX_TILE_PX * 4;
+    return spx_bwd_region0_bytes<NPB>() + spx_bwd_region1_bytes<NPB, NCB>() + 3 * NPB * 32 * 4 + SPX_TILE_PX * 4;   // + |p|^2, class keys, slot plane offsets, rowsum(G)
 }
 static_assert(spx_bwd_lds_bytes<6, 1>() <= 80 * 1024, "pixel kernel must fit two workgroups per CU");
 // bf16 elements of one G (or a) scratch: [panel][tile][wave][pb][s2] fragments of 512 elements
@@ -75,7 +75,8 @@ __host__ __device__ inline uint32_t spx_blob_slot(int r, int h, int s2) {
 // ------------------------------------------------------------------------------------------------
 // kernel 1: pixel side
 // ------------------------------------------------------------------------------------------------
-template <int NPB, int NCB, bool XF32, bool VEC>
+// GATHER: the distance gradient arrives class-gathered ([B, HW, J], spx_dist_bwd_cls) instead of P-wide.
+template <int NPB, int NCB, bool XF32, bool VEC, bool GATHER>
 __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const spx_plan& pl = a.plan;
@@ -106,7 +107,9 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
     const int nchunks = (Cs + SPX_KC - 1) / SPX_KC;
     char* const hlds = smem + spx_bwd_region0_bytes<NPB>();
     float* const p2s = (float*)(hlds + spx_bwd_region1_bytes<NPB, NCB>());
-    float* const rss = p2s + NPB * 32;
+    uint32_t* const keys = (uint32_t*)(p2s + NPB * 32);    // GATHER: (class << 16) | slot per padded prototype row
+    uint32_t* const koff = keys + NPB * 32;                // GATHER: byte offset of the row's slot plane (slot * HW * 4)
+    float* const rss = p2s + 3 * NPB * 32;
 
     const int px = px0 + 32 * wave + r;
     const bool px_ok = px < a.HW;
@@ -117,6 +120,17 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
     const spx_rsrc p2r = make_rsrc(a.p2);
     const spx_rsrc htp = make_rsrc_pred(a.packed_headT);
     const spx_rsrc p2p = make_rsrc_pred(a.p2);
+    // GATHER: this pixel's class (0xFFFE = none; padding rows carry class 0xFFFF) and its [px][slot] row offset
+    uint32_t lab16 = 0xFFFEu, voff_c = SPX_OOB;
+    const spx_rsrc keyr = make_rsrc_pred(GATHER ? a.proto_key : nullptr);
+    const spx_rsrc cdr = make_rsrc_pred((GATHER && a.d_cls_dist) ? a.d_cls_dist + (size_t)b * a.J * a.HW : nullptr);
+    if (GATHER && a.d_cls_dist) {
+        const spx_rsrc labr = make_rsrc_pred(a.labels + (size_t)b * a.HW);
+        const uint32_t l = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(labr, px_ok ? (uint32_t)px * 4u : SPX_OOB, 0, 0);
+        lab16 = (px_ok && l < 0xFFFEu) ? l : 0xFFFEu;
+        voff_c = px_ok ? (uint32_t)px * 4u : SPX_OOB;          // [slot][px] planes
+    }
+    const bool have_dd = GATHER ? a.d_cls_dist != nullptr : a.d_dist != nullptr;
 
     const bool act_is_log = a.act_fn == 0;
     const float act_c1 = act_is_log ? -(1.0f - a.eps) : -1.0f;
@@ -152,16 +166,22 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
     constexpr int HPASS = head_lds / 4096;
     u32x4 hreg[HPASS > 0 ? HPASS : 1];
     float p2reg = 0.0f;
+    uint32_t keyreg = 0xFFFFFFFFu;
     auto consts_issue = [&](int panel) {
 #pragma unroll
         for (int i = 0; i < HPASS; ++i)
             hreg[i] = buf_load_b128(htp, a.d_logits ? (uint32_t)(i * 4096 + tid * 16) : SPX_OOB, (uint32_t)(panel * head_lds));
         p2reg = buf_load_f32(p2p, tid < NPB * 32 ? (uint32_t)tid * 4u : SPX_OOB, (uint32_t)(panel * NPB * 32 * 4));
+        if (GATHER) keyreg = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(keyr, tid < NPB * 32 ? (uint32_t)tid * 4u : SPX_OOB, (uint32_t)(panel * NPB * 32 * 4), 0);
     };
     auto consts_commit = [&]() {
 #pragma unroll
         for (int i = 0; i < HPASS; ++i) *(u32x4*)(hlds + i * 4096 + tid * 16) = hreg[i];
         if (tid < NPB * 32) p2s[tid] = p2reg;
+        if (GATHER && tid < NPB * 32) {
+            keys[tid] = keyreg;
+            koff[tid] = (keyreg & 0xFFFFu) * HW * 4u;
+        }
     };
 
 #ifdef SPX_DIAG_STAMPS
@@ -189,6 +209,31 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
         float rs = 0.0f;
         float ddA[16], ddB[16];     // dDist of the current / next block (double-buffered: the loop is unrolled by 2)
         auto load_ddist = [&](int pb, float (&dst)[16]) {
+            if (GATHER) {
+                // gathered gradient: a lane reads [px][slot] for the rows of its pixel's class, 0 elsewhere; one
+                // ballot skips the 16 load instructions of a block no lane of the wave has a class in
+                uint32_t vo[16];
+                bool any = false;
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const u32x4 kv = *(const u32x4*)(keys + pb * 32 + 8 * g4 + 4 * h);
+                    const u32x4 ko = *(const u32x4*)(koff + pb * 32 + 8 * g4 + 4 * h);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const bool m = (kv[e] >> 16) == lab16;
+                        any |= m;
+                        vo[4 * g4 + e] = m ? voff_c + ko[e] : SPX_OOB;
+                    }
+                }
+                if (__builtin_amdgcn_ballot_w64(any) != 0) {
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) dst[reg] = buf_load_f32(cdr, vo[reg], 0);
+                } else {
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) dst[reg] = 0.0f;
+                }
+                return;
+            }
             const spx_rsrc ddr = make_rsrc_pred(a.d_dist + ((size_t)b * P + p0 + pb * 32) * a.HW);
             if (pb * 32 + 32 <= np) {     // wave-uniform: whole block real, no row predication
 #pragma unroll
@@ -206,7 +251,7 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
         };
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) ddA[reg] = ddB[reg] = 0.0f;
-        if (a.d_dist) load_ddist(0, ddA);
+        if (have_dd) load_ddist(0, ddA);
         const bool tile_full = px0 + SPX_TILE_PX <= a.HW;      // wave-uniform: every pixel of the tile is real
 
         // one prototype block, read from accumulator slot SLOT (static); ddc = its dDist, ddnext = prefetch target;
@@ -222,7 +267,7 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
                     anew[s2][j] = (__bf16)0.0f;
                 }
             if (pb < nv) {
-                if (a.d_dist && pb + 1 < nv) load_ddist(pb + 1, ddnext);
+                if (have_dd && pb + 1 < nv) load_ddist(pb + 1, ddnext);
                 const bool full = pb * 32 + 32 <= np;
                 f32x16 ga;        // (dAct + dLogits.W) * c1, c1 = the constant factor of act'(d)
 #pragma unroll
@@ -528,17 +573,22 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
 #endif
 }
 
-template <int NPB, int NCB>
-static hipError_t launch_bwd_x(const SpxBwdArgs& a, int x_dtype, dim3 grid, hipStream_t s) {
+template <int NPB, int NCB, bool GATHER>
+static hipError_t launch_bwd_g(const SpxBwdArgs& a, int x_dtype, dim3 grid, hipStream_t s) {
     constexpr size_t lds = (size_t)spx_bwd_lds_bytes<NPB, NCB>();
     if (x_dtype == 1) {
-        if (a.vec_ok) hipLaunchKernelGGL((spx_bwd_kernel<NPB, NCB, true, true>), grid, dim3(256), lds, s, a);
-        else hipLaunchKernelGGL((spx_bwd_kernel<NPB, NCB, true, false>), grid, dim3(256), lds, s, a);
+        if (a.vec_ok) hipLaunchKernelGGL((spx_bwd_kernel<NPB, NCB, true, true, GATHER>), grid, dim3(256), lds, s, a);
+        else hipLaunchKernelGGL((spx_bwd_kernel<NPB, NCB, true, false, GATHER>), grid, dim3(256), lds, s, a);
     } else {
-        if (a.vec_ok) hipLaunchKernelGGL((spx_bwd_kernel<NPB, NCB, false, true>), grid, dim3(256), lds, s, a);
-        else hipLaunchKernelGGL((spx_bwd_kernel<NPB, NCB, false, false>), grid, dim3(256), lds, s, a);
+        if (a.vec_ok) hipLaunchKernelGGL((spx_bwd_kernel<NPB, NCB, false, true, GATHER>), grid, dim3(256), lds, s, a);
+        else hipLaunchKernelGGL((spx_bwd_kernel<NPB, NCB, false, false, GATHER>), grid, dim3(256), lds, s, a);
     }
     return hipGetLastError();
+}
+template <int NPB, int NCB>
+static hipError_t launch_bwd_x(const SpxBwdArgs& a, int x_dtype, dim3 grid, hipStream_t s) {
+    if (a.labels) return launch_bwd_g<NPB, NCB, true>(a, x_dtype, grid, s);
+    return launch_bwd_g<NPB, NCB, false>(a, x_dtype, grid, s);
 }
 
 hipError_t spx_launch_bwd(const SpxBwdArgs& a, int x_dtype, hipStream_t s) {

@@ -37,7 +37,7 @@ __host__ __device__ constexpr int spx_fwd_region0_bytes() {
 }
 template <int NPB, int NCB, int SPLIT>
 __host__ __device__ constexpr int spx_fwd_lds_bytes() {
-    return spx_fwd_region0_bytes<NPB, SPLIT>() + spx_fwd_head_lds_bytes<NPB, NCB>() + NPB * 32 * 4;
+    return spx_fwd_region0_bytes<NPB, SPLIT>() + spx_fwd_head_lds_bytes<NPB, NCB>() + 3 * NPB * 32 * 4;   // + |p|^2, class keys, slot plane offsets
 }
 
 // SPLIT = waves per 32-pixel group.  SPLIT 1: 4 waves, each with all NPB blocks of its pixels (<= 256 VGPRs, two
@@ -45,7 +45,8 @@ __host__ __device__ constexpr int spx_fwd_lds_bytes() {
 // pixel group pg in <= 128 VGPRs: four waves per SIMD instead of two hide the LDS / HBM / transcendental latencies
 // that a two-wave SIMD leaves exposed (the kernel was issue-stalled, not bandwidth-bound: MFMA 17 % + VALU ~42 %
 // busy); the two halves' logits partials meet in LDS at the end.
-template <int NPB, int NCB, bool XF32, bool VEC, int SPLIT>
+// GATHER: class-gathered distances (spx_dist_fwd_cls) instead of the P-wide map.
+template <int NPB, int NCB, bool XF32, bool VEC, int SPLIT, bool GATHER>
 __global__ __launch_bounds__(256 * SPLIT, SPX_FWD_WAVES * SPLIT) void spx_fwd_kernel(const SpxFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NT = 256 * SPLIT, NH = NPB / SPLIT;
@@ -78,6 +79,8 @@ __global__ __launch_bounds__(256 * SPLIT, SPX_FWD_WAVES * SPLIT) void spx_fwd_ke
     const int nchunks = (Cs + SPX_KC - 1) / SPX_KC;
     char* const wlds = smem + region0;
     float* const p2s = (float*)(wlds + head_lds);
+    uint32_t* const keys = (uint32_t*)(p2s + NPB * 32);     // GATHER: (class << 16) | slot per padded prototype row
+    uint32_t* const koff = keys + NPB * 32;                 // GATHER: byte offset of the row's slot plane (slot * HW * 4)
 
     Pipe pipe;
     f32x16 acc[NH];
@@ -104,6 +107,16 @@ __global__ __launch_bounds__(256 * SPLIT, SPX_FWD_WAVES * SPLIT) void spx_fwd_ke
     const uint32_t voff_a = px_ok ? ((uint32_t)px * (uint32_t)P + (uint32_t)(4 * h)) * 4u : SPX_OOB;        // [px][row]
     const spx_rsrc hr = make_rsrc_pred(a.packed_head);
     const spx_rsrc p2r = make_rsrc_pred(a.p2);
+    // GATHER: this pixel's class (0xFFFE = none; padding rows carry class 0xFFFF) and its [px][slot] row offset
+    uint32_t lab16 = 0xFFFEu, voff_c = SPX_OOB;
+    const spx_rsrc keyr = make_rsrc_pred(GATHER ? a.proto_key : nullptr);
+    const spx_rsrc cdr = make_rsrc_pred(GATHER ? a.cls_dist + (size_t)b * a.J * a.HW : nullptr);
+    if (GATHER) {
+        const spx_rsrc labr = make_rsrc_pred(a.labels + (size_t)b * a.HW);
+        const uint32_t l = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(labr, px_ok ? (uint32_t)px * 4u : SPX_OOB, 0, 0);
+        lab16 = (px_ok && l < 0xFFFEu) ? l : 0xFFFEu;
+        voff_c = px_ok ? (uint32_t)px * 4u : SPX_OOB;          // [slot][px] planes: a wave's 32 pixels are one 128-B run
+    }
 
     // panel prologue: head fragments + |p|^2 of the panel -> LDS (read in the epilogue, after >= 1 barrier)
     constexpr int HPB = NT * 16;                        // bytes per pass of the whole workgroup
@@ -112,17 +125,23 @@ __global__ __launch_bounds__(256 * SPLIT, SPX_FWD_WAVES * SPLIT) void spx_fwd_ke
     const bool h_in = head_lds >= HPB || tid * 16 < head_lds;
     u32x4 hreg[HPASS > 0 ? HPASS : 1];
     float p2reg = 0.0f;
+    uint32_t keyreg = 0xFFFFFFFFu;
     auto consts_issue = [&](int panel) {
 #pragma unroll
         for (int i = 0; i < HPASS; ++i)
             hreg[i] = buf_load_b128(hr, (want_head && h_in) ? (uint32_t)(i * HPB + tid * 16) : SPX_OOB, (uint32_t)(panel * head_lds));
         p2reg = buf_load_f32(p2r, tid < NPB * 32 ? (uint32_t)tid * 4u : SPX_OOB, (uint32_t)(panel * NPB * 32 * 4));
+        if (GATHER) keyreg = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(keyr, tid < NPB * 32 ? (uint32_t)tid * 4u : SPX_OOB, (uint32_t)(panel * NPB * 32 * 4), 0);
     };
     auto consts_commit = [&]() {
 #pragma unroll
         for (int i = 0; i < HPASS; ++i)
             if (h_in) *(u32x4*)(wlds + i * HPB + tid * 16) = hreg[i];
         if (tid < NPB * 32) p2s[tid] = p2reg;
+        if (GATHER && tid < NPB * 32) {
+            keys[tid] = keyreg;
+            koff[tid] = (keyreg & 0xFFFFu) * HW * 4u;
+        }
     };
 
     // Panel epilogue as a ROLLED loop over the panel's 32-prototype blocks (the body is compiled once, with a
@@ -155,7 +174,29 @@ __global__ __launch_bounds__(256 * SPLIT, SPX_FWD_WAVES * SPLIT) void spx_fwd_ke
 #pragma unroll
                     for (int reg = 0; reg < 16; ++reg) av[reg] = -dv[reg];
                 }
-                if (a.dist && a.dist_vec) {
+                if (GATHER) {
+                    // a lane stores the rows whose class is its pixel's class, at [px][slot]; everything else is
+                    // dropped by the out-of-range offset (rows of one class are few: ~P/K of the 32 per block).
+                    // Label maps are piecewise constant, so most (wave, block) pairs have no match at all: one
+                    // ballot skips their 16 store instructions.
+                    uint32_t vo[16];
+                    bool any = false;
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const u32x4 kv = *(const u32x4*)(keys + pb * 32 + 8 * g4 + 4 * h);
+                        const u32x4 ko = *(const u32x4*)(koff + pb * 32 + 8 * g4 + 4 * h);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const bool m = (kv[e] >> 16) == lab16;
+                            any |= m;
+                            vo[4 * g4 + e] = m ? voff_c + ko[e] : SPX_OOB;
+                        }
+                    }
+                    if (__builtin_amdgcn_ballot_w64(any) != 0) {
+#pragma unroll
+                        for (int reg = 0; reg < 16; ++reg) buf_store_f32(dv[reg], cdr, vo[reg], 0);
+                    }
+                } else if (a.dist && a.dist_vec) {
                     // store-issue is what bounds this epilogue (one VMEM instruction per 256 B with a pixel per
                     // lane): turn the tile through the wave's LDS scratch so a lane owns 4 consecutive pixels of
                     // one prototype row -> 4 16-B stores per block instead of 16 dword stores, same bytes
@@ -278,18 +319,23 @@ __global__ __launch_bounds__(256 * SPLIT, SPX_FWD_WAVES * SPLIT) void spx_fwd_ke
 #endif
 }
 
-template <int NPB, int NCB, int SPLIT>
-static hipError_t launch_fwd_x(const SpxFwdArgs& a, int x_dtype, dim3 grid, hipStream_t s) {
+template <int NPB, int NCB, int SPLIT, bool GATHER>
+static hipError_t launch_fwd_g(const SpxFwdArgs& a, int x_dtype, dim3 grid, hipStream_t s) {
     constexpr size_t lds = (size_t)spx_fwd_lds_bytes<NPB, NCB, SPLIT>();
     const dim3 blk(256 * SPLIT);
     if (x_dtype == 1) {
-        if (a.vec_ok) hipLaunchKernelGGL((spx_fwd_kernel<NPB, NCB, true, true, SPLIT>), grid, blk, lds, s, a);
-        else hipLaunchKernelGGL((spx_fwd_kernel<NPB, NCB, true, false, SPLIT>), grid, blk, lds, s, a);
+        if (a.vec_ok) hipLaunchKernelGGL((spx_fwd_kernel<NPB, NCB, true, true, SPLIT, GATHER>), grid, blk, lds, s, a);
+        else hipLaunchKernelGGL((spx_fwd_kernel<NPB, NCB, true, false, SPLIT, GATHER>), grid, blk, lds, s, a);
     } else {
-        if (a.vec_ok) hipLaunchKernelGGL((spx_fwd_kernel<NPB, NCB, false, true, SPLIT>), grid, blk, lds, s, a);
-        else hipLaunchKernelGGL((spx_fwd_kernel<NPB, NCB, false, false, SPLIT>), grid, blk, lds, s, a);
+        if (a.vec_ok) hipLaunchKernelGGL((spx_fwd_kernel<NPB, NCB, false, true, SPLIT, GATHER>), grid, blk, lds, s, a);
+        else hipLaunchKernelGGL((spx_fwd_kernel<NPB, NCB, false, false, SPLIT, GATHER>), grid, blk, lds, s, a);
     }
     return hipGetLastError();
+}
+template <int NPB, int NCB, int SPLIT>
+static hipError_t launch_fwd_x(const SpxFwdArgs& a, int x_dtype, dim3 grid, hipStream_t s) {
+    if (a.labels) return launch_fwd_g<NPB, NCB, SPLIT, true>(a, x_dtype, grid, s);
+    return launch_fwd_g<NPB, NCB, SPLIT, false>(a, x_dtype, grid, s);
 }
 
 hipError_t spx_launch_fwd(const SpxFwdArgs& a, int x_dtype, hipStream_t s) {

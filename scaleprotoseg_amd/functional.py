@@ -65,6 +65,57 @@ class BankLayout:
         )
 
 
+@dataclass
+class ClassGather:
+    """Class-gathered distance mode: per pixel, only the distances to its own class's prototypes.
+
+    ``labels`` int32 [B, H*W] (class 0..K-1, anything else = no class), ``keys`` int32 [npanels * 32 npb] in the
+    plan's padded row order ((class << 16) | slot, -1 = none), ``width`` = J = slots per pixel,
+    ``table`` int64 [K, J]: prototype index of (class, slot) or -1.
+    """
+
+    labels: torch.Tensor
+    keys: torch.Tensor
+    width: int
+    table: torch.Tensor
+
+
+def class_gather_table(layout: BankLayout, prototype_class_identity: torch.Tensor, device) -> Tuple[torch.Tensor, int, torch.Tensor]:
+    """(keys, J, table) for ClassGather from the module's prototype_class_identity [P, K]
+    (segmentation/model/model_multiscale.py:132-141: one-hot rows, possibly all-zero rows)."""
+    ident = prototype_class_identity.detach().cpu()
+    P, K = ident.shape
+    if P != layout.num_prototypes:
+        raise SpxError(f"class identity has {P} rows, bank has {layout.num_prototypes}")
+    has = ident.sum(dim=1) > 0
+    cls = torch.where(has, ident.argmax(dim=1), torch.full((P,), -1, dtype=torch.long))
+    slot = torch.zeros(P, dtype=torch.long)
+    counts = [0] * K
+    for p in range(P):
+        c = int(cls[p])
+        if c >= 0:
+            slot[p] = counts[c]
+            counts[c] += 1
+    J = max(1, max(counts) if counts else 1)
+    table = torch.full((K, J), -1, dtype=torch.long)
+    for p in range(P):
+        if int(cls[p]) >= 0:
+            table[int(cls[p]), int(slot[p])] = p
+    plan = layout.plan()
+    rows = plan.npb * 32
+    keys = torch.full((plan.npanels * rows,), -1, dtype=torch.int64)
+    for q in range(plan.npanels):
+        p0, n = plan.panel_p0[q], plan.panel_np[q]
+        for r_ in range(n):
+            p = p0 + r_
+            if int(cls[p]) >= 0:
+                keys[q * rows + r_] = (int(cls[p]) << 16) | int(slot[p])
+    keys = torch.where(keys < 0, torch.full_like(keys, 0xFFFFFFFF), keys)
+    keys32 = (keys & 0xFFFFFFFF).to(torch.int64)
+    keys32 = torch.where(keys32 >= 2**31, keys32 - 2**32, keys32).to(torch.int32)   # same bits as uint32
+    return keys32.to(device), J, table.to(device)
+
+
 def _x_dtype_code(x: torch.Tensor) -> int:
     if x.dtype == torch.bfloat16:
         return 0
@@ -107,7 +158,7 @@ class _Packs:
 
 class _ProtoHeadFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, bank, head, layout, want_dist, want_act, epsilon, act_fn):
+    def forward(ctx, x, bank, head, layout, want_dist, want_act, epsilon, act_fn, gather=None):
         lib = _lib.load()
         B, HW = _check_x(x, layout)
         P, K = layout.num_prototypes, layout.num_classes
@@ -121,17 +172,33 @@ class _ProtoHeadFn(torch.autograd.Function):
         need_bwd = any(t is not None and t.requires_grad for t in (x, bank, head))
         packs = _Packs(plan, bank2d, head2d, need_bwd)
         f32 = dict(dtype=torch.float32, device=x.device)
-        dist = torch.empty((B, P) + tuple(x.shape[2:]), **f32) if want_dist else None
         act = torch.empty((B * HW, P), **f32) if want_act else None
         logits = torch.empty((B * HW, K), **f32) if head is not None else None
-        with _timed("spx_dist_fwd"):
-            _lib.check(
-                lib.spx_dist_fwd(
-                    C.byref(plan), _lib.ptr(x), xd, B, HW, _lib.ptr(packs.bank), _lib.ptr(packs.p2),
-                    _lib.ptr(packs.head), _lib.ptr(dist), _lib.ptr(act), _lib.ptr(logits), float(epsilon),
-                    ACT_FN[act_fn], _lib.stream_ptr(),
+        if gather is not None:
+            if tuple(gather.labels.shape) != (B, HW) or gather.labels.dtype != torch.int32:
+                raise SpxError(f"gather labels must be int32 [{B}, {HW}]")
+            # slots no prototype maps to (and pixels without a class) stay 0
+            dist = torch.zeros((B, gather.width, HW), **f32)
+            with _timed("spx_dist_fwd"):
+                _lib.check(
+                    lib.spx_dist_fwd_cls(
+                        C.byref(plan), _lib.ptr(x), xd, B, HW, _lib.ptr(packs.bank), _lib.ptr(packs.p2),
+                        _lib.ptr(packs.head), _lib.ptr(gather.labels), _lib.ptr(gather.keys), gather.width,
+                        _lib.ptr(dist), _lib.ptr(act), _lib.ptr(logits), float(epsilon), ACT_FN[act_fn],
+                        _lib.stream_ptr(),
+                    )
                 )
-            )
+        else:
+            dist = torch.empty((B, P) + tuple(x.shape[2:]), **f32) if want_dist else None
+            with _timed("spx_dist_fwd"):
+                _lib.check(
+                    lib.spx_dist_fwd(
+                        C.byref(plan), _lib.ptr(x), xd, B, HW, _lib.ptr(packs.bank), _lib.ptr(packs.p2),
+                        _lib.ptr(packs.head), _lib.ptr(dist), _lib.ptr(act), _lib.ptr(logits), float(epsilon),
+                        ACT_FN[act_fn], _lib.stream_ptr(),
+                    )
+                )
+        ctx.gather = gather
         ctx.layout, ctx.plan, ctx.packs = layout, plan, packs
         ctx.epsilon, ctx.act_fn = float(epsilon), act_fn
         ctx.have = (logits is not None, dist is not None, act is not None)
@@ -165,13 +232,24 @@ class _ProtoHeadFn(torch.autograd.Function):
         a_scr = torch.empty(scr, dtype=torch.uint8, device=dev) if need_head else None
         s = _lib.stream_ptr()
         with _timed("spx_dist_bwd"):
-            _lib.check(
-                lib.spx_dist_bwd(
-                    pp, _lib.ptr(x), xd, B, HW, _lib.ptr(packs.bank), _lib.ptr(packs.bankT), _lib.ptr(packs.p2),
-                    _lib.ptr(packs.headT) if gl is not None else None, _lib.ptr(gd), _lib.ptr(ga), _lib.ptr(gl),
-                    _lib.ptr(dx), _lib.ptr(g_scr), _lib.ptr(a_scr), ctx.epsilon, ACT_FN[ctx.act_fn], s,
+            if ctx.gather is not None:
+                g = ctx.gather
+                _lib.check(
+                    lib.spx_dist_bwd_cls(
+                        pp, _lib.ptr(x), xd, B, HW, _lib.ptr(packs.bank), _lib.ptr(packs.bankT), _lib.ptr(packs.p2),
+                        _lib.ptr(packs.headT) if gl is not None else None, _lib.ptr(g.labels), _lib.ptr(g.keys),
+                        g.width, _lib.ptr(gd), _lib.ptr(ga), _lib.ptr(gl), _lib.ptr(dx), _lib.ptr(g_scr),
+                        _lib.ptr(a_scr), ctx.epsilon, ACT_FN[ctx.act_fn], s,
+                    )
                 )
-            )
+            else:
+                _lib.check(
+                    lib.spx_dist_bwd(
+                        pp, _lib.ptr(x), xd, B, HW, _lib.ptr(packs.bank), _lib.ptr(packs.bankT), _lib.ptr(packs.p2),
+                        _lib.ptr(packs.headT) if gl is not None else None, _lib.ptr(gd), _lib.ptr(ga), _lib.ptr(gl),
+                        _lib.ptr(dx), _lib.ptr(g_scr), _lib.ptr(a_scr), ctx.epsilon, ACT_FN[ctx.act_fn], s,
+                    )
+                )
         d_bank = d_head = None
         if need_bank or need_head:
             ws = torch.empty(lib.spx_bank_bwd_workspace_bytes(pp, B, HW) // 4, dtype=torch.float32, device=dev)
@@ -190,7 +268,7 @@ class _ProtoHeadFn(torch.autograd.Function):
             d_head = torch.zeros_like(head2d)
         if ctx.needs_input_grad[2] and d_head is None and head2d is not None:
             d_head = torch.zeros_like(head2d)
-        return dx, d_bank, d_head, None, None, None, None, None
+        return dx, d_bank, d_head, None, None, None, None, None, None
 
 
 def proto_head_forward(
@@ -203,16 +281,22 @@ def proto_head_forward(
     want_activations: bool = False,
     epsilon: float = 1e-4,
     activation: str = "log",
+    class_gather: Optional[ClassGather] = None,
 ):
-    """(logits [B*H*W, K] | None, distances [B,P,H,W] | None, activations [B*H*W, P] | None)."""
+    """(logits [B*H*W, K] | None, distances [B,P,H,W] | None, activations [B*H*W, P] | None).
+
+    With ``class_gather`` the distance output is the class-gathered tensor [B, J, H*W] (slot planes) instead of the P-wide map
+    (the only entries the reference's KLDLoss reads, segmentation/model/loss.py:89-107)."""
     if activation not in ACT_FN:
         raise SpxError(f"activation {activation!r} has no fused kernel (use 'log' or 'linear')")
     if not x.is_cuda:
         raise SpxError("scaleprotoseg_amd runs on an AMD GPU only; there is no CPU fallback")
-    logits, dist, act = _ProtoHeadFn.apply(x, bank, head, layout, want_distances, want_activations, epsilon, activation)
+    logits, dist, act = _ProtoHeadFn.apply(
+        x, bank, head, layout, want_distances or class_gather is not None, want_activations, epsilon, activation, class_gather
+    )
     return (
         logits if head is not None else None,
-        dist if want_distances else None,
+        dist if (want_distances or class_gather is not None) else None,
         act if want_activations else None,
     )
 

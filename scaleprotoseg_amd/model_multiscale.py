@@ -15,7 +15,8 @@ from typing import Any, Dict, List, Optional, Tuple, Union
 import torch
 import torch.nn as nn
 
-from .functional import BankLayout, SpxError, proto_head_forward
+from .functional import BankLayout, ClassGather, SpxError, class_gather_table, proto_head_forward
+from .loss import ClassDistances
 
 
 def _first_add_on_channels(features: nn.Module) -> int:
@@ -99,6 +100,21 @@ class _PrototypeBankMixin:
             channels_per_scale=cs,
             scale_ranges=tuple(tuple(int(v) for v in self.scale_num_prototypes[s]) for s in range(self.num_scales)),
         )
+
+    def _class_gather(self, target_labels: torch.Tensor, layout: BankLayout, device) -> ClassGather:
+        """Kernel-side description of 'only my class's prototypes' for labels in the reference's convention
+        (0 = void, 1..K = class; module_multiscale.py:234-242, loss.py:73).  The (class, slot) table is cached
+        until prototype_class_identity is re-assigned (prune_prototypes) or the scale table changes."""
+        ident = self.prototype_class_identity
+        tag = (id(ident), tuple(ident.shape), layout.scale_ranges, str(device))
+        cache = getattr(self, "_gather_cache", None)
+        if cache is None or cache[0] != tag:
+            cache = (tag, class_gather_table(layout, ident, device))
+            self._gather_cache = cache
+        keys, width, table = cache[1]
+        B = target_labels.shape[0]
+        labels0 = (target_labels.reshape(B, -1).to(device=device, dtype=torch.int32) - 1).contiguous()
+        return ClassGather(labels=labels0, keys=keys, width=width, table=table)
 
     def _check_fusable(self):
         if getattr(self, "scale_head", None) is not None:
@@ -185,9 +201,15 @@ class PPNetMultiScale(_PrototypeBankMixin, nn.Module):
         return self.last_layer(prototype_activations)  # :243-244 (callers outside the fused path)
 
     def forward_from_conv_features(
-        self, conv_features, return_activations: bool = False, return_distances: bool = False
+        self, conv_features, return_activations: bool = False, return_distances: bool = False, target_labels=None
     ) -> Any:
-        """Same return-tuple rules as model_multiscale.py:340-388."""
+        """Same return-tuple rules as model_multiscale.py:340-388.
+
+        Extension: with ``target_labels`` ([B, H, W] at the latent resolution, 0 = void, 1..K, i.e.
+        the tensor the training step passes to the losses, module_multiscale.py:234-242) the distance entry of the
+        tuple is a ``ClassDistances`` ([B, J, H*W]: per pixel only the distances to its own class's prototypes, the
+        entries KLDLoss reads) and the P-wide fp32 map is never written; ``scaleprotoseg_amd.loss.KLDLoss`` takes it
+        as is."""
         if isinstance(conv_features, list):
             return [self.forward_from_conv_features(c) for c in conv_features]  # flags dropped, as in :359
         if not (hasattr(self, "patch_classification") and self.patch_classification):
@@ -197,11 +219,19 @@ class PPNetMultiScale(_PrototypeBankMixin, nn.Module):
             raise SpxError("callable prototype_activation_function has no fused kernel")
         B, _, H, W = conv_features.shape
         want_dist = return_distances or not return_activations
+        layout = self._layout(self.num_classes)
+        gather = None
+        if target_labels is not None and want_dist:
+            if tuple(target_labels.shape) != (B, H, W):
+                raise SpxError(f"target_labels must be [{B}, {H}, {W}] (latent grid), got {tuple(target_labels.shape)}")
+            gather = self._class_gather(target_labels, layout, conv_features.device)
         logits, dist, act = proto_head_forward(
-            conv_features, self.prototype_vectors, self.last_layer.weight, self._layout(self.num_classes),
-            want_distances=want_dist, want_activations=return_activations, epsilon=self.epsilon,
-            activation=self.prototype_activation_function,
+            conv_features, self.prototype_vectors, self.last_layer.weight, layout,
+            want_distances=want_dist and gather is None, want_activations=return_activations, epsilon=self.epsilon,
+            activation=self.prototype_activation_function, class_gather=gather,
         )
+        if gather is not None:
+            dist = ClassDistances(values=dist, labels=gather.labels, table=gather.table, grid=(H, W))
         logits = logits.reshape(B, H, W, -1)
         if return_activations and not return_distances:
             return logits, act

@@ -287,3 +287,119 @@ def test_large_shape_properties():
     assert torch.equal(l_b.view(H, W, K), l_s.view(8, 16, K).repeat(H // 8, W // 16, 1))
     l2, _, _ = proto_head_forward(big, bank.to(dev), (2 * Wl).to(dev), lay)
     assert torch.allclose(l2, 2 * l_b, rtol=1e-5, atol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------------
+# class-gathered distances: spx_dist_fwd_cls / spx_dist_bwd_cls
+# ------------------------------------------------------------------------------------------------
+GATHER_SHAPES = [
+    (2, 4, 64, 228, 19, 17, 19),     # 3 prototypes per (class, scale), odd grid
+    (1, 1, 256, 190, 19, 16, 64),    # north-star bank: 10 prototypes per class
+    (1, 2, 16, 16, 3, 5, 7),         # floor semantics: prototypes without a class
+    (2, 4, 64, 252, 21, 8, 16),
+]
+
+
+def _labels(B, H, W, K, seed):
+    g = torch.Generator().manual_seed(seed)
+    t = torch.randint(0, K + 1, (B, H, W), generator=g)      # reference convention: 0 = void, 1..K
+    t[t == K] = 0                                            # last class absent ...
+    t[0, 0, 0] = K                                           # ... but for one pixel
+    return t
+
+
+@pytest.mark.parametrize("shape", GATHER_SHAPES)
+@pytest.mark.parametrize("x_dtype", [torch.float32, torch.bfloat16])
+def test_class_gathered_forward_backward(shape, x_dtype):
+    """The gathered output equals the oracle's gather of the reference distance map (same tolerance as the map),
+    and gradients through it equal autograd through the full map with the scattered gradient."""
+    from scaleprotoseg_amd.functional import ClassGather, class_gather_table, proto_head_forward
+
+    dev = _dev()
+    B, S, Cs, P, K, H, W = shape
+    conv, bank, Wl, ident, ranges = _problem(*shape, seed=11)
+    target = _labels(B, H, W, K, seed=5)
+    lab0 = (target.reshape(B, -1) - 1)
+    lay = _layout(P, K, S, Cs, ranges)
+    keys, J, table = class_gather_table(lay, ident, dev)
+    assert torch.equal(table.cpu(), O.class_slot_table(ident))
+    gather = ClassGather(labels=lab0.to(dev, torch.int32).contiguous(), keys=keys, width=J, table=table)
+
+    g = torch.Generator().manual_seed(9)
+    g_logits = torch.randn(B, H, W, K, generator=g) * 1e-3
+    g_cls = torch.randn(B, H * W, J, generator=g) * 1e-3        # oracle layout [B, HW, J]; the kernels use [B, J, HW]
+
+    # oracle: full map -> gather; loss on the gathered entries
+    c0 = conv.clone().requires_grad_(True)
+    p0 = bank.clone().requires_grad_(True)
+    w0 = Wl.clone().requires_grad_(True)
+    l_ref, d_ref, _ = O.forward_from_conv_features(c0, p0, ranges, S, w0)
+    cd_ref = O.gather_class_distances(d_ref, lab0, ident)
+    ((l_ref * g_logits).sum() + (cd_ref * g_cls).sum()).backward()
+
+    x = conv.to(dev, x_dtype).requires_grad_(True)
+    pv = bank.to(dev).requires_grad_(True)
+    w = Wl.to(dev).requires_grad_(True)
+    logits, cd, _ = proto_head_forward(x, pv, w, lay, class_gather=gather)
+    torch.cuda.synchronize()
+    assert tuple(cd.shape) == (B, J, H * W)
+    ref = cd_ref.detach()
+    got = cd.detach().cpu().permute(0, 2, 1)
+    err = (got - ref).abs()
+    assert (err <= 1e-4 * (1 + ref)).all(), f"class distance err {err.max().item()}"
+    # entries no prototype maps to / void pixels are exactly 0
+    assert (got[ref == 0] == 0).all()
+    _assert_fwd(logits, None, None, l_ref.detach(), None, None)
+    ((logits * g_logits.reshape(-1, K).to(dev)).sum() + (cd * g_cls.permute(0, 2, 1).contiguous().to(dev)).sum()).backward()
+    torch.cuda.synchronize()
+    _grad_close(x.grad, c0.grad, "dX", tol=3e-3 if x_dtype == torch.float32 else 8e-3)
+    _grad_close(pv.grad, p0.grad, "dPrototypes")
+    _grad_close(w.grad, w0.grad, "dLastLayer", tol=8e-3)
+
+
+def test_kld_through_the_module(golden):
+    """PPNetMultiScale.forward_from_conv_features(target_labels=...) + KLDLoss on the gathered output
+    == the oracle's KLD (pinned to the reference's KLDLoss) on the full distance map, value and gradients."""
+    import scaleprotoseg_amd as spx
+
+    dev = _dev()
+    B, S, Cs, P, K, H, W = 2, 4, 16, 40, 5, 9, 11
+    conv, bank, Wl, ident, ranges = _problem(B, S, Cs, P, K, H, W, seed=3)
+    target = _labels(B, H, W, K, seed=2)
+
+    class _Feat(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.base = torch.nn.Sequential(torch.nn.Conv2d(3, S * Cs, 1), torch.nn.Conv2d(S * Cs, S * Cs, 1))
+
+        def __repr__(self):
+            return "MSC(standin)"
+
+        def forward(self, x):
+            return x
+
+    net = spx.PPNetMultiScale(_Feat(), 64, (P, Cs, 1, 1), [], K, add_on_layers_type="deeplab_simple",
+                              patch_classification=True, num_scales=S).to(dev)
+    net.prototype_class_identity = net.prototype_class_identity.to(dev)
+    with torch.no_grad():
+        net.prototype_vectors.copy_(bank.to(dev))
+        net.last_layer.weight.copy_(Wl.to(dev))
+    x = conv.to(dev).requires_grad_(True)
+    logits, cd = net.forward_from_conv_features(x, target_labels=target.to(dev))
+    assert isinstance(cd, spx.ClassDistances)
+    kld = spx.KLDLoss(net.prototype_class_identity, S, net.scale_num_prototypes)(cd, target.to(dev))
+    kld.backward()
+    torch.cuda.synchronize()
+
+    c0 = conv.clone().requires_grad_(True)
+    p0 = bank.clone().requires_grad_(True)
+    _, d_ref, _ = O.forward_from_conv_features(c0, p0, ranges, S, Wl)
+    k_ref = O.kld_loss(d_ref, target, ident, S, ranges)
+    k_ref.backward()
+    assert abs(kld.item() - k_ref.item()) <= 1e-4 * max(1.0, abs(k_ref.item())), (kld.item(), k_ref.item())
+    _grad_close(x.grad, c0.grad, "dX via KLD", tol=5e-3)
+    _grad_close(net.prototype_vectors.grad, p0.grad, "dPrototypes via KLD", tol=5e-3)
+    # same module, same loss class, full-map input: identical value
+    logits2, dist2 = net.forward_from_conv_features(conv.to(dev))
+    k2 = spx.KLDLoss(net.prototype_class_identity, S, net.scale_num_prototypes)(dist2, target.to(dev))
+    assert abs(k2.item() - kld.item()) <= 1e-5 * max(1.0, abs(kld.item()))

@@ -136,3 +136,39 @@ def test_resize_label_matches_pil_sampling():
         lab = rng.integers(0, 20, (hi, wi))
         ref = np.asarray(PIL.fromarray(lab.astype(float)).resize((wo, ho), resample=PIL.NEAREST)).astype(np.int64)
         np.testing.assert_array_equal(spx.resize_label(lab, (wo, ho)).numpy(), ref)
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_kld_loss_module_matches_reference(golden, tag):
+    """scaleprotoseg_amd.loss.KLDLoss (vectorised torch, host logic) against the reference's golden value and
+    gradient, on the full map and on the class-gathered form."""
+    import numpy as np
+    from oracle import ppnet_oracle as O
+    from scaleprotoseg_amd.loss import ClassDistances, KLDLoss, class_slot_table, gather_class_distances
+
+    g = golden("kld_loss")
+    t = torch.from_numpy(g[f"{tag}_target"])
+    ident = torch.from_numpy(g[f"{tag}_ident"])
+    S = int(g[f"{tag}_S"])
+    ranges = {s: tuple(int(v) for v in g[f"{tag}_ranges"][s]) for s in range(S)}
+    d = torch.from_numpy(g[f"{tag}_dist"]).requires_grad_(True)
+    loss = KLDLoss(ident, S, ranges)(d, t)
+    loss.backward()
+    assert abs(loss.item() - float(g[f"{tag}_loss"])) <= 1e-6
+    scale = np.abs(g[f"{tag}_grad"]).max()
+    assert np.abs(d.grad.numpy() - g[f"{tag}_grad"]).max() <= 1e-5 * scale
+    table = class_slot_table(ident)
+    assert torch.equal(table, O.class_slot_table(ident))
+    lab0 = t.reshape(t.shape[0], -1) - 1
+    cv = gather_class_distances(torch.from_numpy(g[f"{tag}_dist"]), lab0, table)
+    assert torch.equal(cv, O.gather_class_distances(torch.from_numpy(g[f"{tag}_dist"]), lab0, ident))
+    lg = KLDLoss(ident, S, ranges)(ClassDistances(cv.permute(0, 2, 1).contiguous(), lab0, table, tuple(t.shape[1:])), t)
+    assert abs(lg.item() - float(g[f"{tag}_loss"])) <= 1e-6
+
+
+def test_kld_loss_no_terms():
+    from scaleprotoseg_amd.loss import KLDLoss
+    from oracle import ppnet_oracle as O
+
+    ident = O.default_class_identity(8, 4, 1)
+    assert KLDLoss(ident, 1, {0: (0, 8)})(torch.rand(1, 8, 3, 3), torch.zeros(1, 3, 3, dtype=torch.long)).item() == 0.0

@@ -126,3 +126,20 @@ def test_simplex_and_prune(golden):
     np.testing.assert_array_equal(g["prune_before_protos"][keep], g["prune_after_protos"])
     np.testing.assert_array_equal(g["prune_before_last"][:, keep], g["prune_after_last"])
     assert tuple(g["prune_after_ones_shape"]) == g["prune_after_protos"].shape
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_kld_loss_matches_reference(golden, tag):
+    """oracle.kld_loss vs the reference's KLDLoss (segmentation/model/loss.py:51-146): value and gradient."""
+    g = golden("kld_loss")
+    d = torch.from_numpy(g[f"{tag}_dist"]).requires_grad_(True)
+    t = torch.from_numpy(g[f"{tag}_target"])
+    ident = torch.from_numpy(g[f"{tag}_ident"])
+    S = int(g[f"{tag}_S"])
+    ranges = {s: tuple(int(v) for v in g[f"{tag}_ranges"][s]) for s in range(S)}
+    loss = O.kld_loss(d, t, ident, S, ranges)
+    loss.backward()
+    assert abs(loss.item() - float(g[f"{tag}_loss"])) <= 1e-7
+    assert np.abs(d.grad.numpy() - g[f"{tag}_grad"]).max() <= 1e-8
+    assert float(g["empty_loss"]) == 0.0
+    assert O.kld_loss(torch.rand(1, 8, 3, 3), torch.zeros(1, 3, 3, dtype=torch.long), O.default_class_identity(8, 4, 1), 1, {0: (0, 8)}).item() == 0.0
