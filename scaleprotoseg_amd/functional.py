@@ -128,6 +128,8 @@ def _check_x(x: torch.Tensor, layout: BankLayout) -> Tuple[int, int]:
     if x.dim() != 4:
         raise SpxError(f"features must be [B, C, H, W], got shape {tuple(x.shape)}")
     B, Cx, H, W = x.shape
+    if B < 1 or H * W < 1:
+        raise SpxError(f"empty input: features have shape {tuple(x.shape)}")
     if Cx != layout.num_scales * layout.channels_per_scale:
         raise SpxError(
             f"features have {Cx} channels, prototype bank expects "

@@ -403,3 +403,66 @@ def test_kld_through_the_module(golden):
     logits2, dist2 = net.forward_from_conv_features(conv.to(dev))
     k2 = spx.KLDLoss(net.prototype_class_identity, S, net.scale_num_prototypes)(dist2, target.to(dev))
     assert abs(k2.item() - kld.item()) <= 1e-5 * max(1.0, abs(kld.item()))
+
+
+def test_north_star_size_properties():
+    """BASELINE.json's full size (one 1024x2048 latent grid, C=256, P=190): properties that need no CPU reference.
+    (a) forward outputs of a pixel do not depend on its position (a periodic image gives periodic outputs, bit for
+    bit); (b) dX of a periodic image under periodic upstream gradients is periodic, bit for bit; (c) dPrototypes and
+    dLastLayer equal (number of periods) x the one-period gradients up to fp32 summation order."""
+    from scaleprotoseg_amd.functional import proto_head_forward
+
+    dev = _dev()
+    S, Cs, P, K = 1, 256, 190, 19
+    H, W, h, w = 1024, 2048, 8, 64
+    conv, bank, Wl, ident, ranges = _problem(1, S, Cs, P, K, h, w, seed=21)
+    lay = _layout(P, K, S, Cs, ranges)
+    g = torch.Generator().manual_seed(3)
+    gl_s = (torch.randn(h * w, K, generator=g) * 1e-3).to(dev)
+    gd_s = (torch.randn(1, P, h, w, generator=g) * 1e-3).to(dev)
+    reps = (H // h) * (W // w)
+
+    def run(x, gl, gd):
+        x = x.requires_grad_(True)
+        pv = bank.to(dev).requires_grad_(True)
+        wl = Wl.to(dev).requires_grad_(True)
+        logits, dist, _ = proto_head_forward(x, pv, wl, lay)
+        torch.autograd.backward([logits, dist], [gl, gd])
+        torch.cuda.synchronize()
+        return logits.detach(), dist.detach(), x.grad, pv.grad, wl.grad
+
+    small = conv.to(dev, torch.bfloat16)
+    l_s, d_s, dx_s, dp_s, dw_s = run(small.clone(), gl_s, gd_s)
+    big = small.repeat(1, 1, H // h, W // w).contiguous()
+    gl_b = gl_s.view(h, w, K).repeat(H // h, W // w, 1).reshape(H * W, K).contiguous()
+    gd_b = gd_s.repeat(1, 1, H // h, W // w).contiguous()
+    l_b, d_b, dx_b, dp_b, dw_b = run(big, gl_b, gd_b)
+    assert torch.equal(d_b, d_s.repeat(1, 1, H // h, W // w))
+    assert torch.equal(l_b.view(H, W, K), l_s.view(h, w, K).repeat(H // h, W // w, 1))
+    assert torch.equal(dx_b, dx_s.repeat(1, 1, H // h, W // w))
+    _grad_close(dp_b, reps * dp_s, "dPrototypes (full size)", tol=2e-3)
+    _grad_close(dw_b, reps * dw_s, "dLastLayer (full size)", tol=2e-3)
+
+
+def test_argument_errors():
+    """Error behaviour of the boundary: bad shapes raise SpxError (the C ABI returns non-zero with a message), nothing
+    is launched."""
+    import scaleprotoseg_amd as spx
+    from scaleprotoseg_amd.functional import proto_head_forward
+
+    dev = _dev()
+    lay = _layout(40, 5, 4, 16, O.default_scale_ranges(40, 4))
+    bank = torch.rand(40, 16, 1, 1, device=dev)
+    head = torch.rand(5, 40, device=dev)
+    with pytest.raises(spx.SpxError, match="channels"):
+        proto_head_forward(torch.rand(1, 48, 4, 4, device=dev), bank, head, lay)
+    with pytest.raises(spx.SpxError, match="bfloat16 or float32"):
+        proto_head_forward(torch.rand(1, 64, 4, 4, device=dev).half(), bank, head, lay)
+    with pytest.raises(spx.SpxError, match="head matrix"):
+        proto_head_forward(torch.rand(1, 64, 4, 4, device=dev), bank, torch.rand(6, 40, device=dev), lay)
+    with pytest.raises(spx.SpxError, match="empty input"):
+        proto_head_forward(torch.rand(0, 64, 4, 4, device=dev), bank, head, lay)
+    # P % num_scales != 0 with the reference's own scale table (Ps = P // S: 189 of 190 rows covered,
+    # model_multiscale.py:146-149): its forward raises at F.linear, the plan is rejected here
+    with pytest.raises(spx.SpxError):
+        _layout(190, 19, 3, 16, {0: (0, 63), 1: (63, 126), 2: (126, 189)}).plan()
