@@ -45,7 +45,7 @@ typedef struct spx_plan {
     int32_t channels_per_scale;    /* Cs (multiple of 16) */
     int32_t kc;                    /* channels staged per LDS step (32; a 16-channel tail is zero-filled) */
     int32_t npb;                   /* 32-prototype blocks per panel (2, 4 or 6) */
-    int32_t ncb;                   /* 32-class blocks of the head (1 or 5) */
+    int32_t ncb;                   /* 32-class blocks of the head (1, 2 or 5) */
     int32_t npanels;
     int32_t panel_ch0[SPX_MAX_PANELS];  /* first feature channel of the panel's scale */
     int32_t panel_p0[SPX_MAX_PANELS];   /* first prototype row of the panel */

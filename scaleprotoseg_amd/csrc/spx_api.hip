@@ -27,7 +27,7 @@ static int check_plan(const spx_plan* pl) {
     if (pl->ncb < 1 || pl->ncb > 5) return fail("plan: ncb %d out of range", pl->ncb);
     if (pl->kc != 32) return fail("plan: kc %d", pl->kc);
     if (pl->npb != 2 && pl->npb != 4 && pl->npb != 6) return fail("plan: npb %d (must be 2, 4 or 6)", pl->npb);
-    if (pl->ncb != 1 && pl->ncb != 5) return fail("plan: ncb %d (must be 1 or 5)", pl->ncb);
+    if (pl->ncb != 1 && pl->ncb != 2 && pl->ncb != 5) return fail("plan: ncb %d (must be 1, 2 or 5)", pl->ncb);
     return 0;
 }
 static int x_vec_ok(const void* x, int x_dtype, int HW) {
@@ -55,7 +55,7 @@ int spx_make_plan(int32_t P, int32_t K, int32_t S, int32_t Cs, const int32_t* lo
     out->num_scales = S;
     out->channels_per_scale = Cs;
     out->kc = 32;                              /* chunks of 32 channels; a 16-channel tail is zero-filled */
-    out->ncb = (K <= 32) ? 1 : 5;              /* the kernels are specialised for 1 or 5 class blocks */
+    out->ncb = (K <= 32) ? 1 : (K <= 64) ? 2 : 5;   /* the kernels are specialised for 1, 2 or 5 class blocks */
     int per_max = 1, covered = 0;
     for (int s = 0; s < S; ++s) {
         const int n = hi[s] - lo[s];

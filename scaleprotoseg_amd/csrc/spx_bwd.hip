@@ -600,6 +600,11 @@ hipError_t spx_launch_bwd(const SpxBwdArgs& a, int x_dtype, hipStream_t s) {
         if (pl.npb == 4) return launch_bwd_x<4, 1>(a, x_dtype, grid, s);
         return launch_bwd_x<6, 1>(a, x_dtype, grid, s);
     }
+    if (pl.ncb == 2) {
+        if (pl.npb == 2) return launch_bwd_x<2, 2>(a, x_dtype, grid, s);
+        if (pl.npb == 4) return launch_bwd_x<4, 2>(a, x_dtype, grid, s);
+        return launch_bwd_x<6, 2>(a, x_dtype, grid, s);
+    }
     if (pl.npb == 2) return launch_bwd_x<2, 5>(a, x_dtype, grid, s);
     if (pl.npb == 4) return launch_bwd_x<4, 5>(a, x_dtype, grid, s);
     return launch_bwd_x<6, 5>(a, x_dtype, grid, s);
@@ -958,6 +963,8 @@ hipError_t spx_launch_bank_bwd(const SpxBankBwdArgs& a, int x_dtype, hipStream_t
     hipError_t e;
     if (pl.ncb == 1)
         e = pl.npb == 2 ? launch_bank_x<2, 1>(a, x_dtype, grid, s) : pl.npb == 4 ? launch_bank_x<4, 1>(a, x_dtype, grid, s) : launch_bank_x<6, 1>(a, x_dtype, grid, s);
+    else if (pl.ncb == 2)
+        e = pl.npb == 2 ? launch_bank_x<2, 2>(a, x_dtype, grid, s) : pl.npb == 4 ? launch_bank_x<4, 2>(a, x_dtype, grid, s) : launch_bank_x<6, 2>(a, x_dtype, grid, s);
     else
         e = pl.npb == 2 ? launch_bank_x<2, 5>(a, x_dtype, grid, s) : pl.npb == 4 ? launch_bank_x<4, 5>(a, x_dtype, grid, s) : launch_bank_x<6, 5>(a, x_dtype, grid, s);
     if (e != hipSuccess) return e;

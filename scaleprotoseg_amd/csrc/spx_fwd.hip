@@ -351,6 +351,12 @@ hipError_t spx_launch_fwd(const SpxFwdArgs& a, int x_dtype, hipStream_t s) {
         if (pl.npb == 4) return launch_fwd_x<4, 1, SPX_FWD_SPLIT>(a, x_dtype, grid, s);
         return launch_fwd_x<6, 1, SPX_FWD_SPLIT>(a, x_dtype, grid, s);
     }
+    if (pl.ncb == 2) {
+        // 33..64 head rows (the grouping head: 3 groups x 19 / 21 classes), head fragments from L2
+        if (pl.npb == 2) return launch_fwd_x<2, 2, 1>(a, x_dtype, grid, s);
+        if (pl.npb == 4) return launch_fwd_x<4, 2, 1>(a, x_dtype, grid, s);
+        return launch_fwd_x<6, 2, 1>(a, x_dtype, grid, s);
+    }
     // up to 160 classes: 80 logits accumulators per lane, one wave per pixel group
     if (pl.npb == 2) return launch_fwd_x<2, 5, 1>(a, x_dtype, grid, s);
     if (pl.npb == 4) return launch_fwd_x<4, 5, 1>(a, x_dtype, grid, s);

@@ -62,6 +62,8 @@ SHAPES = [
     (1, 2, 16, 16, 3, 5, 7),         # Cs = 16 (kc = 16), floor semantics (unassigned prototypes)
     (1, 4, 64, 1800, 150, 9, 8),     # ADE bank: 3 panels per scale, 5 class blocks
     (1, 1, 64, 1500, 150, 6, 8),     # ADE literal 150 x 10
+    (1, 4, 64, 228, 57, 9, 13),      # 57 head rows (grouping head): 2 class blocks
+    (1, 1, 256, 190, 64, 8, 16),     # exactly 64 head rows, 6-block panel
 ]
 
 
@@ -112,6 +114,8 @@ def _grad_close(got, ref, what, tol=3e-3):
 
 
 BWD_SHAPES = [
+    (1, 4, 64, 228, 57, 9, 13),      # dense grouping head of the Cityscapes group phase (3 x 19 rows: 2 class blocks)
+    (1, 1, 64, 210, 63, 8, 16),      # Pascal group phase (3 x 21 rows), 4-block panels
     (2, 4, 64, 228, 19, 17, 19),
     (1, 1, 256, 190, 19, 16, 64),
     (1, 1, 64, 210, 21, 13, 11),
