@@ -35,7 +35,7 @@ extern "C" {
 #endif
 
 #define SPX_MAX_PANELS 64   /* (scale, <=192-prototype block) work units per pixel tile */
-#define SPX_ABI_VERSION 2
+#define SPX_ABI_VERSION 3
 
 /* How the prototype bank is cut into MFMA panels.  Filled by spx_make_plan(). */
 typedef struct spx_plan {
@@ -123,6 +123,32 @@ int spx_dist_bwd_cls(const spx_plan* plan, const void* x, int32_t x_dtype, int32
                      const float* d_class_distances, const float* d_act, const float* d_logits,
                      void* dx, void* g_out, void* a_out,
                      float epsilon, int32_t act_fn, void* stream);
+
+/* Grouping head with its tail fused (segmentation/model/model_multiscale_group.py:283-308, run_last_layer):
+ *   units = act . Wd^T   (Wd = the dense [U = G*K', P] form of the per-class group_projection matrices, packed with
+ *                         spx_pack_head for a plan whose num_classes = U)
+ *   g = exp(units);  logits = g . W_g^T   (W_g = last_layer_group.weight [K2, U], K2 <= 32)
+ * spx_pack_group_tail re-packs W_g (packed_tail: forward, packed_tailT: backward, spx_packed_tail_bytes() each);
+ * spx_pack_headT_units is spx_pack_head's transposed output with the unit index in accumulator order (the
+ * backward builds its dUnits operand in registers): spx_packed_headT_bytes().
+ * Forward: logits [B*HW, K2]; group_activations [B*HW, U] = g (optional output, required by the backward).
+ * Backward: d_logits [B*HW, K2] in; d_units [B*HW, U] = (d_logits . W_g) * g out (the d_logits operand of
+ * spx_bank_bwd, which then yields d_Wd); d_W_g = d_logits^T . g is a [K2, U] product left to the caller. */
+size_t spx_packed_tail_bytes(const spx_plan* plan);
+int spx_pack_group_tail(const spx_plan* plan, const float* Wg, int32_t K2, void* packed_tail, void* packed_tailT,
+                        void* stream);
+int spx_pack_headT_units(const spx_plan* plan, const float* W, void* packed_headT_units, void* stream);
+int spx_dist_fwd_group(const spx_plan* plan, const void* x, int32_t x_dtype, int32_t B, int32_t HW,
+                       const void* packed_bank, const float* packed_p2, const void* packed_head,
+                       const void* packed_tail, int32_t K2,
+                       float* distances, float* activations, float* group_activations, float* logits,
+                       float epsilon, int32_t act_fn, void* stream);
+int spx_dist_bwd_group(const spx_plan* plan, const void* x, int32_t x_dtype, int32_t B, int32_t HW,
+                       const void* packed_bank, const void* packed_bankT, const float* packed_p2,
+                       const void* packed_headT_units, const void* packed_tailT, int32_t K2,
+                       const float* group_activations, const float* d_dist, const float* d_act,
+                       const float* d_logits, float* d_units, void* dx, void* g_out, void* a_out,
+                       float epsilon, int32_t act_fn, void* stream);
 
 /* Bytes of the g_out (and of the a_out) scratch of spx_dist_bwd. */
 size_t spx_bwd_scratch_bytes(const spx_plan* plan, int32_t B, int32_t HW);

@@ -15,7 +15,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libspx_hip.so")
 SPX_MAX_PANELS = 64
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class SpxError(RuntimeError):
@@ -59,6 +59,11 @@ SIGNATURES = {
     "spx_dist_bwd": (C.c_int, [_PP, _V, _I, _I, _I, _V, _V, _V, _V, _V, _V, _V, _V, _V, _V, _F, _I, _V]),
     "spx_dist_fwd_cls": (C.c_int, [_PP, _V, _I, _I, _I, _V, _V, _V, _V, _V, _I, _V, _V, _V, _F, _I, _V]),
     "spx_dist_bwd_cls": (C.c_int, [_PP, _V, _I, _I, _I, _V, _V, _V, _V, _V, _V, _I, _V, _V, _V, _V, _V, _V, _F, _I, _V]),
+    "spx_packed_tail_bytes": (C.c_size_t, [_PP]),
+    "spx_pack_group_tail": (C.c_int, [_PP, _V, _I, _V, _V, _V]),
+    "spx_pack_headT_units": (C.c_int, [_PP, _V, _V, _V]),
+    "spx_dist_fwd_group": (C.c_int, [_PP, _V, _I, _I, _I, _V, _V, _V, _V, _I, _V, _V, _V, _V, _F, _I, _V]),
+    "spx_dist_bwd_group": (C.c_int, [_PP, _V, _I, _I, _I, _V, _V, _V, _V, _V, _I, _V, _V, _V, _V, _V, _V, _V, _V, _F, _I, _V]),
     "spx_bwd_scratch_bytes": (C.c_size_t, [_PP, _I, _I]),
     "spx_bank_bwd_workspace_bytes": (C.c_size_t, [_PP, _I, _I]),
     "spx_bank_bwd": (C.c_int, [_PP, _V, _I, _I, _I, _V, _V, _V, _V, _V, _V, _V, _V]),

@@ -110,10 +110,29 @@ int spx_pack_head(const spx_plan* pl, const float* W, void* ph, void* phT, void*
     return hip_status(spx_launch_pack_head(*pl, W, ph, phT, (hipStream_t)stream), "spx_pack_head");
 }
 
+size_t spx_packed_tail_bytes(const spx_plan* pl) { return (size_t)pl->ncb * 2 * 2048; }
+
+int spx_pack_group_tail(const spx_plan* pl, const float* Wg, int32_t K2, void* packed_tail, void* packed_tailT, void* stream) {
+    if (check_plan(pl)) return 1;
+    if (!Wg || !packed_tail) return fail("spx_pack_group_tail: NULL buffer");
+    if (K2 < 1 || K2 > 32) return fail("spx_pack_group_tail: %d classes (the fused tail carries at most 32)", K2);
+    return hip_status(spx_launch_pack_tail(*pl, Wg, K2, packed_tail, packed_tailT, (hipStream_t)stream), "spx_pack_group_tail");
+}
+
+int spx_pack_headT_units(const spx_plan* pl, const float* W, void* packed_headT_units, void* stream) {
+    if (check_plan(pl)) return 1;
+    if (!W || !packed_headT_units) return fail("spx_pack_headT_units: NULL buffer");
+    return hip_status(spx_launch_pack_headT_units(*pl, W, packed_headT_units, (hipStream_t)stream), "spx_pack_headT_units");
+}
+
+struct SpxTailFwd { const void* packed_tail; int32_t K2; float* gact; };
+struct SpxTailBwd { const void* packed_tailT; int32_t K2; const float* gact; float* d_units; };
+
 static int dist_fwd_impl(const spx_plan* pl, const void* x, int32_t x_dtype, int32_t B, int32_t HW,
                          const void* packed_bank, const float* packed_p2, const void* packed_head, float* distances,
                          const int32_t* labels, const uint32_t* proto_key, int32_t J, float* cls_dist,
-                         float* activations, float* logits, float epsilon, int32_t act_fn, void* stream) {
+                         float* activations, float* logits, float epsilon, int32_t act_fn, void* stream,
+                         SpxTailFwd tail = SpxTailFwd{nullptr, 0, nullptr}) {
     if (check_plan(pl)) return 1;
     if (!x || !packed_bank || !packed_p2) return fail("spx_dist_fwd: NULL operand");
     if (x_dtype != 0 && x_dtype != 1) return fail("spx_dist_fwd: x_dtype %d (0 = bf16, 1 = fp32)", x_dtype);
@@ -140,6 +159,9 @@ static int dist_fwd_impl(const spx_plan* pl, const void* x, int32_t x_dtype, int
     a.proto_key = proto_key;
     a.cls_dist = cls_dist;
     a.J = J;
+    a.packed_tail = (const char*)tail.packed_tail;
+    a.gact = tail.gact;
+    a.K2 = tail.K2;
     a.dist_vec = distances && ((uintptr_t)distances & 15) == 0 && HW % 4 == 0;
     a.eps = epsilon;
     a.act_fn = act_fn;
@@ -152,6 +174,16 @@ int spx_dist_fwd(const spx_plan* pl, const void* x, int32_t x_dtype, int32_t B, 
                  float* logits, float epsilon, int32_t act_fn, void* stream) {
     return dist_fwd_impl(pl, x, x_dtype, B, HW, packed_bank, packed_p2, packed_head, distances, nullptr, nullptr, 0,
                          nullptr, activations, logits, epsilon, act_fn, stream);
+}
+
+int spx_dist_fwd_group(const spx_plan* pl, const void* x, int32_t x_dtype, int32_t B, int32_t HW,
+                       const void* packed_bank, const float* packed_p2, const void* packed_head,
+                       const void* packed_tail, int32_t K2, float* distances, float* activations,
+                       float* group_activations, float* logits, float epsilon, int32_t act_fn, void* stream) {
+    if (!packed_head || !packed_tail || !logits) return fail("spx_dist_fwd_group: NULL head / tail / logits");
+    if (K2 < 1 || K2 > 32) return fail("spx_dist_fwd_group: %d classes (at most 32)", K2);
+    return dist_fwd_impl(pl, x, x_dtype, B, HW, packed_bank, packed_p2, packed_head, distances, nullptr, nullptr, 0,
+                         nullptr, activations, logits, epsilon, act_fn, stream, SpxTailFwd{packed_tail, K2, group_activations});
 }
 
 static int check_cls(const char* who, const int32_t* labels, const uint32_t* proto_key, int32_t J, int32_t HW) {
@@ -176,7 +208,7 @@ static int dist_bwd_impl(const spx_plan* pl, const void* x, int32_t x_dtype, int
                          const void* packed_headT, const float* d_dist, const int32_t* labels,
                          const uint32_t* proto_key, int32_t J, const float* d_cls_dist, const float* d_act,
                          const float* d_logits, void* dx, void* g_out, void* a_out, float epsilon, int32_t act_fn,
-                         void* stream) {
+                         void* stream, SpxTailBwd tail = SpxTailBwd{nullptr, 0, nullptr, nullptr}) {
     if (check_plan(pl)) return 1;
     if (!x || !packed_bank || !packed_p2) return fail("spx_dist_bwd: NULL operand");
     if (x_dtype != 0 && x_dtype != 1) return fail("spx_dist_bwd: x_dtype %d", x_dtype);
@@ -198,6 +230,10 @@ static int dist_bwd_impl(const spx_plan* pl, const void* x, int32_t x_dtype, int
     a.proto_key = proto_key;
     a.d_cls_dist = d_cls_dist;
     a.J = J;
+    a.packed_tailT = (const char*)tail.packed_tailT;
+    a.gact = tail.gact;
+    a.d_units = tail.d_units;
+    a.K2 = tail.K2;
     a.dx = dx;
     a.g_out = (uint16_t*)g_out;
     a.a_out = (uint16_t*)a_out;
@@ -216,6 +252,20 @@ int spx_dist_bwd(const spx_plan* pl, const void* x, int32_t x_dtype, int32_t B, 
                  int32_t act_fn, void* stream) {
     return dist_bwd_impl(pl, x, x_dtype, B, HW, packed_bank, packed_bankT, packed_p2, packed_headT, d_dist, nullptr,
                          nullptr, 0, nullptr, d_act, d_logits, dx, g_out, a_out, epsilon, act_fn, stream);
+}
+
+int spx_dist_bwd_group(const spx_plan* pl, const void* x, int32_t x_dtype, int32_t B, int32_t HW,
+                       const void* packed_bank, const void* packed_bankT, const float* packed_p2,
+                       const void* packed_headT_units, const void* packed_tailT, int32_t K2,
+                       const float* group_activations, const float* d_dist, const float* d_act,
+                       const float* d_logits, float* d_units, void* dx, void* g_out, void* a_out, float epsilon,
+                       int32_t act_fn, void* stream) {
+    if (!packed_headT_units || !packed_tailT || !group_activations || !d_logits || !d_units)
+        return fail("spx_dist_bwd_group: NULL tail operand");
+    if (K2 < 1 || K2 > 32) return fail("spx_dist_bwd_group: %d classes (at most 32)", K2);
+    return dist_bwd_impl(pl, x, x_dtype, B, HW, packed_bank, packed_bankT, packed_p2, packed_headT_units, d_dist,
+                         nullptr, nullptr, 0, nullptr, d_act, d_logits, dx, g_out, a_out, epsilon, act_fn, stream,
+                         SpxTailBwd{packed_tailT, K2, group_activations, d_units});
 }
 
 int spx_dist_bwd_cls(const spx_plan* pl, const void* x, int32_t x_dtype, int32_t B, int32_t HW,

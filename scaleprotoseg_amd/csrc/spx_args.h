@@ -18,6 +18,10 @@ struct SpxFwdArgs {
     const uint32_t* proto_key; // [npanels][32 npb] (class << 16) | slot per padded prototype row, 0xFFFFFFFF = none
     float* cls_dist;           // [B, J, HW] slot planes
     int J;
+    // grouping-head tail (spx_dist_fwd_group): logits = W_g . exp(units), units = the head product
+    const char* packed_tail;   // W_g A-fragments (spx_pack_group_tail); NULL = no tail
+    float* gact;               // [B*HW, U] exp(units) (optional)
+    int K2;                    // classes of the tail (<= 32)
     float eps;
     int act_fn;
     unsigned long long* dbg;   // diagnostic builds only (SPX_DIAG_STAMPS): per-workgroup phase clocks
@@ -36,6 +40,11 @@ struct SpxBwdArgs {
     const uint32_t* proto_key;
     const float* d_cls_dist;    // [B, J, HW]
     int J;
+    // grouping-head tail (spx_dist_bwd_group): d_logits is [B*HW, K2]; dUnits = (W_g^T . dLogits) * exp(units)
+    const char* packed_tailT;   // W_g^T A-fragments; NULL = no tail
+    const float* gact;          // [B*HW, U] exp(units) of the forward
+    float* d_units;             // [B*HW, U] written for the parameter kernel
+    int K2;
     void* dx;
     uint16_t* g_out;
     uint16_t* a_out;
@@ -64,6 +73,8 @@ size_t spx_bwd_scratch_elems(const spx_plan& pl, int B, int HW);
 size_t spx_bank_bwd_ws_floats(const spx_plan& pl, int nsplit);
 hipError_t spx_launch_pack_bank(const spx_plan& pl, const float* bank, void* pb, void* pbT, float* p2, hipStream_t s);
 hipError_t spx_launch_pack_head(const spx_plan& pl, const float* W, void* ph, void* phT, hipStream_t s);
+hipError_t spx_launch_pack_tail(const spx_plan& pl, const float* Wg, int K2, void* pt, void* ptT, hipStream_t s);
+hipError_t spx_launch_pack_headT_units(const spx_plan& pl, const float* W, void* phT, hipStream_t s);
 hipError_t spx_launch_push_argmin(const float* dist, const int32_t* labels, const float* ident, int B, int P, int K,
                                   int HW, int void_class, float max_dist, int64_t* idx, float* val,
                                   uint64_t* scratch, hipStream_t s);

@@ -136,7 +136,64 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
     const float act_c1 = act_is_log ? -(1.0f - a.eps) : -1.0f;
     // dLogits of this lane's pixel as split-bf16 B fragments: element j of k-step c <-> class 16c + 8h + j
     bf16x8 dlhi[NCB * 2], dllo[NCB * 2];
-    {
+    if (a.packed_tailT) {
+        // grouping-head tail: d_logits is [px][K2]; dUnits[u, px] = (sum_k W_g[k, u] dLogits[px, k]) * g[px, u] is
+        // formed here as accumulator tiles (rows = units), written out for the parameter kernel, and becomes the
+        // B operand of the head^T product below in ACCUMULATOR row order (packed_headT is the _units variant).
+        const int K2 = a.K2;
+        const spx_rsrc lr = make_rsrc_pred(a.d_logits + (size_t)b * a.HW * K2);
+        const uint32_t voff_l = px_ok ? ((uint32_t)px * (uint32_t)K2 + (uint32_t)(8 * h)) * 4u : SPX_OOB;
+        bf16x8 l2hi[2], l2lo[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int cls = c * 16 + 8 * h + j;
+                const float v = buf_load_f32(lr, cls < K2 ? voff_l : SPX_OOB, (uint32_t)((c * 16 + j) * 4));
+                __bf16 hi, lo;
+                split_bf16(v, hi, lo);
+                l2hi[c][j] = hi;
+                l2lo[c][j] = lo;
+            }
+        }
+        const spx_rsrc ttr = make_rsrc(a.packed_tailT);
+        const spx_rsrc gir = make_rsrc_pred(a.gact + (size_t)b * a.HW * K);
+        const spx_rsrc dur = make_rsrc_pred(a.d_units + (size_t)b * a.HW * K);
+        const uint32_t voff_u = px_ok ? ((uint32_t)px * (uint32_t)K + (uint32_t)(4 * h)) * 4u : SPX_OOB;     // [px][unit]
+#pragma unroll
+        for (int ub = 0; ub < NCB; ++ub) {
+            f32x16 dg;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) dg[i] = 0.0f;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const uint32_t so = (uint32_t)((ub * 2 + c) * 2048);
+                const bf16x8 whi = __builtin_bit_cast(bf16x8, buf_load_b128(ttr, (uint32_t)lane * 16u, so));
+                const bf16x8 wlo = __builtin_bit_cast(bf16x8, buf_load_b128(ttr, (uint32_t)lane * 16u, so + 1024u));
+                dg = mfma_bf16(whi, l2hi[c], dg);
+                dg = mfma_bf16(wlo, l2hi[c], dg);
+                dg = mfma_bf16(whi, l2lo[c], dg);
+            }
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int u = ub * 32 + acc_row(reg, h);
+                const uint32_t so = (uint32_t)((ub * 32 + (reg & 3) + 8 * (reg >> 2)) * 4);
+                const float gval = buf_load_f32(gir, u < K ? voff_u : SPX_OOB, so);
+                dg[reg] *= gval;                                   // dropped loads return 0: padded units / pixels
+                buf_store_f32(dg[reg], dur, u < K ? voff_u : SPX_OOB, so);
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    __bf16 hi, lo;
+                    split_bf16(act_c1 * dg[8 * s2 + j], hi, lo);
+                    dlhi[ub * 2 + s2][j] = hi;
+                    dllo[ub * 2 + s2][j] = lo;
+                }
+            }
+        }
+    } else {
         const spx_rsrc lr = make_rsrc_pred(a.d_logits ? a.d_logits + (size_t)b * a.HW * K : nullptr);
         const uint32_t voff_l = (a.d_logits && px_ok) ? ((uint32_t)px * (uint32_t)K + (uint32_t)(8 * h)) * 4u : SPX_OOB;
 #pragma unroll

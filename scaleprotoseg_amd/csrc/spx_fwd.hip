@@ -296,7 +296,49 @@ __global__ __launch_bounds__(256 * SPLIT, SPX_FWD_WAVES * SPLIT) void spx_fwd_ke
             for (int reg = 0; reg < 16; ++reg) accl[0][reg] += sc[reg * 64 + lane];
         }
     }
-    if (want_head && ph == 0) {
+    if (want_head && ph == 0 && a.packed_tail) {
+        // grouping-head tail (model_multiscale_group.py:303-308): g = exp(units), logits = W_g . g.  The unit tiles
+        // are the B operand of a second split-bf16 product, exactly as the activation tiles were for the head.
+        const int K2 = a.K2;
+        const spx_rsrc tr = make_rsrc(a.packed_tail);
+        const spx_rsrc gor = make_rsrc_pred(a.gact ? a.gact + (size_t)b * a.HW * K : nullptr);
+        const uint32_t voff_g = px_ok ? ((uint32_t)px * (uint32_t)K + (uint32_t)(4 * h)) * 4u : SPX_OOB;    // [px][unit]
+        f32x16 acc2;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc2[i] = 0.0f;
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) {
+            float gv[16];
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int u = cb * 32 + acc_row(reg, h);
+                gv[reg] = u < K ? __builtin_amdgcn_exp2f(accl[cb][reg] * 1.44269504089f) : 0.0f;
+                if (a.gact) buf_store_f32(gv[reg], gor, u < K ? voff_g : SPX_OOB, (uint32_t)((cb * 32 + (reg & 3) + 8 * (reg >> 2)) * 4));
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                bf16x8 ghi, glo;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    __bf16 hi, lo;
+                    split_bf16(gv[8 * s2 + j], hi, lo);
+                    ghi[j] = hi;
+                    glo[j] = lo;
+                }
+                const uint32_t so = (uint32_t)((cb * 2 + s2) * 2048);
+                const bf16x8 whi = __builtin_bit_cast(bf16x8, buf_load_b128(tr, (uint32_t)lane * 16u, so));
+                const bf16x8 wlo = __builtin_bit_cast(bf16x8, buf_load_b128(tr, (uint32_t)lane * 16u, so + 1024u));
+                acc2 = mfma_bf16(whi, ghi, acc2);
+                acc2 = mfma_bf16(wlo, ghi, acc2);
+                acc2 = mfma_bf16(whi, glo, acc2);
+            }
+        }
+        const spx_rsrc lr = make_rsrc_pred(a.logits + (size_t)b * a.HW * K2);
+        const uint32_t voff_l = px_ok ? ((uint32_t)px * (uint32_t)K2 + (uint32_t)(4 * h)) * 4u : SPX_OOB;   // [px][class]
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg)
+            buf_store_f32(acc2[reg], lr, acc_row(reg, h) < K2 ? voff_l : SPX_OOB, (uint32_t)(((reg & 3) + 8 * (reg >> 2)) * 4));
+    } else if (want_head && ph == 0) {
         const spx_rsrc lr = make_rsrc_pred(a.logits + (size_t)b * a.HW * K);
         const uint32_t voff_l = px_ok ? ((uint32_t)px * (uint32_t)K + (uint32_t)(4 * h)) * 4u : SPX_OOB;   // [px][class]
 #pragma unroll

@@ -126,6 +126,86 @@ __global__ void spx_pack_head_kernel(const spx_plan pl, const float* __restrict_
     }
 }
 
+// Grouping-head tail  logits = W_g . exp(units)  (model_multiscale_group.py:303-308): W_g [K2, U] as
+//   tail   [cb][s2][hi|lo][lane][8]   A = W_g rows (classes), k = the units of accumulator tile cb in the permuted
+//                                    order an accumulator tile presents as B operand (forward)
+//   tailT  [ub][c][hi|lo][lane][8]    A = W_g^T rows (units of block ub), k = classes 16 c + 8 h + j (backward)
+// and the head^T fragments with the UNIT (k) index in accumulator order, for the backward whose dUnits operand is
+// built from accumulator tiles instead of being loaded from memory:
+//   headT_units [panel][pb][cstep][hi|lo][lane][8]
+__global__ void spx_pack_tail_kernel(const spx_plan pl, const float* __restrict__ Wg, int K2, __bf16* __restrict__ pt,
+                                     __bf16* __restrict__ ptT) {
+    const int U = pl.num_classes;                    // head rows = group units
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = pl.ncb * 2 * 64;
+    if (gid >= n) return;
+    const int lane = gid & 63, s2 = (gid >> 6) & 1, cb = gid >> 7;
+    bf16x8 hi, lo;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int cls = lane & 31, u = cb * 32 + perm_row(s2, lane >> 5, j);
+        const float f = (cls < K2 && u < U) ? Wg[(size_t)cls * U + u] : 0.0f;
+        __bf16 a, c;
+        split_bf16(f, a, c);
+        hi[j] = a;
+        lo[j] = c;
+    }
+    *(bf16x8*)(pt + ((size_t)(gid >> 6) * 2) * 512 + (size_t)lane * 8) = hi;
+    *(bf16x8*)(pt + ((size_t)(gid >> 6) * 2 + 1) * 512 + (size_t)lane * 8) = lo;
+    if (ptT) {
+        const int c = s2, ub = cb;                   // same index space: (ub, c) pairs
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int cls = c * 16 + 8 * (lane >> 5) + j, u = ub * 32 + (lane & 31);
+            const float f = (cls < K2 && u < U) ? Wg[(size_t)cls * U + u] : 0.0f;
+            __bf16 a, d;
+            split_bf16(f, a, d);
+            hi[j] = a;
+            lo[j] = d;
+        }
+        *(bf16x8*)(ptT + ((size_t)(gid >> 6) * 2) * 512 + (size_t)lane * 8) = hi;
+        *(bf16x8*)(ptT + ((size_t)(gid >> 6) * 2 + 1) * 512 + (size_t)lane * 8) = lo;
+    }
+}
+
+__global__ void spx_pack_headT_units_kernel(const spx_plan pl, const float* __restrict__ W, __bf16* __restrict__ phT) {
+    const int P = pl.num_prototypes, K = pl.num_classes;
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n_t = pl.npanels * pl.npb * (pl.ncb * 2) * 64;
+    if (gid >= n_t) return;
+    int t = gid;
+    const int lane = t & 63; t >>= 6;
+    const int cstep = t % (pl.ncb * 2); t /= (pl.ncb * 2);
+    const int pb = t % pl.npb; t /= pl.npb;
+    const int panel = t;
+    const int row = pb * 32 + (lane & 31);
+    bf16x8 hi, lo;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int cls = (cstep >> 1) * 32 + perm_row(cstep & 1, lane >> 5, j);
+        float f = 0.0f;
+        if (cls < K && row < pl.panel_np[panel]) f = W[(size_t)cls * P + pl.panel_p0[panel] + row];
+        __bf16 a, c;
+        split_bf16(f, a, c);
+        hi[j] = a;
+        lo[j] = c;
+    }
+    const size_t base = ((size_t)(gid >> 6) * 2) * 512 + (size_t)lane * 8;
+    *(bf16x8*)(phT + base) = hi;
+    *(bf16x8*)(phT + base + 512) = lo;
+}
+
+hipError_t spx_launch_pack_tail(const spx_plan& pl, const float* Wg, int K2, void* pt, void* ptT, hipStream_t s) {
+    const int n = pl.ncb * 2 * 64;
+    hipLaunchKernelGGL(spx_pack_tail_kernel, dim3((n + 255) / 256), dim3(256), 0, s, pl, Wg, K2, (__bf16*)pt, (__bf16*)ptT);
+    return hipGetLastError();
+}
+hipError_t spx_launch_pack_headT_units(const spx_plan& pl, const float* W, void* phT, hipStream_t s) {
+    const int n = pl.npanels * pl.npb * (pl.ncb * 2) * 64;
+    hipLaunchKernelGGL(spx_pack_headT_units_kernel, dim3((n + 255) / 256), dim3(256), 0, s, pl, W, (__bf16*)phT);
+    return hipGetLastError();
+}
+
 hipError_t spx_launch_pack_bank(const spx_plan& pl, const float* bank, void* pb, void* pbT, float* p2, hipStream_t s) {
     const int Cs = pl.channels_per_scale, nchb = (Cs + 31) / 32;
     int n = pl.npanels * pl.npb * 32 * (((Cs + 31) / 32) * 32) / 8;

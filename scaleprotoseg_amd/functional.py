@@ -141,7 +141,8 @@ def _check_x(x: torch.Tensor, layout: BankLayout) -> Tuple[int, int]:
 class _Packs:
     """Device buffers holding the MFMA-ordered operands of one forward."""
 
-    def __init__(self, plan: SpxPlan, bank2d: torch.Tensor, head: Optional[torch.Tensor], need_bwd: bool):
+    def __init__(self, plan: SpxPlan, bank2d: torch.Tensor, head: Optional[torch.Tensor], need_bwd: bool,
+                 tail: Optional[torch.Tensor] = None):
         lib = _lib.load()
         dev = bank2d.device
         pp = C.byref(plan)
@@ -156,11 +157,19 @@ class _Packs:
             self.head = torch.empty(lib.spx_packed_head_bytes(pp), **u8)
             self.headT = torch.empty(lib.spx_packed_headT_bytes(pp), **u8) if need_bwd else None
             _lib.check(lib.spx_pack_head(pp, _lib.ptr(head), _lib.ptr(self.head), _lib.ptr(self.headT), s))
+        self.tail = self.tailT = None
+        if tail is not None:
+            # grouping-head tail: W_g fragments; the backward takes head^T with the unit index in accumulator order
+            self.tail = torch.empty(lib.spx_packed_tail_bytes(pp), **u8)
+            self.tailT = torch.empty(lib.spx_packed_tail_bytes(pp), **u8) if need_bwd else None
+            _lib.check(lib.spx_pack_group_tail(pp, _lib.ptr(tail), int(tail.shape[0]), _lib.ptr(self.tail), _lib.ptr(self.tailT), s))
+            if need_bwd:
+                _lib.check(lib.spx_pack_headT_units(pp, _lib.ptr(head), _lib.ptr(self.headT), s))
 
 
 class _ProtoHeadFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, bank, head, layout, want_dist, want_act, epsilon, act_fn, gather=None):
+    def forward(ctx, x, bank, head, layout, want_dist, want_act, epsilon, act_fn, gather=None, tail=None):
         lib = _lib.load()
         B, HW = _check_x(x, layout)
         P, K = layout.num_prototypes, layout.num_classes
@@ -171,12 +180,32 @@ class _ProtoHeadFn(torch.autograd.Function):
         if head2d is not None and tuple(head2d.shape) != (K, P):
             raise SpxError(f"head matrix must be [{K}, {P}], got {tuple(head2d.shape)}")
         plan = layout.plan()
-        need_bwd = any(t is not None and t.requires_grad for t in (x, bank, head))
-        packs = _Packs(plan, bank2d, head2d, need_bwd)
+        need_bwd = any(t is not None and t.requires_grad for t in (x, bank, head, tail))
+        tail2d = tail.detach().contiguous().float() if tail is not None else None
+        if tail2d is not None:
+            if head2d is None or gather is not None:
+                raise SpxError("the fused group tail needs the dense head and no class gather")
+            if tail2d.dim() != 2 or tail2d.shape[1] != K or tail2d.shape[0] > 32:
+                raise SpxError(f"group tail must be [K2 <= 32, {K}], got {tuple(tail2d.shape)}")
+        packs = _Packs(plan, bank2d, head2d, need_bwd, tail2d)
         f32 = dict(dtype=torch.float32, device=x.device)
         act = torch.empty((B * HW, P), **f32) if want_act else None
         logits = torch.empty((B * HW, K), **f32) if head is not None else None
-        if gather is not None:
+        gact = None
+        if tail2d is not None:
+            K2 = int(tail2d.shape[0])
+            logits = torch.empty((B * HW, K2), **f32)
+            gact = torch.empty((B * HW, K), **f32)
+            dist = torch.empty((B, P) + tuple(x.shape[2:]), **f32) if want_dist else None
+            with _timed("spx_dist_fwd"):
+                _lib.check(
+                    lib.spx_dist_fwd_group(
+                        C.byref(plan), _lib.ptr(x), xd, B, HW, _lib.ptr(packs.bank), _lib.ptr(packs.p2),
+                        _lib.ptr(packs.head), _lib.ptr(packs.tail), K2, _lib.ptr(dist), _lib.ptr(act),
+                        _lib.ptr(gact), _lib.ptr(logits), float(epsilon), ACT_FN[act_fn], _lib.stream_ptr(),
+                    )
+                )
+        elif gather is not None:
             if tuple(gather.labels.shape) != (B, HW) or gather.labels.dtype != torch.int32:
                 raise SpxError(f"gather labels must be int32 [{B}, {HW}]")
             # slots no prototype maps to (and pixels without a class) stay 0
@@ -201,17 +230,20 @@ class _ProtoHeadFn(torch.autograd.Function):
                     )
                 )
         ctx.gather = gather
+        ctx.gact = gact
+        ctx.tail2d = tail2d
         ctx.layout, ctx.plan, ctx.packs = layout, plan, packs
         ctx.epsilon, ctx.act_fn = float(epsilon), act_fn
         ctx.have = (logits is not None, dist is not None, act is not None)
         ctx.save_for_backward(x, bank2d, head2d)
         ctx.bank_shape = tuple(bank.shape)
         outs = tuple(t if t is not None else x.new_empty(0) for t in (logits, dist, act))
-        ctx.mark_non_differentiable(*[o for o, h in zip(outs, ctx.have) if not h])
-        return outs
+        extra = gact if tail2d is not None else x.new_empty(0)     # exp(units): an output for the caller, no gradient path
+        ctx.mark_non_differentiable(*([o for o, h in zip(outs, ctx.have) if not h] + [extra]))
+        return outs + (extra,)
 
     @staticmethod
-    def backward(ctx, g_logits, g_dist, g_act):
+    def backward(ctx, g_logits, g_dist, g_act, _g_gact=None):
         lib = _lib.load()
         x, bank2d, head2d = ctx.saved_tensors
         layout, plan, packs = ctx.layout, ctx.plan, ctx.packs
@@ -233,8 +265,27 @@ class _ProtoHeadFn(torch.autograd.Function):
         g_scr = torch.empty(scr, dtype=torch.uint8, device=dev) if need_bank else None
         a_scr = torch.empty(scr, dtype=torch.uint8, device=dev) if need_head else None
         s = _lib.stream_ptr()
+        tail2d, d_units, d_tail = ctx.tail2d, None, None
+        if tail2d is not None and gl is not None:
+            d_units = torch.empty((B * HW, K), dtype=torch.float32, device=dev)
+            with _timed("spx_dist_bwd"):
+                _lib.check(
+                    lib.spx_dist_bwd_group(
+                        pp, _lib.ptr(x), xd, B, HW, _lib.ptr(packs.bank), _lib.ptr(packs.bankT), _lib.ptr(packs.p2),
+                        _lib.ptr(packs.headT), _lib.ptr(packs.tailT), int(tail2d.shape[0]), _lib.ptr(ctx.gact),
+                        _lib.ptr(gd), _lib.ptr(ga), _lib.ptr(gl), _lib.ptr(d_units), _lib.ptr(dx), _lib.ptr(g_scr),
+                        _lib.ptr(a_scr), ctx.epsilon, ACT_FN[ctx.act_fn], s,
+                    )
+                )
+            if ctx.needs_input_grad[9]:
+                d_tail = gl.t() @ ctx.gact            # d W_g [K2, U]: one small product over the pixels
+            gl = d_units                              # the parameter kernel's d_logits operand
+        elif tail2d is not None:
+            raise SpxError("backward through the fused group tail without a logits gradient")
         with _timed("spx_dist_bwd"):
-            if ctx.gather is not None:
+            if tail2d is not None:
+                pass
+            elif ctx.gather is not None:
                 g = ctx.gather
                 _lib.check(
                     lib.spx_dist_bwd_cls(
@@ -270,7 +321,9 @@ class _ProtoHeadFn(torch.autograd.Function):
             d_head = torch.zeros_like(head2d)
         if ctx.needs_input_grad[2] and d_head is None and head2d is not None:
             d_head = torch.zeros_like(head2d)
-        return dx, d_bank, d_head, None, None, None, None, None, None
+        if tail2d is not None and ctx.needs_input_grad[9] and d_tail is None:
+            d_tail = torch.zeros_like(tail2d)
+        return dx, d_bank, d_head, None, None, None, None, None, None, d_tail
 
 
 def proto_head_forward(
@@ -284,6 +337,7 @@ def proto_head_forward(
     epsilon: float = 1e-4,
     activation: str = "log",
     class_gather: Optional[ClassGather] = None,
+    group_tail: Optional[torch.Tensor] = None,
 ):
     """(logits [B*H*W, K] | None, distances [B,P,H,W] | None, activations [B*H*W, P] | None).
 
@@ -293,9 +347,14 @@ def proto_head_forward(
         raise SpxError(f"activation {activation!r} has no fused kernel (use 'log' or 'linear')")
     if not x.is_cuda:
         raise SpxError("scaleprotoseg_amd runs on an AMD GPU only; there is no CPU fallback")
-    logits, dist, act = _ProtoHeadFn.apply(
-        x, bank, head, layout, want_distances or class_gather is not None, want_activations, epsilon, activation, class_gather
+    logits, dist, act, gact = _ProtoHeadFn.apply(
+        x, bank, head, layout, want_distances or class_gather is not None, want_activations, epsilon, activation,
+        class_gather, group_tail,
     )
+    if group_tail is not None:
+        # fused grouping head (model_multiscale_group.py:283-308): logits = exp(act . head^T) . group_tail^T;
+        # the 4th entry is exp(act . head^T) [B*H*W, U] (cat of compute_group's list), not differentiable here
+        return logits, (dist if want_distances else None), (act if want_activations else None), gact
     return (
         logits if head is not None else None,
         dist if (want_distances or class_gather is not None) else None,

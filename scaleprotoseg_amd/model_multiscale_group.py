@@ -6,8 +6,9 @@ Mirrors segmentation/model/model_multiscale_group.py:82-519: same constructor, `
 
 Fused form of the grouping head: every class's projection is a row block of ONE dense [G*K', P] matrix
 (zeros outside the class's prototype columns), so ``cat_k(act[:, idx_k] @ W_k^T)`` is the kernel's head
-contraction act @ Wd^T; ``exp`` and the small ``last_layer_group`` product follow on the GPU.  The
-reference instead gathers per class with a host sync per class per forward (:297-301).
+contraction act @ Wd^T; ``exp`` and the ``last_layer_group`` product follow inside the same kernel (a second
+split-bf16 MFMA on the unit tiles), and the backward forms dUnits in registers.  The reference instead gathers per
+class with a host sync per class per forward (:297-301).
 """
 from __future__ import annotations
 
@@ -137,12 +138,22 @@ class PPNetMultiScaleGroup(_PrototypeBankMixin, nn.Module):
         B, _, H, W = conv_features.shape
         wd = self._dense_group_matrix()
         want_dist = return_distances or not return_activations
-        gpre, dist, act = proto_head_forward(
-            conv_features, self.prototype_vectors, wd, self._layout(wd.shape[0]),
-            want_distances=want_dist, want_activations=return_activations, epsilon=self.epsilon,
-            activation=self.prototype_activation_function,
-        )
-        logits = F.linear(torch.exp(gpre), self.last_layer_group.weight).reshape(B, H, W, -1)
+        wg = self.last_layer_group.weight
+        if wg.shape[0] <= 32:
+            # whole grouping head in the kernel: units = act . Wd^T, exp, last_layer_group (:303-308)
+            logits, dist, act, _ = proto_head_forward(
+                conv_features, self.prototype_vectors, wd, self._layout(wd.shape[0]),
+                want_distances=want_dist, want_activations=return_activations, epsilon=self.epsilon,
+                activation=self.prototype_activation_function, group_tail=wg,
+            )
+            logits = logits.reshape(B, H, W, -1)
+        else:   # more than 32 classes: the tail runs as two torch GPU ops
+            gpre, dist, act = proto_head_forward(
+                conv_features, self.prototype_vectors, wd, self._layout(wd.shape[0]),
+                want_distances=want_dist, want_activations=return_activations, epsilon=self.epsilon,
+                activation=self.prototype_activation_function,
+            )
+            logits = F.linear(torch.exp(gpre), wg).reshape(B, H, W, -1)
         if return_activations and not return_distances:
             return logits, act
         if return_activations and return_distances:

@@ -470,3 +470,63 @@ def test_argument_errors():
     # model_multiscale.py:146-149): its forward raises at F.linear, the plan is rejected here
     with pytest.raises(spx.SpxError):
         _layout(190, 19, 3, 16, {0: (0, 63), 1: (63, 126), 2: (126, 189)}).plan()
+
+
+@pytest.mark.parametrize("shape", [(2, 4, 64, 228, 19, 9, 13, 3), (1, 1, 64, 210, 21, 8, 16, 3), (1, 4, 16, 40, 5, 9, 11, 3)])
+@pytest.mark.parametrize("x_dtype", [torch.float32, torch.bfloat16])
+def test_fused_group_tail(shape, x_dtype):
+    """Grouping head with exp + last_layer_group inside the kernels (spx_dist_fwd_group / spx_dist_bwd_group) against
+    the oracle's compute_group + last_layer_group (model_multiscale_group.py:283-308) and its autograd."""
+    from scaleprotoseg_amd.functional import proto_head_forward
+
+    dev = _dev()
+    B, S, Cs, P, K, H, W, G = shape
+    conv, bank, _, ident, ranges = _problem(B, S, Cs, P, K, H, W, seed=31)
+    g = torch.Generator().manual_seed(17)
+    idx = O.class_prototype_index(ident)
+    idx = [i for i in idx if len(i) > 0]
+    gw = [O.projection_simplex_sort(torch.rand(G, len(i), generator=g)) for i in idx]        # rows on the simplex
+    gci = O.group_class_identity(ident, G)
+    wg = (gci.t() - 0.5 * (1 - gci.t())) + 0.05 * torch.randn(gci.shape[1], gci.shape[0], generator=g)   # [K, G*K']
+    U = G * len(idx)
+    g_logits = torch.randn(B, H, W, K, generator=g) * 1e-3
+    g_dist = torch.randn(B, P, H, W, generator=g) * 1e-3
+
+    # oracle
+    c0 = conv.clone().requires_grad_(True)
+    p0 = bank.clone().requires_grad_(True)
+    gw0 = [w.clone().requires_grad_(True) for w in gw]
+    wg0 = wg.clone().requires_grad_(True)
+    d_ref = O.scale_l2_convolution(c0, p0, ranges, S)
+    act_ref = O.distance_2_similarity(d_ref).permute(0, 2, 3, 1).reshape(-1, P)
+    units = torch.cat(O.compute_group(act_ref, ident, gw0), dim=-1)                           # exp(...) list -> [M, U]
+    l_ref = torch.nn.functional.linear(units, wg0)
+    ((l_ref * g_logits.reshape(-1, K)).sum() + (d_ref * g_dist).sum()).backward()
+
+    # dense head [U, P] (zeros outside each class's prototype columns), as the module builds it
+    wd = torch.zeros(U, P)
+    for k, i in enumerate(idx):
+        wd[k * G:(k + 1) * G, i] = gw[k]
+    x = conv.to(dev, x_dtype).requires_grad_(True)
+    pv = bank.to(dev).requires_grad_(True)
+    wdd = wd.to(dev).requires_grad_(True)
+    wgd = wg.to(dev).requires_grad_(True)
+    logits, dist, _, gact = proto_head_forward(x, pv, wdd, _layout(P, U, S, Cs, ranges), group_tail=wgd)
+    torch.cuda.synchronize()
+    rl = l_ref.detach()
+    err = (logits.detach().cpu() - rl).abs().max().item()
+    assert err <= 1e-4 * max(1.0, rl.abs().max().item()), f"group logits err {err}"
+    ug = units.detach()
+    assert ((gact.cpu() - ug).abs() <= 2e-4 * (1 + ug.abs())).all(), "group activations"
+    ((logits * g_logits.reshape(-1, K).to(dev)).sum() + (dist * g_dist.to(dev)).sum()).backward()
+    torch.cuda.synchronize()
+    _grad_close(x.grad, c0.grad, "dX", tol=3e-3 if x_dtype == torch.float32 else 8e-3)
+    _grad_close(pv.grad, p0.grad, "dPrototypes")
+    _grad_close(wgd.grad, wg0.grad, "dLastLayerGroup", tol=2e-3)
+    dwd_ref = torch.zeros(U, P)
+    for k, i in enumerate(idx):
+        dwd_ref[k * G:(k + 1) * G, i] = gw0[k].grad
+    mask = torch.zeros(U, P, dtype=torch.bool)
+    for k, i in enumerate(idx):
+        mask[k * G:(k + 1) * G, i] = True
+    _grad_close(wdd.grad.cpu() * mask, dwd_ref, "dGroupProjection", tol=8e-3)
