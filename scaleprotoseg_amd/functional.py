@@ -138,6 +138,19 @@ def _check_x(x: torch.Tensor, layout: BankLayout) -> Tuple[int, int]:
     return B, H * W
 
 
+def _pixel_outer(a: torch.Tensor, b: torch.Tensor, chunk: int = 4096) -> torch.Tensor:
+    """a^T . b for tall-skinny [M, n] operands (M = pixels, n <= a few dozen): chunked batched product + one sum.
+    The plain ``a.t() @ b`` is a single-workgroup-shaped GEMM (2.9 ms for 2 Mpx x 19 x 57 on MI355X vs 0.13 ms)."""
+    M = a.shape[0]
+    n = M // chunk
+    out = torch.zeros((a.shape[1], b.shape[1]), dtype=torch.float32, device=a.device)
+    if n:
+        out = out + torch.bmm(a[: n * chunk].view(n, chunk, -1).transpose(1, 2), b[: n * chunk].view(n, chunk, -1)).sum(0)
+    if M % chunk:
+        out = out + a[n * chunk :].t() @ b[n * chunk :]
+    return out
+
+
 class _Packs:
     """Device buffers holding the MFMA-ordered operands of one forward."""
 
@@ -278,7 +291,7 @@ class _ProtoHeadFn(torch.autograd.Function):
                     )
                 )
             if ctx.needs_input_grad[9]:
-                d_tail = gl.t() @ ctx.gact            # d W_g [K2, U]: one small product over the pixels
+                d_tail = _pixel_outer(gl, ctx.gact)   # d W_g [K2, U]: one small product over the pixels
             gl = d_units                              # the parameter kernel's d_logits operand
         elif tail2d is not None:
             raise SpxError("backward through the fused group tail without a logits gradient")
