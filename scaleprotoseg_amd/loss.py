@@ -53,6 +53,34 @@ def gather_class_distances(prototype_distances: torch.Tensor, labels0: torch.Ten
     return torch.where(valid, out, torch.zeros_like(out))
 
 
+def _pixel_outer(a: torch.Tensor, b: torch.Tensor, chunk: int = 4096) -> torch.Tensor:
+    """a^T . b for tall-skinny [M, n] operands (M = pixels): chunked batched product + one sum (a plain
+    ``a.t() @ b`` runs as a single-workgroup-shaped GEMM on the GPU)."""
+    M = a.shape[0]
+    n = M // chunk
+    out = torch.zeros((a.shape[1], b.shape[1]), dtype=a.dtype, device=a.device)
+    if n:
+        out = out + torch.bmm(a[: n * chunk].reshape(n, chunk, -1).transpose(1, 2), b[: n * chunk].reshape(n, chunk, -1)).sum(0)
+    if M % chunk:
+        out = out + a[n * chunk :].t() @ b[n * chunk :]
+    return out
+
+
+class _SegmentGather(torch.autograd.Function):
+    """rows[seg] whose backward is a segment sum (index_add) instead of autograd's index_put on duplicate indices."""
+
+    @staticmethod
+    def forward(ctx, rows, seg):
+        ctx.save_for_backward(seg)
+        ctx.n = rows.shape[0]
+        return rows[seg]
+
+    @staticmethod
+    def backward(ctx, g):
+        (seg,) = ctx.saved_tensors
+        return torch.zeros((ctx.n, g.shape[1]), device=g.device, dtype=g.dtype).index_add_(0, seg, g), None
+
+
 class KLDLoss(nn.Module):
     """Drop-in for segmentation/model/loss.py:51-146: same constructor, same ``forward(prototype_distances,
     target_labels)`` (labels 0 = void, 1..K = class); ``prototype_distances`` may be the [B, P, H, W] map or a
@@ -91,29 +119,41 @@ class KLDLoss(nn.Module):
         B = vals.shape[0]
         lab = labels0.to(dev)
         ok = ((lab >= 0) & (lab < K)).reshape(-1)
-        seg_all = (torch.arange(B, device=dev).unsqueeze(1) * K + lab.clamp(0, K - 1)).reshape(-1)
-        sel = torch.nonzero(ok).flatten()
-        if sel.numel() == 0:
+        if not bool(ok.any()):
             return torch.tensor(0.0)
-        seg = seg_all[sel]                                               # (image, class) segment of each pixel
-        d = vals.reshape(-1, J)[sel]                                     # [N, J]
         nseg = B * K
-        count = torch.zeros(nseg, device=dev).index_add_(0, seg, torch.ones_like(seg, dtype=torch.float32))
-        # log_softmax over the segment's pixels, per slot (loss.py:110)
-        m = torch.full((nseg, J), float("-inf"), device=dev, dtype=d.dtype)
-        m = m.scatter_reduce(0, seg.unsqueeze(1).expand(-1, J), d.detach(), reduce="amax", include_self=True)
-        m = torch.where(torch.isfinite(m), m, torch.zeros_like(m))
-        ssum = torch.zeros((nseg, J), device=dev, dtype=d.dtype).index_add_(0, seg, torch.exp(d - m[seg]))
-        lse = m + torch.log(ssum.clamp_min(1e-38))
-        logp = d - lse[seg]
+        # (image, class) segment of every pixel; pixels without a class go to a dummy segment that is dropped below
+        seg = (torch.arange(B, device=dev).unsqueeze(1) * K + lab.clamp(0, K - 1)).reshape(-1)
+        seg = torch.where(ok, seg, torch.full_like(seg, nseg))
+        d = vals.reshape(-1, J)                                          # [N, J], every pixel
+        count = torch.bincount(seg, minlength=nseg + 1)[:nseg]
+        # log_softmax over the segment's pixels, per slot (loss.py:110).  The shift is the slot's GLOBAL maximum and the
+        # sums run in fp64 (distances are bounded by the channel count, far inside exp's fp64 range), so no per-segment
+        # maximum - an atomics-bound scatter - is needed.
+        gm = d.detach().amax(dim=0)
+        e = torch.exp((d - gm).double())
+        ssum = torch.zeros((nseg + 1, J), device=dev, dtype=torch.float64)
+        cstep = max(4096, ((1 << 24) // (nseg + 1)) // 4096 * 4096)
+        for i in range(0, d.shape[0], cstep):        # segment sums as one-hot products (fp64 atomics are slow)
+            oh = torch.nn.functional.one_hot(seg[i:i + cstep], nseg + 1).to(torch.float64)
+            ssum = ssum + _pixel_outer(oh, e[i:i + cstep])
+        lse = (gm.double() + torch.log(ssum.clamp_min(1e-300))).to(d.dtype)
+        logp = d - _SegmentGather.apply(lse, seg)
         p = torch.exp(logp)
-        # symmetric KL of every slot pair: 0.5 * sum_px (p_j - p_k)(logp_j - logp_k)   (loss.py:129-136)
-        kld = torch.zeros((nseg, J, J), device=dev, dtype=d.dtype)
-        step = max(1, (1 << 22) // (J * J))
+        # symmetric KL of every slot pair (loss.py:129-136): 0.5 * sum_px (p_j - p_k)(logp_j - logp_k)
+        #   = 0.5 * (A_jj + A_kk - A_jk - A_kj),  A[seg] = P_seg^T . L_seg  ([J, J] per (image, class) segment).
+        # A is ONE tall-skinny product per pixel chunk: rows of Z = p scattered into the pixel's segment block.
+        ns1 = nseg + 1
+        A = torch.zeros((ns1 * J, J), device=dev, dtype=d.dtype)
+        step = max(4096, ((1 << 26) // max(1, ns1 * J)) // 4096 * 4096)
         for i in range(0, d.shape[0], step):
             lp, pp, sg = logp[i:i + step], p[i:i + step], seg[i:i + step]
-            term = 0.5 * (pp.unsqueeze(2) - pp.unsqueeze(1)) * (lp.unsqueeze(2) - lp.unsqueeze(1))
-            kld = kld.index_add(0, sg, term)
+            z = torch.zeros((pp.shape[0], ns1, J), device=dev, dtype=d.dtype)
+            z = z.scatter(1, sg.view(-1, 1, 1).expand(-1, 1, J), pp.unsqueeze(1))
+            A = A + _pixel_outer(z.view(pp.shape[0], ns1 * J), lp)
+        A = A.view(ns1, J, J)[:nseg]
+        diag = torch.diagonal(A, dim1=1, dim2=2)
+        kld = 0.5 * (diag.unsqueeze(2) + diag.unsqueeze(1) - A - A.transpose(1, 2))
         pair_ok = self._pair_mask(table).to(dev)                                    # [K, J, J]
         seg_cls = torch.arange(nseg, device=dev) % K
         valid = pair_ok[seg_cls] & (count >= 2).reshape(-1, 1, 1)                   # loss.py:113-127 (len < 2 skipped)

@@ -1,0 +1,27 @@
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+import scaleprotoseg_amd as spx
+from oracle import ppnet_oracle as O
+dev = torch.device("cuda:0")
+P, K, S, H, W = 190, 19, 1, 1024, 2048
+ident = O.default_class_identity(P, K, S)
+lay = spx.BankLayout(P, K, S, 256, ((0, P),))
+keys, J, table = spx.class_gather_table(lay, ident, dev)
+patches = torch.randint(0, K + 1, (1, H // 64, W // 64), device=dev)
+target = patches.repeat_interleave(64, 1).repeat_interleave(64, 2)
+vals = (torch.rand(1, J, H * W, device=dev) * 6).requires_grad_(True)
+cd = spx.ClassDistances(vals, (target.reshape(1, -1) - 1).int(), table, (H, W))
+loss_fn = spx.KLDLoss(ident, S, {0: (0, P)})
+def step():
+    vals.grad = None
+    l = loss_fn(cd, target)
+    l.backward()
+    return l
+for _ in range(2): step()
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(3): l = step()
+e1.record(); torch.cuda.synchronize()
+print(f"KLDLoss fwd+bwd on gathered [1,{J},{H*W}]: {e0.elapsed_time(e1)/3:.2f} ms, loss {l.item():.5f}, peak mem {torch.cuda.max_memory_allocated()/1e9:.2f} GB")
