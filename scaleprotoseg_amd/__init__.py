@@ -20,6 +20,7 @@ from .functional import (  # noqa: F401
     proto_head_forward,
     push_masked_argmin,
 )
+from .checkpoint import export_state, import_state, load_reference_state_dict  # noqa: F401
 from .loss import ClassDistances, KLDLoss  # noqa: F401
 from .model import PPNet  # noqa: F401
 from .model_multiscale import PPNetMultiScale, construct_PPNet  # noqa: F401
