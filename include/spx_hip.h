@@ -177,6 +177,14 @@ int spx_push_argmin(const float* distances, const int32_t* labels, const float* 
  * push_multiscale_optimization.py:135-137.  values fp32 [N, P] -> best int64 [P]. */
 int spx_argmin_images(const float* values, int32_t N, int32_t P, int64_t* best, void* stream);
 
+/* Evaluation maps: F.interpolate(src, size=(H, W), mode="bilinear", align_corners=False) followed
+ * by argmin (take_max = 0) or argmax (take_max = 1) over the channel dimension, without materialising the
+ * upsampled [N, C, H, W] tensor (segmentation/eval_valid_multiscale.py:229-234, :375-383: nearest prototype per
+ * full-resolution pixel from the distance map, predicted class from the logits).  src fp32 [N, C, h, w];
+ * indices int64 [N, H, W] (lowest channel on ties); values fp32 [N, H, W] (the extremum; may be NULL). */
+int spx_upsample_argext(const float* src, int32_t N, int32_t C, int32_t h, int32_t w, int32_t H, int32_t W,
+                        int32_t take_max, int64_t* indices, float* values, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

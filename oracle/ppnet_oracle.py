@@ -343,6 +343,17 @@ def gather_class_distances(prototype_distances: torch.Tensor, labels0: torch.Ten
 
 
 # --------------------------------------------------------------------------- #
+# evaluation maps
+# --------------------------------------------------------------------------- #
+def upsample_argext(src: torch.Tensor, size: Tuple[int, int], largest: bool = False) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """segmentation/eval_valid_multiscale.py:229-234: F.interpolate(bilinear, align_corners=False) then argmin /
+    argmax over the channels.  Returns (indices, extremum, upsampled tensor)."""
+    up = F.interpolate(src, size=size, mode="bilinear", align_corners=False)
+    val, idx = (up.max(dim=1) if largest else up.min(dim=1))
+    return idx, val, up
+
+
+# --------------------------------------------------------------------------- #
 # helpers used by tests / bench
 # --------------------------------------------------------------------------- #
 def bf16_representable(t: torch.Tensor) -> torch.Tensor:

@@ -19,6 +19,7 @@ from .functional import (  # noqa: F401
     class_gather_table,
     proto_head_forward,
     push_masked_argmin,
+    upsample_argext,
 )
 from .checkpoint import export_state, import_state, load_reference_state_dict  # noqa: F401
 from .loss import ClassDistances, KLDLoss  # noqa: F401

@@ -69,6 +69,7 @@ SIGNATURES = {
     "spx_bank_bwd": (C.c_int, [_PP, _V, _I, _I, _I, _V, _V, _V, _V, _V, _V, _V, _V]),
     "spx_push_argmin": (C.c_int, [_V, _V, _V, _I, _I, _I, _I, _I, _F, _V, _V, _V, _V]),
     "spx_argmin_images": (C.c_int, [_V, _I, _I, _V, _V]),
+    "spx_upsample_argext": (C.c_int, [_V, _I, _I, _I, _I, _I, _I, _I, _V, _V, _V]),
 }
 
 _lib: Optional[C.CDLL] = None

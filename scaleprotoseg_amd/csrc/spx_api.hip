@@ -330,4 +330,13 @@ int spx_argmin_images(const float* values, int32_t N, int32_t P, int64_t* best, 
     return hip_status(spx_launch_argmin_images(values, N, P, best, (hipStream_t)stream), "spx_argmin_images");
 }
 
+int spx_upsample_argext(const float* src, int32_t N, int32_t C, int32_t h, int32_t w, int32_t H, int32_t W,
+                        int32_t take_max, int64_t* indices, float* values, void* stream) {
+    if (!src || !indices) return fail("spx_upsample_argext: NULL buffer");
+    if (N < 1 || C < 1 || h < 1 || w < 1 || H < 1 || W < 1) return fail("spx_upsample_argext: empty input");
+    if ((long long)h * w >= (1LL << 31) || (long long)N > 65535) return fail("spx_upsample_argext: map too large");
+    return hip_status(spx_launch_upsample_argext(src, N, C, h, w, H, W, take_max ? 1 : 0, indices, values,
+                                                 (hipStream_t)stream), "spx_upsample_argext");
+}
+
 }  // extern "C"

@@ -79,4 +79,5 @@ hipError_t spx_launch_push_argmin(const float* dist, const int32_t* labels, cons
                                   int HW, int void_class, float max_dist, int64_t* idx, float* val,
                                   uint64_t* scratch, hipStream_t s);
 hipError_t spx_launch_argmin_images(const float* values, int N, int P, int64_t* best, hipStream_t s);
-
+hipError_t spx_launch_upsample_argext(const float* src, int N, int C, int h, int w, int H, int W, int take_max,
+                                      int64_t* idx, float* val, hipStream_t s);

@@ -414,3 +414,19 @@ def argmin_over_images(values: torch.Tensor) -> torch.Tensor:
     best = torch.empty((P,), dtype=torch.int64, device=v.device)
     _lib.check(lib.spx_argmin_images(_lib.ptr(v), N, P, _lib.ptr(best), _lib.stream_ptr()))
     return best
+
+
+def upsample_argext(src: torch.Tensor, size: Tuple[int, int], largest: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(indices int64 [N,H,W], values f32 [N,H,W]) of ``F.interpolate(src, size, mode="bilinear",
+    align_corners=False)`` reduced with argmin (``largest=False``) / argmax over the channels, fused: the upsampled
+    [N,C,H,W] tensor is never materialised (segmentation/eval_valid_multiscale.py:229-234, :375-383)."""
+    lib = _lib.load()
+    if src.dim() != 4:
+        raise SpxError("src must be [N, C, h, w]")
+    s = src.detach().contiguous().float()
+    N, Cc, h, w = s.shape
+    H, W = int(size[0]), int(size[1])
+    idx = torch.empty((N, H, W), dtype=torch.int64, device=s.device)
+    val = torch.empty((N, H, W), dtype=torch.float32, device=s.device)
+    _lib.check(lib.spx_upsample_argext(_lib.ptr(s), N, Cc, h, w, H, W, 1 if largest else 0, _lib.ptr(idx), _lib.ptr(val), _lib.stream_ptr()))
+    return idx, val

@@ -530,3 +530,29 @@ def test_fused_group_tail(shape, x_dtype):
     for k, i in enumerate(idx):
         mask[k * G:(k + 1) * G, i] = True
     _grad_close(wdd.grad.cpu() * mask, dwd_ref, "dGroupProjection", tol=8e-3)
+
+
+@pytest.mark.parametrize("case", [(1, 228, 17, 33, 129, 257, False), (2, 19, 9, 11, 70, 90, True), (1, 5, 4, 5, 4, 5, False),
+                                  (1, 40, 33, 65, 17, 20, False)])
+def test_upsample_argext(case):
+    """Fused bilinear upsample + argmin/argmax against torch's interpolate + reduction on the CPU:
+    the extremum within 1e-5 relative; the index equal wherever the runner-up is not within that tolerance; and the
+    index always points at a channel whose upsampled value is the extremum within tolerance."""
+    from scaleprotoseg_amd.functional import upsample_argext
+
+    dev = _dev()
+    N, C, h, w, H, W, largest = case
+    g = torch.Generator().manual_seed(77)
+    src = torch.rand(N, C, h, w, generator=g) * 10
+    idx_ref, val_ref, up = O.upsample_argext(src, (H, W), largest)
+    idx, val = upsample_argext(src.to(dev), (H, W), largest)
+    torch.cuda.synchronize()
+    idx, val = idx.cpu(), val.cpu()
+    tol = 1e-5 * (1 + val_ref.abs())
+    assert ((val - val_ref).abs() <= tol).all(), (val - val_ref).abs().max().item()
+    picked = torch.gather(up, 1, idx.unsqueeze(1)).squeeze(1)
+    assert ((picked - val_ref).abs() <= 2 * tol).all()
+    srt = torch.sort(up, dim=1, descending=largest).values
+    clear = (srt[:, 1] - srt[:, 0]).abs() > 4 * tol if C > 1 else torch.ones_like(val_ref, dtype=torch.bool)
+    assert torch.equal(idx[clear], idx_ref[clear])
+    assert clear.float().mean() > 0.99
