@@ -374,6 +374,18 @@ def case_kld(lossmod, ms, name):
         out[f"{tag}_S"] = np.int64(S)
         out[f"{tag}_loss"] = _np(loss)
         out[f"{tag}_grad"] = _np(d.grad)
+    # PixelWiseCrossEntropyLoss (loss.py:9-48): the training modules construct it with ignore_index=-1 so that void
+    # (label 0 -> -1 after the shift) is skipped
+    torch.manual_seed(SEED + 60)
+    lg = torch.randn(2, 6, 7, 5, requires_grad=True)
+    tg = torch.randint(0, 6, (2, 6, 7))
+    ce, correct = lossmod.PixelWiseCrossEntropyLoss(ignore_index=-1, return_correct=True)(predicted_logits=lg, target_labels=tg)
+    ce.backward()
+    out["ce_logits"] = _np(lg)
+    out["ce_target"] = tg.numpy().astype(np.int64)
+    out["ce_loss"] = _np(ce)
+    out["ce_grad"] = _np(lg.grad)
+    out["ce_correct"] = correct.numpy().astype(np.int64)
     # no valid term at all -> 0.0 (loss.py:143-144)
     net = _make_proto_phase(ms, P=8, Cs=16, S=1, K=4)
     t0 = torch.zeros(1, 3, 3, dtype=torch.long)

@@ -22,7 +22,7 @@ from .functional import (  # noqa: F401
     upsample_argext,
 )
 from .checkpoint import export_state, import_state, load_reference_state_dict  # noqa: F401
-from .loss import ClassDistances, KLDLoss  # noqa: F401
+from .loss import ClassDistances, KLDLoss, PixelWiseCrossEntropyLoss  # noqa: F401
 from .model import PPNet  # noqa: F401
 from .model_multiscale import PPNetMultiScale, construct_PPNet  # noqa: F401
 from .model_multiscale_group import PPNetMultiScaleGroup, construct_PPNet_Group  # noqa: F401

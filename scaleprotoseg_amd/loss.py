@@ -66,6 +66,29 @@ def _pixel_outer(a: torch.Tensor, b: torch.Tensor, chunk: int = 4096) -> torch.T
     return out
 
 
+class PixelWiseCrossEntropyLoss(nn.Module):
+    """Drop-in for segmentation/model/loss.py:9-48: cross entropy over the [..., K] logits with labels shifted by one
+    (1..K -> 0..K-1; the training modules pass ``ignore_index=-1`` so that void = 0 is skipped,
+    module_multiscale.py:162-164), optionally with the per-pixel correctness of the non-ignored pixels."""
+
+    def __init__(self, ignore_index: int = 255, return_correct: bool = False) -> None:
+        super().__init__()
+        self.loss = nn.CrossEntropyLoss(ignore_index=ignore_index)
+        self.return_correct = return_correct
+        self.ignore_index = ignore_index
+
+    def forward(self, predicted_logits: torch.Tensor, target_labels: torch.Tensor):
+        predicted_logits = predicted_logits.reshape(-1, predicted_logits.size(-1))
+        target_labels = target_labels.reshape(-1) - 1                                  # loss.py:32
+        loss = self.loss(predicted_logits, target_labels)
+        if not self.return_correct:
+            return loss
+        predicted_labels = torch.argmax(predicted_logits, dim=-1)
+        correct = predicted_labels == target_labels
+        mask = (target_labels != self.ignore_index).nonzero().squeeze()
+        return loss, correct[mask]
+
+
 class _SegmentGather(torch.autograd.Function):
     """rows[seg] whose backward is a segment sum (index_add) instead of autograd's index_put on duplicate indices."""
 

@@ -208,3 +208,15 @@ def test_reference_state_dict_after_push_dedup(tmp_path, golden):
     np.testing.assert_array_equal(dst2.prototype_class_identity.numpy(), g["prune_after_identity"])
     np.testing.assert_array_equal(dst2.prototype_vectors.detach().numpy(), g["prune_after_protos"])
     assert dst2.scale_num_prototypes == {s: tuple(int(v) for v in g["prune_after_ranges"][s]) for s in range(S)}
+
+
+def test_cross_entropy_matches_reference(golden):
+    from scaleprotoseg_amd.loss import PixelWiseCrossEntropyLoss
+
+    g = golden("kld_loss")
+    lg = torch.from_numpy(g["ce_logits"]).requires_grad_(True)
+    ce, correct = PixelWiseCrossEntropyLoss(ignore_index=-1, return_correct=True)(lg, torch.from_numpy(g["ce_target"]))
+    ce.backward()
+    assert abs(ce.item() - float(g["ce_loss"])) <= 1e-6
+    np.testing.assert_allclose(lg.grad.numpy(), g["ce_grad"], atol=1e-7)
+    np.testing.assert_array_equal(correct.numpy().astype(np.int64), g["ce_correct"])
