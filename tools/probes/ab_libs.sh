@@ -1,7 +1,7 @@
 #!/bin/bash
 # scratch: A/B several prebuilt libspx_hip.so variants with the default bench (run on the GPU box)
 for v in "$@"; do
-  cp tools/scratch/libs/libspx_$v.so scaleprotoseg_amd/libspx_hip.so
+  cp tools/probes/libs/libspx_$v.so scaleprotoseg_amd/libspx_hip.so
   echo "== $v"
   timeout -k 10 200 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "
 import sys, json
