@@ -697,7 +697,7 @@ size_t spx_bank_bwd_ws_floats(const spx_plan& pl, int nsplit) {
 }
 template <int NPB, int NCB>
 __host__ __device__ constexpr int spx_bk_lds_bytes() {
-    return 2 * (2 * NPB * 2 * 1024) + 256 * SPX_BK_ROW + NCB * 32 * SPX_BK_ROW;
+    return 2 * (2 * NPB * 2 * 1024) + 256 * SPX_BK_ROW + 2 * NCB * 32 * SPX_BK_ROW;   // dLogits^T as (hi, lo) images
 }
 
 template <int NPB, int NCB, bool XF32, bool VEC>
@@ -729,7 +729,8 @@ __global__ __launch_bounds__(SPX_BK_THREADS, 2) void spx_bank_bwd_kernel(const S
     char* Gs = smem;                                  // G fragments, verbatim
     char* As = Gs + FBYTES;                           // a fragments, verbatim
     char* Xs = As + FBYTES;                           // [256][144 B]  X rows (rows >= Cs are zero)
-    char* Ls = Xs + 256 * SPX_BK_ROW;                 // [NCB*32][144 B] dLogits^T (bf16)
+    char* Ls = Xs + 256 * SPX_BK_ROW;                 // [NCB*32][144 B] dLogits^T, bf16 high part
+    char* Ls2 = Ls + NCB * 32 * SPX_BK_ROW;           // ... and the bf16 residual: dLogits enters d_W as hi + lo (~2^-17)
 
     // wave roles
     const int cpair = wave & 3;                       // channel blocks 2*cpair, 2*cpair+1
@@ -842,7 +843,10 @@ __global__ __launch_bounds__(SPX_BK_THREADS, 2) void spx_bank_bwd_kernel(const S
             const int e = i * SPX_BK_THREADS + tid;
             if (e < SPX_BK_PX * K) {
                 const int p = e / K, cls = e - p * K;
-                *(uint16_t*)(Ls + cls * SPX_BK_ROW + p * 2) = __builtin_bit_cast(uint16_t, (__bf16)lr_[i]);
+                __bf16 hi, lo;
+                split_bf16(lr_[i], hi, lo);
+                *(uint16_t*)(Ls + cls * SPX_BK_ROW + p * 2) = __builtin_bit_cast(uint16_t, hi);
+                *(uint16_t*)(Ls2 + cls * SPX_BK_ROW + p * 2) = __builtin_bit_cast(uint16_t, lo);
             }
         }
     };
@@ -850,7 +854,10 @@ __global__ __launch_bounds__(SPX_BK_THREADS, 2) void spx_bank_bwd_kernel(const S
     // padded class rows of the dLogits^T image stay zero for the whole kernel
     for (int e = tid; e < NCB * 32 * SPX_BK_PX; e += SPX_BK_THREADS) {
         const int cls = e / SPX_BK_PX, p = e - cls * SPX_BK_PX;
-        if (cls >= K) *(uint16_t*)(Ls + cls * SPX_BK_ROW + p * 2) = 0;
+        if (cls >= K) {
+            *(uint16_t*)(Ls + cls * SPX_BK_ROW + p * 2) = 0;
+            *(uint16_t*)(Ls2 + cls * SPX_BK_ROW + p * 2) = 0;
+        }
     }
 
     // transposed-read lane map of an A fragment (rows = prototypes of block pb, k = 16 px of a k-step):
@@ -898,7 +905,9 @@ __global__ __launch_bounds__(SPX_BK_THREADS, 2) void spx_bank_bwd_kernel(const S
 #pragma unroll
                 for (int cb = 0; cb < NCB; ++cb) {
                     const bf16x8 lf = *(const bf16x8*)(Ls + (cb * 32 + r) * SPX_BK_ROW + koff);
+                    const bf16x8 lf2 = *(const bf16x8*)(Ls2 + (cb * 32 + r) * SPX_BK_ROW + koff);
                     accw[cb] = mfma_bf16(af, lf, accw[cb]);
+                    accw[cb] = mfma_bf16(af, lf2, accw[cb]);
                 }
             }
         }

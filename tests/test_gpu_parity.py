@@ -4,7 +4,9 @@ Stated tolerances (inputs are bf16-representable fp32, SURVEY.md 8d "identical i
   distances   |d - d_ref| <= 1e-4 * (1 + d_ref)
   activations |a - a_ref| <= 2e-4 * (1 + |a_ref|)
   logits      |l - l_ref| <= 1e-4 * max(1, max|l_ref|)      (1e-4 relative, north star)
-  gradients   max|g - g_ref| <= 3e-3 * max|g_ref| for dX (fp32 X) and dPrototypes, 8e-3 for dX in bf16 and
+  gradients   max|g - g_ref| <= 4e-3 * max|g_ref| for dX with fp32 X (G enters dX = 2(rs x - P^T G) as ONE bf16
+              operand: unit roundoff 2^-8 = 3.9e-3, reached when a scale has one or two prototypes and nothing
+              averages), 3e-3 for dPrototypes (a sum over all pixels), 8e-3 for dX in bf16 and
               for dLastLayer (G, the activations and dLogits enter the pixel-sum MFMAs as bf16: unbiased
               2^-9 operand rounding, which does not average out on the random-sign test gradients)
   push        indices bit-exact, values bit-exact given the same distance map
@@ -146,7 +148,7 @@ def test_backward_matches_oracle(shape, x_dtype):
     loss.backward()
     torch.cuda.synchronize()
     assert x.grad.dtype == x_dtype and x.grad.shape == x.shape
-    _grad_close(x.grad, dx_ref, "dX", tol=3e-3 if x_dtype == torch.float32 else 8e-3)
+    _grad_close(x.grad, dx_ref, "dX", tol=4e-3 if x_dtype == torch.float32 else 8e-3)
     _grad_close(pv.grad, dp_ref, "dPrototypes")
     _grad_close(w.grad, dw_ref, "dLastLayer", tol=8e-3)
 
@@ -356,7 +358,7 @@ def test_class_gathered_forward_backward(shape, x_dtype):
     _assert_fwd(logits, None, None, l_ref.detach(), None, None)
     ((logits * g_logits.reshape(-1, K).to(dev)).sum() + (cd * g_cls.permute(0, 2, 1).contiguous().to(dev)).sum()).backward()
     torch.cuda.synchronize()
-    _grad_close(x.grad, c0.grad, "dX", tol=3e-3 if x_dtype == torch.float32 else 8e-3)
+    _grad_close(x.grad, c0.grad, "dX", tol=4e-3 if x_dtype == torch.float32 else 8e-3)
     _grad_close(pv.grad, p0.grad, "dPrototypes")
     _grad_close(w.grad, w0.grad, "dLastLayer", tol=8e-3)
 
@@ -520,7 +522,7 @@ def test_fused_group_tail(shape, x_dtype):
     assert ((gact.cpu() - ug).abs() <= 2e-4 * (1 + ug.abs())).all(), "group activations"
     ((logits * g_logits.reshape(-1, K).to(dev)).sum() + (dist * g_dist.to(dev)).sum()).backward()
     torch.cuda.synchronize()
-    _grad_close(x.grad, c0.grad, "dX", tol=3e-3 if x_dtype == torch.float32 else 8e-3)
+    _grad_close(x.grad, c0.grad, "dX", tol=4e-3 if x_dtype == torch.float32 else 8e-3)
     _grad_close(pv.grad, p0.grad, "dPrototypes")
     _grad_close(wgd.grad, wg0.grad, "dLastLayerGroup", tol=2e-3)
     dwd_ref = torch.zeros(U, P)
@@ -556,3 +558,58 @@ def test_upsample_argext(case):
     clear = (srt[:, 1] - srt[:, 0]).abs() > 4 * tol if C > 1 else torch.ones_like(val_ref, dtype=torch.bool)
     assert torch.equal(idx[clear], idx_ref[clear])
     assert clear.float().mean() > 0.99
+
+
+def _random_case(rng):
+    S = int(rng.choice([1, 2, 3, 4]))
+    Cs = int(rng.choice([16, 32, 48, 64, 80, 128]))
+    K = int(rng.choice([2, 3, 5, 19, 21, 40, 64, 70]))
+    per_scale = [int(rng.integers(1, 7)) * max(1, K // int(rng.choice([1, 2, 4]))) for _ in range(S)]
+    per_scale = [min(p, 230) for p in per_scale]
+    if rng.random() < 0.4:                       # unequal scales, as after the push's de-duplication
+        per_scale = [max(1, p - int(rng.integers(0, 5))) for p in per_scale]
+    B = int(rng.integers(1, 4))
+    H, W = int(rng.integers(1, 24)), int(rng.integers(1, 40))
+    if rng.random() < 0.3:
+        W = 8 * int(rng.integers(1, 12))         # aligned rows: vector staging path
+    return B, S, Cs, per_scale, K, H, W
+
+
+@pytest.mark.parametrize("seed", list(range(24)))
+def test_random_configurations(seed):
+    """Randomised shapes (scale counts, unequal per-scale banks, channel widths with 16-channel tails, 1/2/5-block
+    heads, odd and aligned grids, partial tiles, both feature dtypes): forward outputs and all gradients against the
+    oracle, with the stated tolerances."""
+    from scaleprotoseg_amd.functional import BankLayout, proto_head_forward
+
+    dev = _dev()
+    rng = np.random.default_rng(1000 + seed)
+    B, S, Cs, per_scale, K, H, W = _random_case(rng)
+    P = sum(per_scale)
+    ranges, lo = {}, 0
+    for s, n in enumerate(per_scale):
+        ranges[s] = (lo, lo + n)
+        lo += n
+    g = torch.Generator().manual_seed(seed)
+    conv = O.bf16_representable(torch.sigmoid(torch.randn(B, S * Cs, H, W, generator=g)))
+    bank = O.bf16_representable(torch.rand(P, Cs, 1, 1, generator=g))
+    Wl = torch.randn(K, P, generator=g) * 0.3
+    x_dtype = torch.bfloat16 if seed % 2 else torch.float32
+    g_logits = torch.randn(B, H, W, K, generator=g) * 1e-3
+    g_dist = torch.randn(B, P, H, W, generator=g) * 1e-3
+    g_act = torch.randn(B * H * W, P, generator=g) * 1e-3
+    l_ref, d_ref, a_ref, dx_ref, dp_ref, dw_ref = O.fwd_bwd_reference(conv, bank, ranges, S, Wl, g_logits, g_dist, g_act)
+
+    x = conv.to(dev, x_dtype).requires_grad_(True)
+    pv = bank.to(dev).requires_grad_(True)
+    w = Wl.to(dev).requires_grad_(True)
+    lay = BankLayout(P, K, S, Cs, tuple(ranges[s] for s in range(S)))
+    logits, dist, act = proto_head_forward(x, pv, w, lay, want_distances=True, want_activations=True)
+    torch.cuda.synchronize()
+    _assert_fwd(logits, dist, act, l_ref, d_ref, a_ref)
+    ((logits * g_logits.reshape(-1, K).to(dev)).sum() + (dist * g_dist.to(dev)).sum() + (act * g_act.to(dev)).sum()).backward()
+    torch.cuda.synchronize()
+    tag = f"B{B} S{S} Cs{Cs} P{per_scale} K{K} {H}x{W} {x_dtype}"
+    _grad_close(x.grad, dx_ref, "dX " + tag, tol=4e-3 if x_dtype == torch.float32 else 8e-3)
+    _grad_close(pv.grad, dp_ref, "dPrototypes " + tag)
+    _grad_close(w.grad, dw_ref, "dLastLayer " + tag, tol=8e-3)
