@@ -393,9 +393,12 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
                 }
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) {
-                    rs += gv[reg];
                     // register reg = 8 s2 + j of the tile -> element j of k-step s2 of the B fragment
-                    gout[reg >> 3][reg & 7] = (__bf16)gv[reg];
+                    const __bf16 gb = (__bf16)gv[reg];
+                    gout[reg >> 3][reg & 7] = gb;
+                    // the row sum uses the SAME rounded G as the P^T.G product: dX = 2 sum_p G_p (x - p) then carries
+                    // G's rounding relative to |x - p|, not to |p| (matters where a pixel sits on a prototype)
+                    rs += (float)gb;
                     anew[reg >> 3][reg & 7] = (__bf16)av[reg];
                 }
             }

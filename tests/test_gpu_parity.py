@@ -613,3 +613,78 @@ def test_random_configurations(seed):
     _grad_close(x.grad, dx_ref, "dX " + tag, tol=4e-3 if x_dtype == torch.float32 else 8e-3)
     _grad_close(pv.grad, dp_ref, "dPrototypes " + tag)
     _grad_close(w.grad, dw_ref, "dLastLayer " + tag, tol=8e-3)
+
+
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_random_gather_and_tail(seed):
+    """Randomised shapes for the two extended modes: class-gathered distances (even seeds) and the fused grouping
+    tail (odd seeds), forward + all gradients against the oracle."""
+    from scaleprotoseg_amd.functional import BankLayout, ClassGather, class_gather_table, proto_head_forward
+
+    dev = _dev()
+    rng = np.random.default_rng(5000 + seed)
+    S = int(rng.choice([1, 2, 4]))
+    Cs = int(rng.choice([16, 32, 64]))
+    K = int(rng.choice([2, 3, 5, 7, 19]))
+    r = int(rng.integers(1, 4))
+    P = K * S * r
+    B, H, W = int(rng.integers(1, 3)), int(rng.integers(2, 14)), int(rng.integers(2, 30))
+    x_dtype = torch.bfloat16 if (seed // 2) % 2 else torch.float32
+    conv, bank, Wl, ident, ranges = _problem(B, S, Cs, P, K, H, W, seed=100 + seed)
+    lay_k = BankLayout(P, K, S, Cs, tuple(ranges[s] for s in range(S)))
+    g = torch.Generator().manual_seed(seed)
+    g_logits = torch.randn(B, H, W, K, generator=g) * 1e-3
+    x = conv.to(dev, x_dtype).requires_grad_(True)
+    pv = bank.to(dev).requires_grad_(True)
+    c0 = conv.clone().requires_grad_(True)
+    p0 = bank.clone().requires_grad_(True)
+    # tiny banks (P as small as 4): dX is a sum of a handful of signed terms G_p (x - p), each carrying G's bf16
+    # rounding (2^-8); with cancellation between them the error relative to max|dX| can pass the 4e-3 of the
+    # realistic shapes, so these toy cases get 6e-3
+    dx_tol = 6e-3 if x_dtype == torch.float32 else 8e-3
+    if seed % 2 == 0:
+        target = _labels(B, H, W, K, seed=seed)
+        lab0 = target.reshape(B, -1) - 1
+        keys, J, table = class_gather_table(lay_k, ident, dev)
+        gather = ClassGather(labels=lab0.to(dev, torch.int32).contiguous(), keys=keys, width=J, table=table)
+        g_cls = torch.randn(B, H * W, J, generator=g) * 1e-3
+        w0 = Wl.clone().requires_grad_(True)
+        l_ref, d_ref, _ = O.forward_from_conv_features(c0, p0, ranges, S, w0)
+        cd_ref = O.gather_class_distances(d_ref, lab0, ident)
+        ((l_ref * g_logits).sum() + (cd_ref * g_cls).sum()).backward()
+        w = Wl.to(dev).requires_grad_(True)
+        logits, cd, _ = proto_head_forward(x, pv, w, lay_k, class_gather=gather)
+        got = cd.detach().cpu().permute(0, 2, 1)
+        assert ((got - cd_ref.detach()).abs() <= 1e-4 * (1 + cd_ref.detach())).all()
+        _assert_fwd(logits, None, None, l_ref.detach(), None, None)
+        ((logits * g_logits.reshape(-1, K).to(dev)).sum() + (cd * g_cls.permute(0, 2, 1).contiguous().to(dev)).sum()).backward()
+        torch.cuda.synchronize()
+        _grad_close(w.grad, w0.grad, "dLastLayer", tol=8e-3)
+    else:
+        G = int(rng.integers(2, 4))
+        idx = [i for i in O.class_prototype_index(ident) if len(i) > 0]
+        gw = [O.projection_simplex_sort(torch.rand(G, len(i), generator=g)) for i in idx]
+        U = G * len(idx)
+        wg = torch.randn(K, U, generator=g) * 0.5
+        gw0 = [t.clone().requires_grad_(True) for t in gw]
+        wg0 = wg.clone().requires_grad_(True)
+        d_ref = O.scale_l2_convolution(c0, p0, ranges, S)
+        act_ref = O.distance_2_similarity(d_ref).permute(0, 2, 3, 1).reshape(-1, P)
+        units = torch.cat(O.compute_group(act_ref, ident, gw0), dim=-1)
+        l_ref = torch.nn.functional.linear(units, wg0)
+        (l_ref * g_logits.reshape(-1, K)).sum().backward()
+        wd = torch.zeros(U, P)
+        for k, i in enumerate(idx):
+            wd[k * G:(k + 1) * G, i] = gw[k]
+        wdd = wd.to(dev).requires_grad_(True)
+        wgd = wg.to(dev).requires_grad_(True)
+        logits, _, _, gact = proto_head_forward(x, pv, wdd, BankLayout(P, U, S, Cs, tuple(ranges[s] for s in range(S))),
+                                                want_distances=False, group_tail=wgd)
+        rl = l_ref.detach()
+        err = (logits.detach().cpu() - rl).abs().max().item()
+        assert err <= 1e-4 * max(1.0, rl.abs().max().item()), f"group logits err {err}"
+        (logits * g_logits.reshape(-1, K).to(dev)).sum().backward()
+        torch.cuda.synchronize()
+        _grad_close(wgd.grad, wg0.grad, "dLastLayerGroup", tol=2e-3)
+    _grad_close(x.grad, c0.grad, "dX", tol=dx_tol)
+    _grad_close(pv.grad, p0.grad, "dPrototypes")
