@@ -703,7 +703,10 @@ __host__ __device__ constexpr int spx_bk_lds_bytes() {
     return 2 * (2 * NPB * 2 * 1024) + 256 * SPX_BK_ROW + 2 * NCB * 32 * SPX_BK_ROW;   // dLogits^T as (hi, lo) images
 }
 
-template <int NPB, int NCB, bool XF32, bool VEC>
+// DO_P / DO_W: which of the two products this instance carries.  One launch does both for small heads; for the
+// 5-block head (80 d_W accumulators per lane next to 96 for d_bank) the launcher runs two instances, each with its
+// own operands only (G + X, or a + dLogits): no byte is read twice and neither instance spills.
+template <int NPB, int NCB, bool XF32, bool VEC, bool DO_P, bool DO_W>
 __global__ __launch_bounds__(SPX_BK_THREADS, 2) void spx_bank_bwd_kernel(const SpxBankBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const spx_plan& pl = a.plan;
@@ -723,8 +726,8 @@ __global__ __launch_bounds__(SPX_BK_THREADS, 2) void spx_bank_bwd_kernel(const S
     const long long per = (total + a.nsplit - 1) / a.nsplit;
     const long long c_begin = split * per;
     const long long c_end = (c_begin + per < total) ? c_begin + per : total;
-    const bool want_w = a.d_W != nullptr;
-    const bool want_p = a.d_bank != nullptr;
+    const bool want_w = DO_W && a.d_W != nullptr;
+    const bool want_p = DO_P && a.d_bank != nullptr;
     constexpr int ESZ = XF32 ? 4 : 2;
     constexpr int NFRAG = 2 * NPB * 2;                // fragments per chunk and image: 2 kernel-1 waves x NPB x 2 k-steps
     constexpr int FBYTES = NFRAG * 1024;
@@ -886,7 +889,7 @@ __global__ __launch_bounds__(SPX_BK_THREADS, 2) void spx_bank_bwd_kernel(const S
 #pragma unroll
             for (int t = 0; t < 2; ++t) xb[t] = *(const bf16x8*)(Xs + ((2 * cpair + t) * 32 + r) * SPX_BK_ROW + koff);
 #pragma unroll
-            for (int i = 0; i < PH; ++i) {
+            for (int i = 0; i < (DO_P ? PH : 0); ++i) {
                 const int fb = ((wsel * NPB + pb0 + i) * 2 + ts2) * 1024;
                 const bf16x4 g0 = __builtin_bit_cast(bf16x4, lds_tr_read(Gs + fb + fo0));
                 const bf16x4 g1 = __builtin_bit_cast(bf16x4, lds_tr_read(Gs + fb + fo1));
@@ -900,7 +903,7 @@ __global__ __launch_bounds__(SPX_BK_THREADS, 2) void spx_bank_bwd_kernel(const S
 #pragma unroll
                 for (int t = 0; t < 2; ++t) accp[i][t] = mfma_bf16(gf, xb[t], accp[i][t]);
             }
-            if (w_role) {
+            if (DO_W && w_role) {
                 const int fb = ((wsel * NPB + wave) * 2 + ts2) * 1024;
                 const bf16x4 a0 = __builtin_bit_cast(bf16x4, lds_tr_read(As + fb + fo0));
                 const bf16x4 a1 = __builtin_bit_cast(bf16x4, lds_tr_read(As + fb + fo1));
@@ -1012,17 +1015,28 @@ __global__ __launch_bounds__(SPX_RED_ELEMS * SPX_RED_PARTS) void spx_bank_reduce
     }
 }
 
-template <int NPB, int NCB>
-static hipError_t launch_bank_x(const SpxBankBwdArgs& a, int x_dtype, dim3 grid, hipStream_t s) {
+template <int NPB, int NCB, bool DO_P, bool DO_W>
+static hipError_t launch_bank_pw(const SpxBankBwdArgs& a, int x_dtype, dim3 grid, hipStream_t s) {
     constexpr size_t lds = (size_t)spx_bk_lds_bytes<NPB, NCB>();
     if (x_dtype == 1) {
-        if (a.vec_ok) hipLaunchKernelGGL((spx_bank_bwd_kernel<NPB, NCB, true, true>), grid, dim3(SPX_BK_THREADS), lds, s, a);
-        else hipLaunchKernelGGL((spx_bank_bwd_kernel<NPB, NCB, true, false>), grid, dim3(SPX_BK_THREADS), lds, s, a);
+        if (a.vec_ok) hipLaunchKernelGGL((spx_bank_bwd_kernel<NPB, NCB, true, true, DO_P, DO_W>), grid, dim3(SPX_BK_THREADS), lds, s, a);
+        else hipLaunchKernelGGL((spx_bank_bwd_kernel<NPB, NCB, true, false, DO_P, DO_W>), grid, dim3(SPX_BK_THREADS), lds, s, a);
     } else {
-        if (a.vec_ok) hipLaunchKernelGGL((spx_bank_bwd_kernel<NPB, NCB, false, true>), grid, dim3(SPX_BK_THREADS), lds, s, a);
-        else hipLaunchKernelGGL((spx_bank_bwd_kernel<NPB, NCB, false, false>), grid, dim3(SPX_BK_THREADS), lds, s, a);
+        if (a.vec_ok) hipLaunchKernelGGL((spx_bank_bwd_kernel<NPB, NCB, false, true, DO_P, DO_W>), grid, dim3(SPX_BK_THREADS), lds, s, a);
+        else hipLaunchKernelGGL((spx_bank_bwd_kernel<NPB, NCB, false, false, DO_P, DO_W>), grid, dim3(SPX_BK_THREADS), lds, s, a);
     }
     return hipGetLastError();
+}
+template <int NPB, int NCB>
+static hipError_t launch_bank_x(const SpxBankBwdArgs& a, int x_dtype, dim3 grid, hipStream_t s) {
+    if constexpr (NCB < 5) {
+        return launch_bank_pw<NPB, NCB, true, true>(a, x_dtype, grid, s);
+    } else {
+        hipError_t e = hipSuccess;
+        if (a.d_bank) e = launch_bank_pw<NPB, NCB, true, false>(a, x_dtype, grid, s);
+        if (e == hipSuccess && a.d_W) e = launch_bank_pw<NPB, NCB, false, true>(a, x_dtype, grid, s);
+        return e;
+    }
 }
 
 hipError_t spx_launch_bank_bwd(const SpxBankBwdArgs& a, int x_dtype, hipStream_t s) {
