@@ -22,3 +22,12 @@ def golden():
         return np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
 
     return load
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _built_library():
+    """The C-ABI library is an in-tree build product (git-ignored): build it (incrementally, hipcc cross-compiles
+    gfx950 without a GPU) before any test touches it, so a fresh checkout or a stale object never decides a test."""
+    from scaleprotoseg_amd.build import build
+
+    build()
