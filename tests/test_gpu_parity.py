@@ -688,3 +688,4 @@ def test_random_gather_and_tail(seed):
         _grad_close(wgd.grad, wg0.grad, "dLastLayerGroup", tol=2e-3)
     _grad_close(x.grad, c0.grad, "dX", tol=dx_tol)
     _grad_close(pv.grad, p0.grad, "dPrototypes")
+
