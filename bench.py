@@ -86,6 +86,8 @@ def main():
     ap.add_argument("--grads", default="logits,dist", help="diagnostic only: which output gradients flow back")
     ap.add_argument("--outputs", default="logits,dist", help="diagnostic only: 'logits' = logits-only forward (no fp32 distance map); "
                     "'logits,class_dist' = class-gathered distances (SURVEY 8f-1: what the fused KLD consumes) instead of the P-wide map")
+    ap.add_argument("--group-tail", action="store_true", help="diagnostic only: group phase - the head is the dense [3K, P] grouping "
+                    "matrix and exp + last_layer_group run fused in the kernels (spx_dist_fwd_group / spx_dist_bwd_group)")
     ap.add_argument("--freeze", default="", help="diagnostic only: comma list of x,bank,head to exclude from the backward")
     args = ap.parse_args()
 
@@ -133,11 +135,25 @@ def main():
         for k in range(K):
             ident[s * per_scale + k * per_cs : s * per_scale + (k + 1) * per_cs, k] = 1
     head = (ident.t() - 0.5 * (1 - ident.t())).contiguous().requires_grad_(True)
+    tail = None
+    if args.group_tail:
+        G = 3                                            # scaleproto_*.gin: num_groups = 3
+        U = G * K
+        wd = torch.zeros(U, P, device=dev)
+        for k in range(K):
+            cols = ident[:, k].nonzero().flatten()
+            wd[k * G:(k + 1) * G, cols] = torch.rand(G, cols.numel(), device=dev, generator=gp) / max(1, cols.numel())
+        head = wd.requires_grad_(True)
+        gci = torch.zeros(U, K, device=dev)
+        for k in range(K):
+            gci[k * G:(k + 1) * G, k] = 1
+        tail = (gci.t() - 0.5 * (1 - gci.t())).contiguous().requires_grad_(True)
+        layout = spx.BankLayout(P, U, S, Cs, layout.scale_ranges)
     g_logits = torch.randn(H * W, K, device=dev, generator=g) * 1e-3
     g_dist = torch.randn(1, P, H, W, device=dev, generator=g) * 1e-3
     for name in filter(None, args.freeze.split(",")):
         {"x": x, "bank": bank, "head": head}[name].requires_grad_(False)
-    bucket = FlatGradBucket([p for p in (bank, head) if p.requires_grad] or [bank.requires_grad_(True)])
+    bucket = FlatGradBucket([p for p in (bank, head, tail) if p is not None and p.requires_grad] or [bank.requires_grad_(True)])
 
     gather = None
     if "class_dist" in args.outputs.split(","):
@@ -153,7 +169,11 @@ def main():
         bank.grad = None
         head.grad = None
         want_d = "dist" in args.outputs.split(",")
-        logits, dmap, _ = spx.proto_head_forward(x, bank, head, layout, want_distances=want_d, class_gather=gather)
+        if tail is not None:
+            tail.grad = None
+            logits, dmap, _, _ = spx.proto_head_forward(x, bank, head, layout, want_distances=want_d, group_tail=tail)
+        else:
+            logits, dmap, _ = spx.proto_head_forward(x, bank, head, layout, want_distances=want_d, class_gather=gather)
         outs, gouts = [], []
         if "logits" in args.grads:
             outs.append(logits); gouts.append(g_logits)
@@ -238,7 +258,8 @@ def main():
                 "classes": K,
                 "features_dtype": args.x_dtype,
                 "outputs": ("logits + fp32 distance map (reference forward contract); grads dX, dPrototypes, dLastLayer"
-                            if args.outputs == "logits,dist" else f"DIAGNOSTIC outputs={args.outputs} grads={args.grads}"),
+                            if (args.outputs == "logits,dist" and not args.group_tail)
+                            else f"DIAGNOSTIC outputs={args.outputs} grads={args.grads} group_tail={args.group_tail}"),
                 "parallelism": f"dp{world}" if world > 1 else "single",
             },
             "kernels": kernels,

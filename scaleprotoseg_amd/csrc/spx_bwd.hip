@@ -41,7 +41,7 @@
 template <int NPB>
 __host__ __device__ constexpr int spx_bwd_bt_bytes() { return NPB * 2 * 1024; }
 template <int NPB, int NCB>
-__host__ __device__ constexpr int spx_bwd_head_lds_bytes() { return NCB == 1 ? NPB * 2 * 2048 : 0; }
+__host__ __device__ constexpr int spx_bwd_head_lds_bytes() { return NCB * NPB <= 6 ? NPB * NCB * 2 * 2048 : 0; }   // <= 24 KiB
 template <int NPB>
 __host__ __device__ constexpr int spx_bwd_region0_bytes() {
     constexpr int a = 2 * spx_stage_bytes(NPB);

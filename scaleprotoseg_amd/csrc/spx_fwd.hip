@@ -28,7 +28,7 @@ template <int NPB, int NCB>
 __host__ __device__ constexpr int spx_fwd_head_lds_bytes() { return 0; }   // experiment: head fragments straight from L2
 #else
 template <int NPB, int NCB>
-__host__ __device__ constexpr int spx_fwd_head_lds_bytes() { return NCB == 1 ? NPB * 4096 : 0; }
+__host__ __device__ constexpr int spx_fwd_head_lds_bytes() { return NCB * NPB <= 6 ? NCB * NPB * 4096 : 0; }   // <= 24 KiB: resident in LDS
 #endif
 // region 0 = the two main-loop stages, re-used after the loop as the waves' epilogue scratch
 template <int NPB, int SPLIT>
@@ -122,14 +122,20 @@ __global__ __launch_bounds__(256 * SPLIT, SPX_FWD_WAVES * SPLIT) void spx_fwd_ke
     constexpr int HPB = NT * 16;                        // bytes per pass of the whole workgroup
     constexpr int HPASS = (head_lds + HPB - 1) / HPB;
     static_assert(head_lds % HPB == 0 || head_lds < HPB, "head fragments: whole passes, or one partial pass");
+    static_assert(NCB == 1 || (NPB * 4096) % HPB == 0, "a pass must not straddle two class blocks");
     const bool h_in = head_lds >= HPB || tid * 16 < head_lds;
     u32x4 hreg[HPASS > 0 ? HPASS : 1];
     float p2reg = 0.0f;
     uint32_t keyreg = 0xFFFFFFFFu;
     auto consts_issue = [&](int panel) {
 #pragma unroll
-        for (int i = 0; i < HPASS; ++i)
-            hreg[i] = buf_load_b128(hr, (want_head && h_in) ? (uint32_t)(i * HPB + tid * 16) : SPX_OOB, (uint32_t)(panel * head_lds));
+        for (int i = 0; i < HPASS; ++i) {
+            // packed head = [class block][panel][block][k-step][hi|lo]: the panel's share of class block cb is
+            // NPB * 4 KiB; the LDS image is [class block][block][k-step][hi|lo]
+            const int cb = (i * HPB) / (NPB * 4096), rest = (i * HPB) % (NPB * 4096);
+            hreg[i] = buf_load_b128(hr, (want_head && h_in) ? (uint32_t)(rest + tid * 16) : SPX_OOB,
+                                    (uint32_t)((cb * pl.npanels + panel) * NPB * 4096));
+        }
         p2reg = buf_load_f32(p2r, tid < NPB * 32 ? (uint32_t)tid * 4u : SPX_OOB, (uint32_t)(panel * NPB * 32 * 4));
         if (GATHER) keyreg = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(keyr, tid < NPB * 32 ? (uint32_t)tid * 4u : SPX_OOB, (uint32_t)(panel * NPB * 32 * 4), 0);
     };

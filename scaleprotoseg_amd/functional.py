@@ -279,9 +279,11 @@ class _ProtoHeadFn(torch.autograd.Function):
         a_scr = torch.empty(scr, dtype=torch.uint8, device=dev) if need_head else None
         s = _lib.stream_ptr()
         tail2d, d_units, d_tail = ctx.tail2d, None, None
-        if tail2d is not None and gl is not None:
-            d_units = torch.empty((B * HW, K), dtype=torch.float32, device=dev)
-            with _timed("spx_dist_bwd"):
+        if tail2d is not None and gl is None:
+            raise SpxError("backward through the fused group tail without a logits gradient")
+        with _timed("spx_dist_bwd"):
+            if tail2d is not None:
+                d_units = torch.empty((B * HW, K), dtype=torch.float32, device=dev)
                 _lib.check(
                     lib.spx_dist_bwd_group(
                         pp, _lib.ptr(x), xd, B, HW, _lib.ptr(packs.bank), _lib.ptr(packs.bankT), _lib.ptr(packs.p2),
@@ -290,14 +292,6 @@ class _ProtoHeadFn(torch.autograd.Function):
                         _lib.ptr(a_scr), ctx.epsilon, ACT_FN[ctx.act_fn], s,
                     )
                 )
-            if ctx.needs_input_grad[9]:
-                d_tail = _pixel_outer(gl, ctx.gact)   # d W_g [K2, U]: one small product over the pixels
-            gl = d_units                              # the parameter kernel's d_logits operand
-        elif tail2d is not None:
-            raise SpxError("backward through the fused group tail without a logits gradient")
-        with _timed("spx_dist_bwd"):
-            if tail2d is not None:
-                pass
             elif ctx.gather is not None:
                 g = ctx.gather
                 _lib.check(
@@ -316,6 +310,10 @@ class _ProtoHeadFn(torch.autograd.Function):
                         _lib.ptr(dx), _lib.ptr(g_scr), _lib.ptr(a_scr), ctx.epsilon, ACT_FN[ctx.act_fn], s,
                     )
                 )
+        if tail2d is not None:
+            if ctx.needs_input_grad[9]:
+                d_tail = _pixel_outer(gl, ctx.gact)   # d W_g [K2, U]: one small product over the pixels
+            gl = d_units                              # the parameter kernel's d_logits operand
         d_bank = d_head = None
         if need_bank or need_head:
             ws = torch.empty(lib.spx_bank_bwd_workspace_bytes(pp, B, HW) // 4, dtype=torch.float32, device=dev)
