@@ -29,6 +29,7 @@ WORKLOADS = {
     # name: (C, P, S, K, H, W)   latent grid H x W per image, one image per GPU
     "cityscapes_1024x2048_c256_p190_s1": (256, 190, 1, 19, 1024, 2048),   # north-star shape (SURVEY.md 8d primary)
     "cityscapes_native_129x257_p228_s4": (256, 228, 4, 19, 129, 257),     # scaleproto_cityscapes.gin full image
+    "cityscapes_1024x2048_c256_p228_s4": (256, 228, 4, 19, 1024, 2048),   # the gin's 4-scale bank at the north-star grid
 }
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
 MFMA_BF16_PEAK_TFLOPS = 2500.0
