@@ -10,7 +10,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libspx_hip.so")
-SOURCES = ["spx_api.hip", "spx_fwd.hip", "spx_bwd.hip", "spx_pack.hip", "spx_push.hip", "spx_eval.hip"]
+SOURCES = ["spx_api.hip", "spx_fwd.hip", "spx_bwd.hip", "spx_bank.hip", "spx_pack.hip", "spx_push.hip", "spx_eval.hip"]
 HEADERS = ["spx_common.h", "spx_args.h", "spx_mainloop.h", os.path.join("..", "..", "include", "spx_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off"]
 FLAGS += os.environ.get("SPX_EXTRA_HIPCC_FLAGS", "").split()

@@ -65,6 +65,14 @@ struct SpxBankBwdArgs {
     float* workspace;
     int B, HW, vec_ok, nsplit;
 };
+// Slot (16-B unit) of lane (r = pixel, h) inside the 1-KiB fragment blob of k-step s2.  Kernel 2 copies the blobs
+// verbatim into LDS and reads them back with ds_read_b64_tr_b16 (pixel = k): the 32 lanes of a half-wave then
+// touch 4 consecutive pixels x both lane halves x both k-steps, which this permutation spreads over all 16
+// 16-B bank groups (the plain slot r + 32 h would put them 4-way on the same banks).
+__host__ __device__ inline uint32_t spx_blob_slot(int r, int h, int s2) {
+    return (uint32_t)(((r >> 2) * 8 + (r & 3) + 4 * h + 8 * s2) & 63);
+}
+
 hipError_t spx_launch_fwd(const SpxFwdArgs& a, int x_dtype, hipStream_t s);        // a.labels != NULL: class-gathered variant
 hipError_t spx_launch_bwd(const SpxBwdArgs& a, int x_dtype, hipStream_t s);
 hipError_t spx_launch_bank_bwd(const SpxBankBwdArgs& a, int x_dtype, hipStream_t s);

@@ -64,14 +64,6 @@ size_t spx_bwd_scratch_elems(const spx_plan& pl, int B, int HW) {
     return (size_t)pl.npanels * tiles * 4 * pl.npb * 2 * 512;
 }
 
-// Slot (16-B unit) of lane (r = pixel, h) inside the 1-KiB fragment blob of k-step s2.  Kernel 2 copies the blobs
-// verbatim into LDS and reads them back with ds_read_b64_tr_b16 (pixel = k): the 32 lanes of a half-wave then
-// touch 4 consecutive pixels x both lane halves x both k-steps, which this permutation spreads over all 16
-// 16-B bank groups (the plain slot r + 32 h would put them 4-way on the same banks).
-__host__ __device__ inline uint32_t spx_blob_slot(int r, int h, int s2) {
-    return (uint32_t)(((r >> 2) * 8 + (r & 3) + 4 * h + 8 * s2) & 63);
-}
-
 // ------------------------------------------------------------------------------------------------
 // kernel 1: pixel side
 // ------------------------------------------------------------------------------------------------
@@ -668,391 +660,4 @@ hipError_t spx_launch_bwd(const SpxBwdArgs& a, int x_dtype, hipStream_t s) {
     if (pl.npb == 2) return launch_bwd_x<2, 5>(a, x_dtype, grid, s);
     if (pl.npb == 4) return launch_bwd_x<4, 5>(a, x_dtype, grid, s);
     return launch_bwd_x<6, 5>(a, x_dtype, grid, s);
-}
-
-// ------------------------------------------------------------------------------------------------
-// kernel 2: parameter side   S[q][row][col] = sum_px Gq[row][px] * Xs[col][px]   (+ a^T.dLogits, colsum G)
-//
-// One workgroup = 8 waves (2 per SIMD) owns one (panel, pixel split) and walks its 64-px chunks.  Per chunk the
-// G / a fragment blobs of the two kernel-1 waves covering it are copied VERBATIM into LDS and read back with
-// ds_read_b64_tr_b16 so that the pixel becomes the MFMA k (A operand = G^T / a^T rows); X rows [channel][px]
-// are the B operand (ds_read_b128); dLogits is transposed to bf16 [class][px] while staged.  Wave w accumulates
-// the 32x32 tiles (prototype block pb in its half, channel blocks 2(w&3), 2(w&3)+1); the tiles live in
-// registers for the whole launch and leave as one fp32 slab per workgroup.  Straight-line chunk body: panel
-// height, class blocks and the 8 channel blocks are compile-time (channels beyond Cs are zero rows).
-// ------------------------------------------------------------------------------------------------
-#define SPX_BK_PX 64          // pixels per K-chunk (half a kernel-1 tile)
-#define SPX_BK_ROW 144        // LDS row stride of the [channel][px] images (128 + 16: conflict-free ds_read_b128)
-#define SPX_BK_THREADS 512
-
-__host__ __device__ inline int spx_bk_wstride(const spx_plan& pl) {
-    return ((pl.channels_per_scale + 31) / 32) * 32 + pl.ncb * 32 + 32;   // [dP cols | dW cols | colsum + pad]
-}
-int spx_bank_bwd_nsplit(const spx_plan& pl, int B, int HW) {
-    const long long chunks = 2LL * B * ((HW + SPX_TILE_PX - 1) / SPX_TILE_PX);
-    long long n = 256 / pl.npanels;
-    if (n < 1) n = 1;
-    if (n > chunks) n = chunks;
-    return (int)n;
-}
-size_t spx_bank_bwd_ws_floats(const spx_plan& pl, int nsplit) {
-    return (size_t)nsplit * pl.npanels * pl.npb * 32 * spx_bk_wstride(pl);
-}
-template <int NPB, int NCB>
-__host__ __device__ constexpr int spx_bk_lds_bytes() {
-    return 2 * (2 * NPB * 2 * 1024) + 256 * SPX_BK_ROW + 2 * NCB * 32 * SPX_BK_ROW;   // dLogits^T as (hi, lo) images
-}
-
-// DO_P / DO_W: which of the two products this instance carries.  One launch does both for small heads; for the
-// 5-block head (80 d_W accumulators per lane next to 96 for d_bank) the launcher runs two instances, each with its
-// own operands only (G + X, or a + dLogits): no byte is read twice and neither instance spills.
-template <int NPB, int NCB, bool XF32, bool VEC, bool DO_P, bool DO_W>
-__global__ __launch_bounds__(SPX_BK_THREADS, 2) void spx_bank_bwd_kernel(const SpxBankBwdArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const spx_plan& pl = a.plan;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r = lane & 31, h = lane >> 5;
-    const int q = blockIdx.y, split = blockIdx.x;
-    const int Cs = pl.channels_per_scale, K = pl.num_classes;
-    const int C = pl.num_scales * Cs;
-    const int nchb = (Cs + 31) / 32;
-    constexpr int rows = NPB * 32;
-    const int ch0 = pl.panel_ch0[q];
-    const int tiles_per_img = (a.HW + SPX_TILE_PX - 1) / SPX_TILE_PX;
-    const size_t ntiles = (size_t)a.B * tiles_per_img;
-    const int nci = 2 * tiles_per_img;                       // 64-px chunks per image
-    const long long total = (long long)a.B * nci;
-    const long long per = (total + a.nsplit - 1) / a.nsplit;
-    const long long c_begin = split * per;
-    const long long c_end = (c_begin + per < total) ? c_begin + per : total;
-    const bool want_w = DO_W && a.d_W != nullptr;
-    const bool want_p = DO_P && a.d_bank != nullptr;
-    constexpr int ESZ = XF32 ? 4 : 2;
-    constexpr int NFRAG = 2 * NPB * 2;                // fragments per chunk and image: 2 kernel-1 waves x NPB x 2 k-steps
-    constexpr int FBYTES = NFRAG * 1024;
-
-    char* Gs = smem;                                  // G fragments, verbatim
-    char* As = Gs + FBYTES;                           // a fragments, verbatim
-    char* Xs = As + FBYTES;                           // [256][144 B]  X rows (rows >= Cs are zero)
-    char* Ls = Xs + 256 * SPX_BK_ROW;                 // [NCB*32][144 B] dLogits^T, bf16 high part
-    char* Ls2 = Ls + NCB * 32 * SPX_BK_ROW;           // ... and the bf16 residual: dLogits enters d_W as hi + lo (~2^-17)
-
-    // wave roles
-    const int cpair = wave & 3;                       // channel blocks 2*cpair, 2*cpair+1
-    constexpr int PH = NPB / 2;                       // prototype blocks per half
-    const int pb0 = (wave >> 2) * PH;                 // this wave's prototype blocks pb0 .. pb0+PH-1
-    const bool w_role = wave < NPB;                   // waves 0..NPB-1 also own the dW tiles of block `wave`
-    const bool cs_role = cpair == 0;                  // one wave per prototype half sums colsum(G)
-
-    f32x16 accp[PH][2];
-    f32x16 accw[NCB];
-    float csum[PH];
-#pragma unroll
-    for (int i = 0; i < PH; ++i) {
-        csum[i] = 0.0f;
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) accp[i][t][e] = 0.0f;
-    }
-#pragma unroll
-    for (int cb = 0; cb < NCB; ++cb)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) accw[cb][e] = 0.0f;
-
-    // staging registers (512 threads)
-    constexpr int FP = (FBYTES / 16 + SPX_BK_THREADS - 1) / SPX_BK_THREADS;   // 16-B pieces per thread per image
-    constexpr int XPT = 256 * 8 / SPX_BK_THREADS;                               // X pieces (8 px) per thread = 4
-    u32x4 gr[FP], ar[FP], xr[XPT][XF32 ? 2 : 1];
-    constexpr int LPT = (SPX_BK_PX * 32 * NCB + SPX_BK_THREADS - 1) / SPX_BK_THREADS;   // dLogits elements per thread (upper bound)
-    float lr_[LPT];
-    const int piece = tid & 7, prow = tid >> 3;      // X staging: piece of 8 px, row (0..63) within a pass of 64 rows
-
-    auto issue = [&](long long c) {
-        const int b = (int)(c / nci);
-        const int ci = (int)(c - (long long)b * nci);
-        const size_t tile_g = (size_t)b * tiles_per_img + (ci >> 1);
-        // the chunk's fragments are contiguous: kernel-1 waves 2(ci&1), 2(ci&1)+1 of the tile
-        const size_t blob0 = ((((size_t)q * ntiles + tile_g) * 4 + 2 * (ci & 1)) * NPB * 2) * 1024;
-        const spx_rsrc grs = make_rsrc_pred(a.g_in ? (const char*)a.g_in + blob0 : nullptr);
-        const spx_rsrc ars = make_rsrc_pred(a.a_in ? (const char*)a.a_in + blob0 : nullptr);
-#pragma unroll
-        for (int i = 0; i < FP; ++i) {
-            const uint32_t off = (uint32_t)((i * SPX_BK_THREADS + tid) * 16);
-            gr[i] = buf_load_b128(grs, (want_p && off < (uint32_t)FBYTES) ? off : SPX_OOB, 0);
-            ar[i] = buf_load_b128(ars, (want_w && off < (uint32_t)FBYTES) ? off : SPX_OOB, 0);
-        }
-        const int px = ci * SPX_BK_PX + piece * 8;
-#pragma unroll
-        for (int i = 0; i < XPT; ++i) {
-            const int row = prow + 64 * i;
-            // rebase per (image, 64-row block): offsets from the tensor base can exceed 4 GiB for large batches
-            const spx_rsrc xb = make_rsrc_pred((const char*)a.x + ((size_t)b * C + ch0 + 64 * i) * a.HW * ESZ);
-            const uint32_t vo = ((uint32_t)prow * (uint32_t)a.HW + (uint32_t)px) * ESZ;
-            const bool row_ok = want_p && row < Cs;
-            if (VEC) {
-                const uint32_t v = (row_ok && px + 8 <= a.HW) ? vo : SPX_OOB;
-                xr[i][0] = buf_load_b128(xb, v, 0);
-                if (XF32) xr[i][1] = buf_load_b128(xb, v == SPX_OOB ? SPX_OOB : v + 16, 0);
-            } else if (XF32) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    xr[i][e >> 2][e & 3] = __float_as_uint(buf_load_f32(xb, (row_ok && px + e < a.HW) ? vo + 4 * e : SPX_OOB, 0));
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const uint32_t lo = buf_load_u16(xb, (row_ok && px + 2 * e < a.HW) ? vo + 4 * e : SPX_OOB, 0);
-                    const uint32_t hi = buf_load_u16(xb, (row_ok && px + 2 * e + 1 < a.HW) ? vo + 4 * e + 2 : SPX_OOB, 0);
-                    xr[i][0][e] = lo | (hi << 16);
-                }
-            }
-        }
-        // dLogits of the chunk's 64 px: a contiguous [64][K] fp32 block
-        const int px0 = ci * SPX_BK_PX;
-        const spx_rsrc lb = make_rsrc_pred(a.d_logits ? a.d_logits + ((size_t)b * a.HW + px0) * K : nullptr);
-#pragma unroll
-        for (int i = 0; i < LPT; ++i) {
-            const int e = i * SPX_BK_THREADS + tid;
-            const int p = e / K;
-            lr_[i] = buf_load_f32(lb, (want_w && e < SPX_BK_PX * K && px0 + p < a.HW) ? (uint32_t)e * 4u : SPX_OOB, 0);
-        }
-    };
-
-    auto commit = [&]() {
-#pragma unroll
-        for (int i = 0; i < FP; ++i) {
-            const int off = (i * SPX_BK_THREADS + tid) * 16;
-            if (off < FBYTES) {
-                *(u32x4*)(Gs + off) = gr[i];
-                *(u32x4*)(As + off) = ar[i];
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < XPT; ++i) {
-            u32x4 v;
-            if (XF32) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    bf16x2 p;
-                    p[0] = (__bf16)__uint_as_float(xr[i][e >> 1][(2 * e) & 3]);
-                    p[1] = (__bf16)__uint_as_float(xr[i][e >> 1][(2 * e + 1) & 3]);
-                    v[e] = __builtin_bit_cast(uint32_t, p);
-                }
-            } else {
-                v = xr[i][0];
-            }
-            *(u32x4*)(Xs + (prow + 64 * i) * SPX_BK_ROW + piece * 16) = v;
-        }
-#pragma unroll
-        for (int i = 0; i < LPT; ++i) {
-            const int e = i * SPX_BK_THREADS + tid;
-            if (e < SPX_BK_PX * K) {
-                const int p = e / K, cls = e - p * K;
-                __bf16 hi, lo;
-                split_bf16(lr_[i], hi, lo);
-                *(uint16_t*)(Ls + cls * SPX_BK_ROW + p * 2) = __builtin_bit_cast(uint16_t, hi);
-                *(uint16_t*)(Ls2 + cls * SPX_BK_ROW + p * 2) = __builtin_bit_cast(uint16_t, lo);
-            }
-        }
-    };
-
-    // padded class rows of the dLogits^T image stay zero for the whole kernel
-    for (int e = tid; e < NCB * 32 * SPX_BK_PX; e += SPX_BK_THREADS) {
-        const int cls = e / SPX_BK_PX, p = e - cls * SPX_BK_PX;
-        if (cls >= K) {
-            *(uint16_t*)(Ls + cls * SPX_BK_ROW + p * 2) = 0;
-            *(uint16_t*)(Ls2 + cls * SPX_BK_ROW + p * 2) = 0;
-        }
-    }
-
-    // transposed-read lane map of an A fragment (rows = prototypes of block pb, k = 16 px of a k-step):
-    // 16-lane group g: prototype sub-block s2 = g & 1, k-half g >> 1; lane 4 qq + pp: pixel row qq, prototype quad pp
-    const int tg = lane >> 4, tli = lane & 15, tqq = tli >> 2, tpp = tli & 3;
-    const int ts2 = tg & 1, tkh = tg >> 1;
-
-    if (c_begin < c_end) issue(c_begin);
-    for (long long c = c_begin; c < c_end; ++c) {
-        commit();
-        __syncthreads();
-        issue(c + 1 < c_end ? c + 1 : c);       // always issue (branch-free); the last chunk is re-read and ignored
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int ks = 0; ks < SPX_BK_PX / 16; ++ks) {
-            const int koff = (ks * 16 + 8 * h) * 2;
-            // this lane's pixel rows of the k-step: px = 16 ks + 8 tkh + tqq (+4): kernel-1 wave px >> 5, lane px & 31
-            const int pxa = ks * 16 + 8 * tkh + tqq;
-            const int wsel = pxa >> 5, ra = pxa & 31;
-            const int fo0 = spx_blob_slot(ra, tpp & 1, ts2) * 16 + 8 * (tpp >> 1);
-            const int fo1 = spx_blob_slot(ra + 4, tpp & 1, ts2) * 16 + 8 * (tpp >> 1);
-            bf16x8 xb[2];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) xb[t] = *(const bf16x8*)(Xs + ((2 * cpair + t) * 32 + r) * SPX_BK_ROW + koff);
-#pragma unroll
-            for (int i = 0; i < (DO_P ? PH : 0); ++i) {
-                const int fb = ((wsel * NPB + pb0 + i) * 2 + ts2) * 1024;
-                const bf16x4 g0 = __builtin_bit_cast(bf16x4, lds_tr_read(Gs + fb + fo0));
-                const bf16x4 g1 = __builtin_bit_cast(bf16x4, lds_tr_read(Gs + fb + fo1));
-                const bf16x8 gf = __builtin_shufflevector(g0, g1, 0, 1, 2, 3, 4, 5, 6, 7);
-                if (cs_role) {   // colsum(G): every lane holds 8 px of its prototype row; lanes r, r+32 cover the k-step
-                    float s8 = 0.0f;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) s8 += (float)gf[j];
-                    csum[i] += s8;
-                }
-#pragma unroll
-                for (int t = 0; t < 2; ++t) accp[i][t] = mfma_bf16(gf, xb[t], accp[i][t]);
-            }
-            if (DO_W && w_role) {
-                const int fb = ((wsel * NPB + wave) * 2 + ts2) * 1024;
-                const bf16x4 a0 = __builtin_bit_cast(bf16x4, lds_tr_read(As + fb + fo0));
-                const bf16x4 a1 = __builtin_bit_cast(bf16x4, lds_tr_read(As + fb + fo1));
-                const bf16x8 af = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
-#pragma unroll
-                for (int cb = 0; cb < NCB; ++cb) {
-                    const bf16x8 lf = *(const bf16x8*)(Ls + (cb * 32 + r) * SPX_BK_ROW + koff);
-                    const bf16x8 lf2 = *(const bf16x8*)(Ls2 + (cb * 32 + r) * SPX_BK_ROW + koff);
-                    accw[cb] = mfma_bf16(af, lf, accw[cb]);
-                    accw[cb] = mfma_bf16(af, lf2, accw[cb]);
-                }
-            }
-        }
-        __syncthreads();
-    }
-
-    // ---- write this workgroup's partial slab ----
-    const int ws = spx_bk_wstride(pl);
-    float* slab = a.workspace + ((size_t)split * pl.npanels + q) * rows * ws;
-    if (want_p) {
-#pragma unroll
-        for (int i = 0; i < PH; ++i) {
-            const int pb = pb0 + i;
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int chb = 2 * cpair + t;
-                if (chb < nchb) {
-#pragma unroll
-                    for (int reg = 0; reg < 16; ++reg)
-                        slab[(size_t)(pb * 32 + acc_row(reg, h)) * ws + chb * 32 + r] = accp[i][t][reg];
-                }
-            }
-            if (cs_role) {
-                const float s = csum[i] + __shfl_xor(csum[i], 32);
-                if (h == 0) slab[(size_t)(pb * 32 + r) * ws + nchb * 32 + NCB * 32] = s;
-            }
-        }
-    }
-    if (want_w && w_role) {
-#pragma unroll
-        for (int cb = 0; cb < NCB; ++cb) {
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg)
-                slab[(size_t)(wave * 32 + acc_row(reg, h)) * ws + nchb * 32 + cb * 32 + r] = accw[cb][reg];
-        }
-    }
-}
-
-// kernel 3: fixed-order sum of the slabs, + the p * colsum(G) term.  Four independent partial sums per output
-// (slab j goes to partial j & 3) keep several loads in flight per thread; the order is fixed, so results are
-// run-to-run identical.
-#define SPX_RED_ELEMS 32     // output elements per workgroup
-#define SPX_RED_PARTS 8      // slab ranges summed in parallel per element (256 threads)
-__global__ __launch_bounds__(SPX_RED_ELEMS * SPX_RED_PARTS) void spx_bank_reduce_kernel(const SpxBankBwdArgs a) {
-    __shared__ float red_s[SPX_RED_PARTS][SPX_RED_ELEMS], red_c[SPX_RED_PARTS][SPX_RED_ELEMS];
-    const spx_plan& pl = a.plan;
-    const int Cs = pl.channels_per_scale, K = pl.num_classes, P = pl.num_prototypes;
-    const int nchb = (Cs + 31) / 32;
-    const int rows = pl.npb * 32;
-    const int ws = spx_bk_wstride(pl);
-    const int ncols = Cs + K;
-    const long long n = (long long)pl.npanels * rows * ncols;
-    const int el = threadIdx.x % SPX_RED_ELEMS, part = threadIdx.x / SPX_RED_ELEMS;
-    const long long gid = (long long)blockIdx.x * SPX_RED_ELEMS + el;
-    const bool in = gid < n;
-    const int col = in ? (int)(gid % ncols) : 0;
-    const int row = in ? (int)((gid / ncols) % rows) : 0;
-    const int q = in ? (int)(gid / ((long long)ncols * rows)) : 0;
-    const bool is_p = col < Cs;
-    const bool live = in && row < pl.panel_np[q] && (is_p ? a.d_bank != nullptr : a.d_W != nullptr);
-    const size_t slab_stride = (size_t)pl.npanels * rows * ws;
-    const float* base = a.workspace + ((size_t)q * rows + row) * ws;
-    const int c0 = is_p ? col : nchb * 32 + (col - Cs);
-    const int c1 = nchb * 32 + pl.ncb * 32;          // colsum column
-    // this thread's slab range; inside it slab j goes to partial (j - j0) & 3: a fixed order, so results are
-    // run-to-run identical
-    const int per = (a.nsplit + SPX_RED_PARTS - 1) / SPX_RED_PARTS;
-    const int j0 = part * per, j1 = min(a.nsplit, j0 + per);
-    float s[4] = {0.f, 0.f, 0.f, 0.f}, cs[4] = {0.f, 0.f, 0.f, 0.f};
-    if (live) {
-        int j = j0;
-        for (; j + 4 <= j1; j += 4) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                s[u] += base[(size_t)(j + u) * slab_stride + c0];
-                if (is_p) cs[u] += base[(size_t)(j + u) * slab_stride + c1];
-            }
-        }
-        for (; j < j1; ++j) {
-            s[(j - j0) & 3] += base[(size_t)j * slab_stride + c0];
-            if (is_p) cs[(j - j0) & 3] += base[(size_t)j * slab_stride + c1];
-        }
-    }
-    red_s[part][el] = (s[0] + s[1]) + (s[2] + s[3]);
-    red_c[part][el] = (cs[0] + cs[1]) + (cs[2] + cs[3]);
-    __syncthreads();
-    if (part != 0 || !live) return;
-    float st = 0.0f, ct = 0.0f;
-#pragma unroll
-    for (int i = 0; i < SPX_RED_PARTS; ++i) {
-        st += red_s[i][el];
-        ct += red_c[i][el];
-    }
-    const int p = pl.panel_p0[q] + row;
-    if (is_p) {
-        a.d_bank[(size_t)p * Cs + col] = 2.0f * (a.bank[(size_t)p * Cs + col] * ct - st);
-    } else {
-        a.d_W[(size_t)(col - Cs) * P + p] = 0.69314718056f * st;     // kernel 1's activation blob holds a / ln 2
-    }
-}
-
-template <int NPB, int NCB, bool DO_P, bool DO_W>
-static hipError_t launch_bank_pw(const SpxBankBwdArgs& a, int x_dtype, dim3 grid, hipStream_t s) {
-    constexpr size_t lds = (size_t)spx_bk_lds_bytes<NPB, NCB>();
-    if (x_dtype == 1) {
-        if (a.vec_ok) hipLaunchKernelGGL((spx_bank_bwd_kernel<NPB, NCB, true, true, DO_P, DO_W>), grid, dim3(SPX_BK_THREADS), lds, s, a);
-        else hipLaunchKernelGGL((spx_bank_bwd_kernel<NPB, NCB, true, false, DO_P, DO_W>), grid, dim3(SPX_BK_THREADS), lds, s, a);
-    } else {
-        if (a.vec_ok) hipLaunchKernelGGL((spx_bank_bwd_kernel<NPB, NCB, false, true, DO_P, DO_W>), grid, dim3(SPX_BK_THREADS), lds, s, a);
-        else hipLaunchKernelGGL((spx_bank_bwd_kernel<NPB, NCB, false, false, DO_P, DO_W>), grid, dim3(SPX_BK_THREADS), lds, s, a);
-    }
-    return hipGetLastError();
-}
-template <int NPB, int NCB>
-static hipError_t launch_bank_x(const SpxBankBwdArgs& a, int x_dtype, dim3 grid, hipStream_t s) {
-    if constexpr (NCB < 5) {
-        return launch_bank_pw<NPB, NCB, true, true>(a, x_dtype, grid, s);
-    } else {
-        hipError_t e = hipSuccess;
-        if (a.d_bank) e = launch_bank_pw<NPB, NCB, true, false>(a, x_dtype, grid, s);
-        if (e == hipSuccess && a.d_W) e = launch_bank_pw<NPB, NCB, false, true>(a, x_dtype, grid, s);
-        return e;
-    }
-}
-
-hipError_t spx_launch_bank_bwd(const SpxBankBwdArgs& a, int x_dtype, hipStream_t s) {
-    const spx_plan& pl = a.plan;
-    const int rows = pl.npb * 32;
-    dim3 grid((unsigned)a.nsplit, (unsigned)pl.npanels);
-    hipError_t e;
-    if (pl.ncb == 1)
-        e = pl.npb == 2 ? launch_bank_x<2, 1>(a, x_dtype, grid, s) : pl.npb == 4 ? launch_bank_x<4, 1>(a, x_dtype, grid, s) : launch_bank_x<6, 1>(a, x_dtype, grid, s);
-    else if (pl.ncb == 2)
-        e = pl.npb == 2 ? launch_bank_x<2, 2>(a, x_dtype, grid, s) : pl.npb == 4 ? launch_bank_x<4, 2>(a, x_dtype, grid, s) : launch_bank_x<6, 2>(a, x_dtype, grid, s);
-    else
-        e = pl.npb == 2 ? launch_bank_x<2, 5>(a, x_dtype, grid, s) : pl.npb == 4 ? launch_bank_x<4, 5>(a, x_dtype, grid, s) : launch_bank_x<6, 5>(a, x_dtype, grid, s);
-    if (e != hipSuccess) return e;
-    const long long n = (long long)pl.npanels * rows * (pl.channels_per_scale + pl.num_classes);
-    hipLaunchKernelGGL(spx_bank_reduce_kernel, dim3((unsigned)((n + SPX_RED_ELEMS - 1) / SPX_RED_ELEMS)),
-                       dim3(SPX_RED_ELEMS * SPX_RED_PARTS), 0, s, a);
-    return hipGetLastError();
 }
