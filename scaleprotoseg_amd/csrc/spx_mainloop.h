@@ -223,18 +223,25 @@ struct SpxPipeline {
     // consts_issue / consts_commit stage the panel's epilogue constants (head fragments, |p|^2) into LDS: the
     // loads are issued behind the pipeline's prologue loads and committed after the first barrier, so they share
     // the fill latency instead of adding a serial round trip in front of it.
-    template <typename F, typename G>
-    __device__ __forceinline__ void run_panel(f32x16 (&acc)[NH], float& x2part, const SpxTileCtx& tc, char* smem,
-                                              const char* bank0, int ch0, int Cs, int lane, int wave, int tid,
-                                              F consts_issue, G consts_commit) {
-        const int nchunks = (Cs + SPX_KC - 1) / SPX_KC;
-        const int nrounds = (nchunks + XR - 1) / XR;       // chunks are processed XR at a time
+    // A panel = issue_prologue (global loads of the first chunks + the epilogue constants into registers) followed by
+    // run_body.  Kernels with register room issue the NEXT panel's prologue before the current panel's epilogue, so
+    // its pipeline fill hides behind the epilogue (multi-scale banks run 4+ panels per tile).
+    template <typename F>
+    __device__ __forceinline__ void issue_prologue(const SpxTileCtx& tc, const char* bank0, int ch0, int Cs, int tid,
+                                                   F consts_issue) {
         xs[0].load(tc, ch0, Cs);
         as_[0].load(bank0, true, tid);
 #pragma unroll
         for (int i = 1; i < XR; ++i) xs[i].load(tc, ch0 + i * SPX_KC, Cs - i * SPX_KC);
         as_[1].load(bank0 + CHUNK_BYTES, Cs - SPX_KC > 0, tid);
         consts_issue();      // loads only: they ride behind the pipeline's own prologue loads
+    }
+    template <typename G>
+    __device__ __forceinline__ void run_body(f32x16 (&acc)[NH], float& x2part, const SpxTileCtx& tc, char* smem,
+                                             const char* bank0, int ch0, int Cs, int lane, int wave, int tid,
+                                             G consts_commit) {
+        const int nchunks = (Cs + SPX_KC - 1) / SPX_KC;
+        const int nrounds = (nchunks + XR - 1) / XR;       // chunks are processed XR at a time
         xs[0].write(smem, tid);
         as_[0].write(smem + SPX_STAGE_X_BYTES, tid);
         __syncthreads();
@@ -246,6 +253,13 @@ struct SpxPipeline {
             if (XR > 2) step<2 % XR>(acc, x2part, tc, smem, bank0, ch0, Cs, c + 2, lane, wave, tid);
             if (XR > 2) step<3 % XR>(acc, x2part, tc, smem, bank0, ch0, Cs, c + 3, lane, wave, tid);
         }
+    }
+    template <typename F, typename G>
+    __device__ __forceinline__ void run_panel(f32x16 (&acc)[NH], float& x2part, const SpxTileCtx& tc, char* smem,
+                                              const char* bank0, int ch0, int Cs, int lane, int wave, int tid,
+                                              F consts_issue, G consts_commit) {
+        issue_prologue(tc, bank0, ch0, Cs, tid, consts_issue);
+        run_body(acc, x2part, tc, smem, bank0, ch0, Cs, lane, wave, tid, consts_commit);
     }
 };
 
