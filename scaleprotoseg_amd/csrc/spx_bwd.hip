@@ -170,9 +170,14 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
             for (int reg = 0; reg < 16; ++reg) {
                 const int u = ub * 32 + acc_row(reg, h);
                 const uint32_t so = (uint32_t)((ub * 32 + (reg & 3) + 8 * (reg >> 2)) * 4);
+#ifdef SPX_DIAG_NO_UNIT_IO
+                const float gval = 1.0f;     // timing-only build: prices the [px][unit] loads / stores (results are wrong)
+                dg[reg] *= gval;
+#else
                 const float gval = buf_load_f32(gir, u < K ? voff_u : SPX_OOB, so);
                 dg[reg] *= gval;                                   // dropped loads return 0: padded units / pixels
                 buf_store_f32(dg[reg], dur, u < K ? voff_u : SPX_OOB, so);
+#endif
             }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {

@@ -24,7 +24,7 @@
 // per-wave LDS scratch of the epilogue's distance-tile turn: 32 prototype rows x 32 pixels fp32, 160-B rows (the
 // two half-waves land 32 banks apart: conflict-free writes); aliases the main-loop stages, free after the loop
 #define SPX_FWD_TROW 40
-#define SPX_FWD_TSCRATCH (32 * SPX_FWD_TROW * 4)
+#define SPX_FWD_TSCRATCH 8192           // per wave: >= 32 * SPX_FWD_TROW * 4 (distance turn) and 32 px x 64 values (block I/O)
 // LDS carve (bytes): [stage 0][stage 1][head fragments of the current panel (NCB == 1 only)][|p|^2 of the panel]
 #ifdef SPX_FWD_HEAD_L2
 template <int NPB, int NCB>
@@ -316,11 +316,25 @@ __global__ __launch_bounds__(256 * SPLIT, SPX_FWD_WAVES * SPLIT) void spx_fwd_ke
             for (int reg = 0; reg < 16; ++reg) accl[0][reg] += sc[reg * 64 + lane];
         }
     }
+    // A wave's 32 pixels x n values of a [pixel][n] fp32 tensor (logits, group activations) are ONE contiguous block of
+    // 128 n bytes in memory.  Written value by value from the accumulator layout they are n dword stores per lane with
+    // an n*4-byte lane stride (each instruction touches 32+ cache lines: 0.9 ms per 2 Mpx for n = 57, measured); turned
+    // through the wave's LDS scratch they leave as n/2 fully coalesced dword stores.
+    const int pxw0 = px0 + 32 * pg;
+    float* const bsc = (float*)(smem + wave * SPX_FWD_TSCRATCH);
+    auto block_flush = [&](float* gimg, int n) {      // bsc holds [32][n]; gimg = tensor base of image b
+        const int nvalid = (a.HW - pxw0 < 32 ? (a.HW - pxw0 > 0 ? a.HW - pxw0 : 0) : 32) * n;
+        const spx_rsrc rs = make_rsrc_pred(gimg + (size_t)pxw0 * n);
+#pragma unroll 1
+        for (int i = lane; i < 32 * n; i += 64) buf_store_f32(bsc[i], rs, i < nvalid ? (uint32_t)i * 4u : SPX_OOB, 0);
+    };
+    if (want_head && SPLIT == 2) __syncthreads();     // (split variant: the hand-off scratch above is read before it is reused)
     if (want_head && ph == 0 && a.packed_tail) {
         // grouping-head tail (model_multiscale_group.py:303-308): g = exp(units), logits = W_g . g.  The unit tiles
         // are the B operand of a second split-bf16 product, exactly as the activation tiles were for the head.
         const int K2 = a.K2;
         const spx_rsrc tr = make_rsrc(a.packed_tail);
+        const bool blk = NCB <= 2;                    // 32 px x (<= 64) values fit the scratch
         const spx_rsrc gor = make_rsrc_pred(a.gact ? a.gact + (size_t)b * a.HW * K : nullptr);
         const uint32_t voff_g = px_ok ? ((uint32_t)px * (uint32_t)K + (uint32_t)(4 * h)) * 4u : SPX_OOB;    // [px][unit]
         f32x16 acc2;
@@ -333,7 +347,13 @@ __global__ __launch_bounds__(256 * SPLIT, SPX_FWD_WAVES * SPLIT) void spx_fwd_ke
             for (int reg = 0; reg < 16; ++reg) {
                 const int u = cb * 32 + acc_row(reg, h);
                 gv[reg] = u < K ? __builtin_amdgcn_exp2f(accl[cb][reg] * 1.44269504089f) : 0.0f;
-                if (a.gact) buf_store_f32(gv[reg], gor, u < K ? voff_g : SPX_OOB, (uint32_t)((cb * 32 + (reg & 3) + 8 * (reg >> 2)) * 4));
+                if (a.gact) {
+                    if (blk) {
+                        if (u < K) bsc[r * K + u] = gv[reg];
+                    } else {
+                        buf_store_f32(gv[reg], gor, u < K ? voff_g : SPX_OOB, (uint32_t)((cb * 32 + (reg & 3) + 8 * (reg >> 2)) * 4));
+                    }
+                }
             }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
@@ -353,20 +373,31 @@ __global__ __launch_bounds__(256 * SPLIT, SPX_FWD_WAVES * SPLIT) void spx_fwd_ke
                 acc2 = mfma_bf16(whi, glo, acc2);
             }
         }
-        const spx_rsrc lr = make_rsrc_pred(a.logits + (size_t)b * a.HW * K2);
-        const uint32_t voff_l = px_ok ? ((uint32_t)px * (uint32_t)K2 + (uint32_t)(4 * h)) * 4u : SPX_OOB;   // [px][class]
+        if (a.gact && blk) block_flush(a.gact + (size_t)b * a.HW * K, K);
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg)
-            buf_store_f32(acc2[reg], lr, acc_row(reg, h) < K2 ? voff_l : SPX_OOB, (uint32_t)(((reg & 3) + 8 * (reg >> 2)) * 4));
+            if (acc_row(reg, h) < K2) bsc[r * K2 + acc_row(reg, h)] = acc2[reg];
+        block_flush(a.logits + (size_t)b * a.HW * K2, K2);
     } else if (want_head && ph == 0) {
-        const spx_rsrc lr = make_rsrc_pred(a.logits + (size_t)b * a.HW * K);
-        const uint32_t voff_l = px_ok ? ((uint32_t)px * (uint32_t)K + (uint32_t)(4 * h)) * 4u : SPX_OOB;   // [px][class]
+        if (NCB <= 2) {
 #pragma unroll
-        for (int cb = 0; cb < NCB; ++cb) {
+            for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int cls = cb * 32 + acc_row(reg, h);
-                buf_store_f32(accl[cb][reg], lr, cls < K ? voff_l : SPX_OOB, (uint32_t)((cb * 32 + (reg & 3) + 8 * (reg >> 2)) * 4));
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int cls = cb * 32 + acc_row(reg, h);
+                    if (cls < K) bsc[r * K + cls] = accl[cb][reg];
+                }
+            block_flush(a.logits + (size_t)b * a.HW * K, K);
+        } else {
+            const spx_rsrc lr = make_rsrc_pred(a.logits + (size_t)b * a.HW * K);
+            const uint32_t voff_l = px_ok ? ((uint32_t)px * (uint32_t)K + (uint32_t)(4 * h)) * 4u : SPX_OOB;   // [px][class]
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) {
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int cls = cb * 32 + acc_row(reg, h);
+                    buf_store_f32(accl[cb][reg], lr, cls < K ? voff_l : SPX_OOB, (uint32_t)((cb * 32 + (reg & 3) + 8 * (reg >> 2)) * 4));
+                }
             }
         }
     }
