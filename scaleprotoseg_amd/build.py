@@ -10,8 +10,9 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libspx_hip.so")
-SOURCES = ["spx_api.hip", "spx_fwd.hip", "spx_bwd.hip", "spx_bank.hip", "spx_pack.hip", "spx_push.hip", "spx_eval.hip"]
-HEADERS = ["spx_common.h", "spx_args.h", "spx_mainloop.h", os.path.join("..", "..", "include", "spx_hip.h")]
+SOURCES = ["spx_api.hip", "spx_fwd_npb2.hip", "spx_fwd_npb4.hip", "spx_fwd_npb6.hip", "spx_bwd_npb2.hip", "spx_bwd_npb4.hip",
+           "spx_bwd_npb6.hip", "spx_bank.hip", "spx_pack.hip", "spx_push.hip", "spx_eval.hip"]
+HEADERS = ["spx_common.h", "spx_args.h", "spx_mainloop.h", "spx_fwd_impl.h", "spx_bwd_impl.h", os.path.join("..", "..", "include", "spx_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off"]
 FLAGS += os.environ.get("SPX_EXTRA_HIPCC_FLAGS", "").split()
 
@@ -49,7 +50,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         if r.returncode != 0:
             raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
 
-    with ThreadPoolExecutor(max_workers=min(4, max(1, len(jobs)))) as ex:
+    with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
         list(ex.map(run, jobs))
     objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in SOURCES]
     if force or jobs or _stale(LIB, objs):

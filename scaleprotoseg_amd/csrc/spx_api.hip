@@ -37,6 +37,19 @@ static int x_vec_ok(const void* x, int x_dtype, int HW) {
     return HW % 8 == 0;   /* staging pieces are 8 pixels: they must be wholly inside or outside an image row */
 }
 
+hipError_t spx_launch_fwd_npb2(const SpxFwdArgs& a, int x_dtype, hipStream_t s);
+hipError_t spx_launch_fwd_npb4(const SpxFwdArgs& a, int x_dtype, hipStream_t s);
+hipError_t spx_launch_fwd_npb6(const SpxFwdArgs& a, int x_dtype, hipStream_t s);
+hipError_t spx_launch_bwd_npb2(const SpxBwdArgs& a, int x_dtype, hipStream_t s);
+hipError_t spx_launch_bwd_npb4(const SpxBwdArgs& a, int x_dtype, hipStream_t s);
+hipError_t spx_launch_bwd_npb6(const SpxBwdArgs& a, int x_dtype, hipStream_t s);
+hipError_t spx_launch_fwd(const SpxFwdArgs& a, int x_dtype, hipStream_t s) {
+    return a.plan.npb == 2 ? spx_launch_fwd_npb2(a, x_dtype, s) : a.plan.npb == 4 ? spx_launch_fwd_npb4(a, x_dtype, s) : spx_launch_fwd_npb6(a, x_dtype, s);
+}
+hipError_t spx_launch_bwd(const SpxBwdArgs& a, int x_dtype, hipStream_t s) {
+    return a.plan.npb == 2 ? spx_launch_bwd_npb2(a, x_dtype, s) : a.plan.npb == 4 ? spx_launch_bwd_npb4(a, x_dtype, s) : spx_launch_bwd_npb6(a, x_dtype, s);
+}
+
 extern "C" {
 
 int spx_version(void) { return SPX_ABI_VERSION; }

@@ -1,4 +1,4 @@
-// Backward, parameter side (kernels 2 and 3 of the backward; kernel 1 = spx_bwd.hip, whose header describes the
+// Backward, parameter side (kernels 2 and 3 of the backward; kernel 1 = spx_bwd_impl.h, whose header describes the
 // G / a fragment blobs consumed here).
 #include "spx_args.h"
 #include "spx_common.h"

@@ -20,6 +20,7 @@
 // Kernel 2 (parameter side, spx_bank_bwd_kernel): pixel-split MFMA reduction G^T.X and a^T.dLogits; the blobs
 // are laid out [pixel][prototype] in LDS and read back with ds_read_b64_tr_b16 (pixel becomes the MFMA k).
 // Per-workgroup fp32 partial slabs, summed in a fixed order by kernel 3 (no float atomics).
+#pragma once
 #include "spx_args.h"
 #include "spx_mainloop.h"
 #include <type_traits>
@@ -59,16 +60,13 @@ __host__ __device__ constexpr int spx_bwd_lds_bytes() {
 }
 static_assert(spx_bwd_lds_bytes<6, 1>() <= 80 * 1024, "pixel kernel must fit two workgroups per CU");
 // bf16 elements of one G (or a) scratch: [panel][tile][wave][pb][s2] fragments of 512 elements
-size_t spx_bwd_scratch_elems(const spx_plan& pl, int B, int HW) {
-    const size_t tiles = (size_t)B * ((HW + SPX_TILE_PX - 1) / SPX_TILE_PX);
-    return (size_t)pl.npanels * tiles * 4 * pl.npb * 2 * 512;
-}
 
 // ------------------------------------------------------------------------------------------------
 // kernel 1: pixel side
 // ------------------------------------------------------------------------------------------------
 // GATHER: the distance gradient arrives class-gathered ([B, HW, J], spx_dist_bwd_cls) instead of P-wide.
-template <int NPB, int NCB, bool XF32, bool VEC, bool GATHER>
+// DACT: a gradient arrives on the [pixel][P] activations (kept out of the default instance).
+template <int NPB, int NCB, bool XF32, bool VEC, bool GATHER, bool DACT>
 __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const spx_plan& pl = a.plan;
@@ -390,13 +388,24 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
                         ga = mfma_bf16(whi, dllo[c], ga);
                     }
                 }
-                if (a.d_act) {   // group phase only: gradient arriving on the activations
+                if (DACT) {   // gradient arriving on the activations ([pixel][P] rows)
+                    // loaded with a prototype column per lane (two 128-B row pieces per instruction, all 16 loads in
+                    // flight), turned through the wave's LDS scratch into the accumulator layout (pixel per lane)
                     const spx_rsrc dar = make_rsrc_pred(a.d_act + (size_t)b * a.HW * P + p0 + pb * 32);
+                    float* const sc = (float*)(smem + wave * 4352);     // 32 x 33 floats + pad; the stages are idle in phase 1
+                    const int col = lane & 31;
+                    const bool col_ok = pb * 32 + col < np;
+                    float dv[16];
 #pragma unroll
-                    for (int reg = 0; reg < 16; ++reg) {
-                        const int rb = (reg & 3) + 8 * (reg >> 2);
-                        ga[reg] = __builtin_fmaf(act_c1, buf_load_f32(dar, (full || (pb * 32 + rb + 4 * h < np)) ? voff_a : SPX_OOB, (uint32_t)(rb * 4)), ga[reg]);
+                    for (int q = 0; q < 16; ++q) {
+                        const int pxs = px0 + 32 * wave + 2 * q + (lane >> 5);
+                        dv[q] = buf_load_f32(dar, (col_ok && pxs < a.HW) ? ((uint32_t)pxs * (uint32_t)P + (uint32_t)col) * 4u : SPX_OOB, 0);
                     }
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) sc[(2 * q + (lane >> 5)) * 33 + col] = dv[q];
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg)
+                        ga[reg] = __builtin_fmaf(act_c1, sc[r * 33 + (reg & 3) + 8 * (reg >> 2) + 4 * h], ga[reg]);
                 }
                 // straight-line element math, no per-element control flow: d, 1/((d+1)(d+eps)), a / ln 2, then G
                 float dr[16], rpv[16], av[16];
@@ -547,6 +556,7 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
         };
         bt_load(0);
         x_load(0);
+        if (DACT) __syncthreads();     // the dAct scratch of slower waves sits where the P^T stages go
         bt_write(0);
         __syncthreads();
         for (int chb = 0; chb < nchb; ++chb) {
@@ -676,39 +686,33 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
 #endif
 }
 
-template <int NPB, int NCB, bool GATHER>
-static hipError_t launch_bwd_g(const SpxBwdArgs& a, int x_dtype, dim3 grid, hipStream_t s) {
+template <int NPB, int NCB, bool GATHER, bool DACT>
+static hipError_t launch_bwd_gd(const SpxBwdArgs& a, int x_dtype, dim3 grid, hipStream_t s) {
     constexpr size_t lds = (size_t)spx_bwd_lds_bytes<NPB, NCB>();
     if (x_dtype == 1) {
-        if (a.vec_ok) hipLaunchKernelGGL((spx_bwd_kernel<NPB, NCB, true, true, GATHER>), grid, dim3(256), lds, s, a);
-        else hipLaunchKernelGGL((spx_bwd_kernel<NPB, NCB, true, false, GATHER>), grid, dim3(256), lds, s, a);
+        if (a.vec_ok) hipLaunchKernelGGL((spx_bwd_kernel<NPB, NCB, true, true, GATHER, DACT>), grid, dim3(256), lds, s, a);
+        else hipLaunchKernelGGL((spx_bwd_kernel<NPB, NCB, true, false, GATHER, DACT>), grid, dim3(256), lds, s, a);
     } else {
-        if (a.vec_ok) hipLaunchKernelGGL((spx_bwd_kernel<NPB, NCB, false, true, GATHER>), grid, dim3(256), lds, s, a);
-        else hipLaunchKernelGGL((spx_bwd_kernel<NPB, NCB, false, false, GATHER>), grid, dim3(256), lds, s, a);
+        if (a.vec_ok) hipLaunchKernelGGL((spx_bwd_kernel<NPB, NCB, false, true, GATHER, DACT>), grid, dim3(256), lds, s, a);
+        else hipLaunchKernelGGL((spx_bwd_kernel<NPB, NCB, false, false, GATHER, DACT>), grid, dim3(256), lds, s, a);
     }
     return hipGetLastError();
 }
 template <int NPB, int NCB>
 static hipError_t launch_bwd_x(const SpxBwdArgs& a, int x_dtype, dim3 grid, hipStream_t s) {
-    if (a.labels) return launch_bwd_g<NPB, NCB, true>(a, x_dtype, grid, s);
-    return launch_bwd_g<NPB, NCB, false>(a, x_dtype, grid, s);
+    if (a.labels) return a.d_act ? launch_bwd_gd<NPB, NCB, true, true>(a, x_dtype, grid, s)
+                                 : launch_bwd_gd<NPB, NCB, true, false>(a, x_dtype, grid, s);
+    return a.d_act ? launch_bwd_gd<NPB, NCB, false, true>(a, x_dtype, grid, s)
+                   : launch_bwd_gd<NPB, NCB, false, false>(a, x_dtype, grid, s);
 }
 
-hipError_t spx_launch_bwd(const SpxBwdArgs& a, int x_dtype, hipStream_t s) {
+// one translation unit per panel height, so the variants compile in parallel
+template <int NPB>
+static hipError_t spx_launch_bwd_npb(const SpxBwdArgs& a, int x_dtype, hipStream_t s) {
     const spx_plan& pl = a.plan;
     const int tiles = (a.HW + SPX_TILE_PX - 1) / SPX_TILE_PX;
     dim3 grid((unsigned)(tiles * a.B));
-    if (pl.ncb == 1) {
-        if (pl.npb == 2) return launch_bwd_x<2, 1>(a, x_dtype, grid, s);
-        if (pl.npb == 4) return launch_bwd_x<4, 1>(a, x_dtype, grid, s);
-        return launch_bwd_x<6, 1>(a, x_dtype, grid, s);
-    }
-    if (pl.ncb == 2) {
-        if (pl.npb == 2) return launch_bwd_x<2, 2>(a, x_dtype, grid, s);
-        if (pl.npb == 4) return launch_bwd_x<4, 2>(a, x_dtype, grid, s);
-        return launch_bwd_x<6, 2>(a, x_dtype, grid, s);
-    }
-    if (pl.npb == 2) return launch_bwd_x<2, 5>(a, x_dtype, grid, s);
-    if (pl.npb == 4) return launch_bwd_x<4, 5>(a, x_dtype, grid, s);
-    return launch_bwd_x<6, 5>(a, x_dtype, grid, s);
+    if (pl.ncb == 1) return launch_bwd_x<NPB, 1>(a, x_dtype, grid, s);
+    if (pl.ncb == 2) return launch_bwd_x<NPB, 2>(a, x_dtype, grid, s);
+    return launch_bwd_x<NPB, 5>(a, x_dtype, grid, s);
 }

@@ -3,6 +3,7 @@
 //   activations = log((d+1)/(d+eps)) | -d                  (:324-330)
 //   logits = activations . W^T                             (:243-244, :369-376)
 // one launch, one pass over X, distances written once in the reference's [B,P,H,W] layout.
+#pragma once
 #include "spx_args.h"
 #include "spx_mainloop.h"
 
@@ -49,8 +50,10 @@ __host__ __device__ constexpr int spx_fwd_lds_bytes() {
 // that a two-wave SIMD leaves exposed (the kernel was issue-stalled, not bandwidth-bound: MFMA 17 % + VALU ~42 %
 // busy); the two halves' logits partials meet in LDS at the end.
 // GATHER: class-gathered distances (spx_dist_fwd_cls) instead of the P-wide map.
-template <int NPB, int NCB, bool XF32, bool VEC, int SPLIT, bool GATHER>
-__global__ __launch_bounds__(256 * SPLIT, SPX_FWD_WAVES * SPLIT) void spx_fwd_kernel(const SpxFwdArgs a) {
+// (2-block panels with a one-block head fit 168 VGPRs: three waves per SIMD.)
+// ACT: the [pixel][P] activation output is requested (kept out of the default instance: its code costs registers).
+template <int NPB, int NCB, bool XF32, bool VEC, int SPLIT, bool GATHER, bool ACT>
+__global__ __launch_bounds__(256 * SPLIT, (NPB == 2 && NCB == 1 ? 3 : SPX_FWD_WAVES) * SPLIT) void spx_fwd_kernel(const SpxFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NT = 256 * SPLIT, NH = NPB / SPLIT;
     static_assert(NPB % SPLIT == 0, "blocks must split evenly over the waves of a pixel group");
@@ -165,7 +168,7 @@ __global__ __launch_bounds__(256 * SPLIT, SPX_FWD_WAVES * SPLIT) void spx_fwd_ke
             const f32x16 tile = tile_get<NH>(acc, pbl);
             if (pb * 32 < np) {
                 const spx_rsrc dr = make_rsrc_pred(a.dist ? a.dist + ((size_t)b * P + p0 + pb * 32) * a.HW : nullptr);
-                const spx_rsrc ar = make_rsrc_pred(a.act ? a.act + (size_t)b * a.HW * P + p0 + pb * 32 : nullptr);
+                const spx_rsrc ar = make_rsrc_pred(ACT ? a.act + (size_t)b * a.HW * P + p0 + pb * 32 : nullptr);
                 const bool full = pb * 32 + 32 <= np;       // wave-uniform: no per-row predication needed
                 // all arithmetic first (one straight-line block), then the stores under wave-uniform conditions
                 float dv[16], av[16];
@@ -226,12 +229,21 @@ __global__ __launch_bounds__(256 * SPLIT, SPX_FWD_WAVES * SPLIT) void spx_fwd_ke
                         buf_store_f32(dv[reg], dr, vo, (uint32_t)rb * HW * 4u);
                     }
                 }
-                if (a.act) {
+                if (ACT) {
+                    // [pixel][P] rows: with a pixel per lane a store instruction scatters 64 dwords over 64 rows
+                    // (0.6 ms of pattern cost per 2 Mpx, measured).  Turned through the wave's scratch a lane owns
+                    // one prototype column: each instruction writes two 128-B row pieces.
+                    float* const sc = (float*)(smem + wave * SPX_FWD_TSCRATCH);
 #pragma unroll
-                    for (int reg = 0; reg < 16; ++reg) {
-                        const int rb = (reg & 3) + 8 * (reg >> 2);
-                        const uint32_t vo = (full || (pb * 32 + rb + 4 * h < np)) ? voff_a : SPX_OOB;
-                        buf_store_f32(av[reg], ar, vo, (uint32_t)(rb * 4));
+                    for (int reg = 0; reg < 16; ++reg) sc[r * 33 + (reg & 3) + 8 * (reg >> 2) + 4 * h] = av[reg];
+                    const int col = lane & 31;                                  // prototype inside the block
+                    const bool col_ok = pb * 32 + col < np;
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const int pl_ = 2 * q + (lane >> 5);                    // pixel inside the wave's 32
+                        const int pxs = px0 + 32 * pg + pl_;
+                        const uint32_t vo = (col_ok && pxs < a.HW) ? ((uint32_t)pxs * (uint32_t)P + (uint32_t)col) * 4u : SPX_OOB;
+                        buf_store_f32(sc[pl_ * 33 + col], ar, vo, 0);
                     }
                 }
                 if (want_head) {
@@ -412,46 +424,37 @@ __global__ __launch_bounds__(256 * SPLIT, SPX_FWD_WAVES * SPLIT) void spx_fwd_ke
 #endif
 }
 
-template <int NPB, int NCB, int SPLIT, bool GATHER>
-static hipError_t launch_fwd_g(const SpxFwdArgs& a, int x_dtype, dim3 grid, hipStream_t s) {
+template <int NPB, int NCB, int SPLIT, bool GATHER, bool ACT>
+static hipError_t launch_fwd_ga(const SpxFwdArgs& a, int x_dtype, dim3 grid, hipStream_t s) {
     constexpr size_t lds = (size_t)spx_fwd_lds_bytes<NPB, NCB, SPLIT>();
     const dim3 blk(256 * SPLIT);
     if (x_dtype == 1) {
-        if (a.vec_ok) hipLaunchKernelGGL((spx_fwd_kernel<NPB, NCB, true, true, SPLIT, GATHER>), grid, blk, lds, s, a);
-        else hipLaunchKernelGGL((spx_fwd_kernel<NPB, NCB, true, false, SPLIT, GATHER>), grid, blk, lds, s, a);
+        if (a.vec_ok) hipLaunchKernelGGL((spx_fwd_kernel<NPB, NCB, true, true, SPLIT, GATHER, ACT>), grid, blk, lds, s, a);
+        else hipLaunchKernelGGL((spx_fwd_kernel<NPB, NCB, true, false, SPLIT, GATHER, ACT>), grid, blk, lds, s, a);
     } else {
-        if (a.vec_ok) hipLaunchKernelGGL((spx_fwd_kernel<NPB, NCB, false, true, SPLIT, GATHER>), grid, blk, lds, s, a);
-        else hipLaunchKernelGGL((spx_fwd_kernel<NPB, NCB, false, false, SPLIT, GATHER>), grid, blk, lds, s, a);
+        if (a.vec_ok) hipLaunchKernelGGL((spx_fwd_kernel<NPB, NCB, false, true, SPLIT, GATHER, ACT>), grid, blk, lds, s, a);
+        else hipLaunchKernelGGL((spx_fwd_kernel<NPB, NCB, false, false, SPLIT, GATHER, ACT>), grid, blk, lds, s, a);
     }
     return hipGetLastError();
 }
 template <int NPB, int NCB, int SPLIT>
 static hipError_t launch_fwd_x(const SpxFwdArgs& a, int x_dtype, dim3 grid, hipStream_t s) {
-    if (a.labels) return launch_fwd_g<NPB, NCB, SPLIT, true>(a, x_dtype, grid, s);
-    return launch_fwd_g<NPB, NCB, SPLIT, false>(a, x_dtype, grid, s);
+    if (a.labels) return a.act ? launch_fwd_ga<NPB, NCB, SPLIT, true, true>(a, x_dtype, grid, s)
+                               : launch_fwd_ga<NPB, NCB, SPLIT, true, false>(a, x_dtype, grid, s);
+    return a.act ? launch_fwd_ga<NPB, NCB, SPLIT, false, true>(a, x_dtype, grid, s)
+                 : launch_fwd_ga<NPB, NCB, SPLIT, false, false>(a, x_dtype, grid, s);
 }
 
-hipError_t spx_launch_fwd(const SpxFwdArgs& a, int x_dtype, hipStream_t s) {
+// one translation unit per panel height (SPX_TU_NPB), so the variants compile in parallel
+template <int NPB>
+static hipError_t spx_launch_fwd_npb(const SpxFwdArgs& a, int x_dtype, hipStream_t s) {
     const spx_plan& pl = a.plan;
     const int tiles = (a.HW + SPX_TILE_PX - 1) / SPX_TILE_PX;
     dim3 grid((unsigned)(tiles * a.B));
-    if (pl.ncb == 1) {
-        // SPX_FWD_SPLIT 2 = 8-wave workgroups (4 waves per SIMD).  Measured on MI355X at the north-star shape:
-        // 0.84 ms against 0.72 ms for SPLIT 1 -- the kernel is bound by VALU issue throughput (one wave64 VALU
-        // instruction per 4 SIMD cycles, ~2300 of them per wave-tile) plus the MFMA pipe, not by exposed latency,
-        // so more waves per SIMD only add barrier and staging overhead.
-        if (pl.npb == 2) return launch_fwd_x<2, 1, SPX_FWD_SPLIT>(a, x_dtype, grid, s);
-        if (pl.npb == 4) return launch_fwd_x<4, 1, SPX_FWD_SPLIT>(a, x_dtype, grid, s);
-        return launch_fwd_x<6, 1, SPX_FWD_SPLIT>(a, x_dtype, grid, s);
-    }
-    if (pl.ncb == 2) {
-        // 33..64 head rows (the grouping head: 3 groups x 19 / 21 classes), head fragments from L2
-        if (pl.npb == 2) return launch_fwd_x<2, 2, 1>(a, x_dtype, grid, s);
-        if (pl.npb == 4) return launch_fwd_x<4, 2, 1>(a, x_dtype, grid, s);
-        return launch_fwd_x<6, 2, 1>(a, x_dtype, grid, s);
-    }
-    // up to 160 classes: 80 logits accumulators per lane, one wave per pixel group
-    if (pl.npb == 2) return launch_fwd_x<2, 5, 1>(a, x_dtype, grid, s);
-    if (pl.npb == 4) return launch_fwd_x<4, 5, 1>(a, x_dtype, grid, s);
-    return launch_fwd_x<6, 5, 1>(a, x_dtype, grid, s);
+    // SPX_FWD_SPLIT 2 = 8-wave workgroups (4 waves per SIMD): measured 0.84 vs 0.72 ms at the north-star shape, off
+    if (pl.ncb == 1) return launch_fwd_x<NPB, 1, SPX_FWD_SPLIT>(a, x_dtype, grid, s);
+    // 33..64 head rows (the grouping head: 3 groups x 19 / 21 classes)
+    if (pl.ncb == 2) return launch_fwd_x<NPB, 2, 1>(a, x_dtype, grid, s);
+    // up to 160 classes: 80 logits accumulators per lane
+    return launch_fwd_x<NPB, 5, 1>(a, x_dtype, grid, s);
 }

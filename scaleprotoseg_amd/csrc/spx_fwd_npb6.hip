@@ -1,0 +1,3 @@
+// Forward kernel instances for 6-block panels (see spx_fwd_impl.h).
+#include "spx_fwd_impl.h"
+hipError_t spx_launch_fwd_npb6(const SpxFwdArgs& a, int x_dtype, hipStream_t s) { return spx_launch_fwd_npb<6>(a, x_dtype, s); }
