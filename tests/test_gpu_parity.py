@@ -468,6 +468,11 @@ def test_argument_errors():
         proto_head_forward(torch.rand(1, 64, 4, 4, device=dev), bank, torch.rand(6, 40, device=dev), lay)
     with pytest.raises(spx.SpxError, match="empty input"):
         proto_head_forward(torch.rand(0, 64, 4, 4, device=dev), bank, head, lay)
+    # maximum size: P * H * W must stay below 2^29 (32-bit byte offsets inside one image of the distance map)
+    big = _layout(190, 19, 1, 16, {0: (0, 190)})
+    with pytest.raises(spx.SpxError, match="too large"):
+        proto_head_forward(torch.zeros(1, 16, 1700, 1700, device=dev, dtype=torch.bfloat16), torch.rand(190, 16, 1, 1, device=dev),
+                           torch.rand(19, 190, device=dev), big)
     # P % num_scales != 0 with the reference's own scale table (Ps = P // S: 189 of 190 rows covered,
     # model_multiscale.py:146-149): its forward raises at F.linear, the plan is rejected here
     with pytest.raises(spx.SpxError):
