@@ -651,7 +651,7 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
                 }
             }
         }
-        clear_acc();       // the next panel accumulates from zero
+        if (panel + 1 < pl.npanels) clear_acc();       // the next panel (if any) accumulates from zero
         __syncthreads();   // T tiles / P^T stages are rewritten by the next panel's main loop
     };
 

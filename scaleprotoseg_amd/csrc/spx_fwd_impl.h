@@ -277,11 +277,13 @@ __global__ __launch_bounds__(256 * SPLIT, (NPB == 2 && NCB == 1 ? 3 : SPX_FWD_WA
                 }
             }
         }
-        // the next panel accumulates from zero
+        // the next panel (if any) accumulates from zero
+        if (panel + 1 < pl.npanels) {
 #pragma unroll
-        for (int pb = 0; pb < NH; ++pb)
+            for (int pb = 0; pb < NH; ++pb)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[pb][i] = 0.0f;
+                for (int i = 0; i < 16; ++i) acc[pb][i] = 0.0f;
+        }
     };
 
 #ifdef SPX_DIAG_STAMPS
