@@ -35,7 +35,7 @@ extern "C" {
 #endif
 
 #define SPX_MAX_PANELS 64   /* (scale, <=192-prototype block) work units per pixel tile */
-#define SPX_ABI_VERSION 3
+#define SPX_ABI_VERSION 4
 
 /* How the prototype bank is cut into MFMA panels.  Filled by spx_make_plan(). */
 typedef struct spx_plan {
@@ -176,6 +176,26 @@ int spx_push_argmin(const float* distances, const int32_t* labels, const float* 
 /* Lexicographic (value, image) argmin over images per prototype: tot_dist.argmin(dim=0),
  * push_multiscale_optimization.py:135-137.  values fp32 [N, P] -> best int64 [P]. */
 int spx_argmin_images(const float* values, int32_t N, int32_t P, int64_t* best, void* stream);
+
+/* KLD loss over class-gathered distances (segmentation/model/loss.py:51-146).  vals fp32 [B, J, HW]
+ * (the slot planes of spx_dist_fwd_cls), labels int32 [B, HW].  A segment = (image, class).  Four streaming passes,
+ * each reading vals once; all segment reductions use integer atomics (run-to-run identical results):
+ *   spx_kld_segment_max    smax_keys uint32 [B, K, J] (caller zero-fills): ordered key of max_px vals over the segment
+ *                          (key k -> float: k & 0x80000000 ? k ^ 0x80000000 : ~k)
+ *   spx_kld_segment_sumexp ssum_fx uint64 [B, K, J] (zero-filled): sum_px exp(vals - smax) * 2^40
+ *   spx_kld_pair_sums      a_fx int64 [B, K, J, J] (zero-filled): sum_px p_j * l_k * scale, l = vals - lse (the
+ *                          log_softmax over the segment's pixels, loss.py:110), p = exp(l)
+ *   spx_kld_backward       grad fp32 [B, J, HW] = dLoss/dvals given A = a_fx / scale and Cf = dLoss/dA [B, K, J, J]
+ * The [B, K, J, J]-sized algebra between the passes (loss.py:113-142: symmetric KL of the slot pairs of one scale,
+ * exp(-kld), mean) is left to the caller.  J <= 16 and K*J*J*8 bytes must fit the LDS table (~60 KiB). */
+int spx_kld_segment_max(const float* vals, const int32_t* labels, int32_t B, int32_t J, int32_t HW, int32_t K,
+                        uint32_t* smax_keys, void* stream);
+int spx_kld_segment_sumexp(const float* vals, const int32_t* labels, int32_t B, int32_t J, int32_t HW, int32_t K,
+                           const float* smax, uint64_t* ssum_fx, void* stream);
+int spx_kld_pair_sums(const float* vals, const int32_t* labels, int32_t B, int32_t J, int32_t HW, int32_t K,
+                      const float* lse, double scale, int64_t* a_fx, void* stream);
+int spx_kld_backward(const float* vals, const int32_t* labels, int32_t B, int32_t J, int32_t HW, int32_t K,
+                     const float* lse, const float* A, const float* Cf, float* grad, void* stream);
 
 /* Evaluation maps: F.interpolate(src, size=(H, W), mode="bilinear", align_corners=False) followed
  * by argmin (take_max = 0) or argmax (take_max = 1) over the channel dimension, without materialising the

@@ -15,7 +15,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libspx_hip.so")
 SPX_MAX_PANELS = 64
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class SpxError(RuntimeError):
@@ -69,6 +69,10 @@ SIGNATURES = {
     "spx_bank_bwd": (C.c_int, [_PP, _V, _I, _I, _I, _V, _V, _V, _V, _V, _V, _V, _V]),
     "spx_push_argmin": (C.c_int, [_V, _V, _V, _I, _I, _I, _I, _I, _F, _V, _V, _V, _V]),
     "spx_argmin_images": (C.c_int, [_V, _I, _I, _V, _V]),
+    "spx_kld_segment_max": (C.c_int, [_V, _V, _I, _I, _I, _I, _V, _V]),
+    "spx_kld_segment_sumexp": (C.c_int, [_V, _V, _I, _I, _I, _I, _V, _V, _V]),
+    "spx_kld_pair_sums": (C.c_int, [_V, _V, _I, _I, _I, _I, _V, C.c_double, _V, _V]),
+    "spx_kld_backward": (C.c_int, [_V, _V, _I, _I, _I, _I, _V, _V, _V, _V, _V]),
     "spx_upsample_argext": (C.c_int, [_V, _I, _I, _I, _I, _I, _I, _I, _V, _V, _V]),
 }
 

@@ -352,4 +352,36 @@ int spx_upsample_argext(const float* src, int32_t N, int32_t C, int32_t h, int32
                                                  (hipStream_t)stream), "spx_upsample_argext");
 }
 
+static int kld_check(const char* who, const float* vals, const int32_t* labels, int32_t B, int32_t J, int32_t HW, int32_t K,
+                     const void* out, int pairs) {
+    if (!vals || !labels || !out) return fail("%s: NULL buffer", who);
+    if (B < 1 || B > 65535 || HW < 1 || K < 1 || J < 1 || J > 16) return fail("%s: bad sizes (B=%d HW=%d K=%d J=%d; J <= 16)", who, B, HW, K, J);
+    if ((long long)J * HW >= (1LL << 31)) return fail("%s: J*HW too large", who);
+    const long long lds = pairs ? (long long)K * J * J * 8 + (long long)K * J * 8 : (long long)K * J * 8;
+    if (lds > 60 * 1024) return fail("%s: K*J*J = %d exceeds the LDS table (use the torch path)", who, K * J * J);
+    return 0;
+}
+
+int spx_kld_segment_max(const float* vals, const int32_t* labels, int32_t B, int32_t J, int32_t HW, int32_t K,
+                        uint32_t* smax_keys, void* stream) {
+    if (kld_check("spx_kld_segment_max", vals, labels, B, J, HW, K, smax_keys, 0)) return 1;
+    return hip_status(spx_launch_kld(0, vals, labels, B, J, HW, K, nullptr, nullptr, nullptr, 0.0, smax_keys, (hipStream_t)stream), "spx_kld_segment_max");
+}
+int spx_kld_segment_sumexp(const float* vals, const int32_t* labels, int32_t B, int32_t J, int32_t HW, int32_t K,
+                           const float* smax, uint64_t* ssum_fx, void* stream) {
+    if (kld_check("spx_kld_segment_sumexp", vals, labels, B, J, HW, K, ssum_fx, 0) || !smax) return smax ? 1 : fail("spx_kld_segment_sumexp: NULL smax");
+    return hip_status(spx_launch_kld(1, vals, labels, B, J, HW, K, smax, nullptr, nullptr, 0.0, ssum_fx, (hipStream_t)stream), "spx_kld_segment_sumexp");
+}
+int spx_kld_pair_sums(const float* vals, const int32_t* labels, int32_t B, int32_t J, int32_t HW, int32_t K,
+                      const float* lse, double scale, int64_t* a_fx, void* stream) {
+    if (kld_check("spx_kld_pair_sums", vals, labels, B, J, HW, K, a_fx, 1) || !lse) return lse ? 1 : fail("spx_kld_pair_sums: NULL lse");
+    return hip_status(spx_launch_kld(2, vals, labels, B, J, HW, K, lse, nullptr, nullptr, scale, a_fx, (hipStream_t)stream), "spx_kld_pair_sums");
+}
+int spx_kld_backward(const float* vals, const int32_t* labels, int32_t B, int32_t J, int32_t HW, int32_t K,
+                     const float* lse, const float* A, const float* Cf, float* grad, void* stream) {
+    if (kld_check("spx_kld_backward", vals, labels, B, J, HW, K, grad, 1)) return 1;
+    if (!lse || !A || !Cf) return fail("spx_kld_backward: NULL table");
+    return hip_status(spx_launch_kld(3, vals, labels, B, J, HW, K, lse, A, Cf, 0.0, grad, (hipStream_t)stream), "spx_kld_backward");
+}
+
 }  // extern "C"

@@ -1,0 +1,227 @@
+// KLD loss over class-gathered distances (reference: segmentation/model/loss.py:51-146).
+//
+// Input: vals [B, J, HW] (slot planes of spx_dist_fwd_cls), labels [B, HW] (class 0..K-1, else none).  A segment is
+// (image, class); per segment and slot j the reference takes log_softmax of the slot's distances over the segment's
+// pixels, then the symmetric KL of every slot pair, which is a function of the segment Gram matrix
+//     A[seg][j][k] = sum_px p_j(px) * l_k(px),   l = log_softmax, p = exp(l)
+// Four streaming passes over vals (each 4 J bytes per pixel, nothing else): segment max, segment sum-exp, A, and the
+// gradient (which needs no further reduction: see spx_kld_backward_kernel).  Segment reductions use per-workgroup LDS
+// tables and INTEGER atomics (ordered float keys for the max, 64-bit fixed point for the sums), so results do not
+// depend on the order of arrival: the loss is run-to-run bit-identical like the rest of the path.
+#include "spx_common.h"
+
+#define SPX_KLD_THREADS 256
+#define SPX_KLD_PX_PER_WG 2048
+#define SPX_KLD_MAXJ 16
+
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const int lo = __shfl_xor((int)__double2loint(v), m), hi = __shfl_xor((int)__double2hiint(v), m);
+        v += __hiloint2double(hi, lo);
+    }
+    return v;      // fixed butterfly order: deterministic
+}
+__device__ __forceinline__ float wave_max_f32(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m));
+    return v;
+}
+
+// pass 0: smax_key[b][c][j] = max over the segment's pixels of vals (ordered-uint key of the float)
+__global__ __launch_bounds__(SPX_KLD_THREADS) void spx_kld_max_kernel(const float* __restrict__ vals, const int32_t* __restrict__ labels,
+                                                                     int J, int HW, int K, unsigned int* __restrict__ smax_key) {
+    extern __shared__ unsigned long long kld_smem[];
+    unsigned int* tab = (unsigned int*)kld_smem;          // [K][J]
+    const int b = blockIdx.y, tid = threadIdx.x;
+    for (int i = tid; i < K * J; i += SPX_KLD_THREADS) tab[i] = 0u;
+    __syncthreads();
+    const float* v = vals + (size_t)b * J * HW;
+    const int32_t* lab = labels + (size_t)b * HW;
+    const int px_end = min(HW, (int)(blockIdx.x + 1) * SPX_KLD_PX_PER_WG);
+    for (int px = blockIdx.x * SPX_KLD_PX_PER_WG + tid; px - tid < px_end; px += SPX_KLD_THREADS) {
+        const int c = px < px_end ? lab[px] : -1;
+        const bool ok = c >= 0 && c < K;
+        const int c0 = __shfl(c, 0);
+        const bool uniform = __builtin_amdgcn_ballot_w64(c != c0) == 0;
+        for (int j = 0; j < J; ++j) {
+            const float d = ok ? v[(size_t)j * HW + px] : -3.0e38f;
+            if (uniform) {
+                const float m = wave_max_f32(d);
+                if ((tid & 63) == 0 && ok) atomicMax(&tab[c * J + j], float_key(m));
+            } else if (ok) {
+                atomicMax(&tab[c * J + j], float_key(d));
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < K * J; i += SPX_KLD_THREADS)
+        if (tab[i]) atomicMax(&smax_key[(size_t)b * K * J + i], tab[i]);
+}
+
+// pass 1: ssum_fx[b][c][j] = sum exp(d - smax) in 2^40 fixed point (every term is in (0, 1], the maximum contributes 1)
+__global__ __launch_bounds__(SPX_KLD_THREADS) void spx_kld_sumexp_kernel(const float* __restrict__ vals, const int32_t* __restrict__ labels,
+                                                                        int J, int HW, int K, const float* __restrict__ smax,
+                                                                        unsigned long long* __restrict__ ssum_fx) {
+    extern __shared__ unsigned long long kld_smem[];
+    unsigned long long* tab = kld_smem;                    // [K][J]
+    const int b = blockIdx.y, tid = threadIdx.x;
+    for (int i = tid; i < K * J; i += SPX_KLD_THREADS) tab[i] = 0ull;
+    __syncthreads();
+    const float* v = vals + (size_t)b * J * HW;
+    const int32_t* lab = labels + (size_t)b * HW;
+    const float* sm = smax + (size_t)b * K * J;
+    const int px_end = min(HW, (int)(blockIdx.x + 1) * SPX_KLD_PX_PER_WG);
+    const double FX = 1099511627776.0;                     // 2^40
+    for (int px = blockIdx.x * SPX_KLD_PX_PER_WG + tid; px - tid < px_end; px += SPX_KLD_THREADS) {
+        const int c = px < px_end ? lab[px] : -1;
+        const bool ok = c >= 0 && c < K;
+        const int c0 = __shfl(c, 0);
+        const bool uniform = __builtin_amdgcn_ballot_w64(c != c0) == 0;
+        for (int j = 0; j < J; ++j) {
+            const double e = ok ? (double)__expf(v[(size_t)j * HW + px] - sm[c * J + j]) : 0.0;
+            if (uniform) {
+                const double s = wave_sum_f64(e);
+                if ((tid & 63) == 0 && ok) atomicAdd(&tab[c * J + j], (unsigned long long)(s * FX + 0.5));
+            } else if (ok) {
+                atomicAdd(&tab[c * J + j], (unsigned long long)(e * FX + 0.5));
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < K * J; i += SPX_KLD_THREADS)
+        if (tab[i]) atomicAdd(&ssum_fx[(size_t)b * K * J + i], tab[i]);
+}
+
+// pass 2: A_fx[b][c][j][k] = sum_px p_j * l_k in signed fixed point (scale given by the host from the pixel count)
+template <int JT>
+__global__ __launch_bounds__(SPX_KLD_THREADS) void spx_kld_pairs_kernel(const float* __restrict__ vals, const int32_t* __restrict__ labels,
+                                                                       int J, int HW, int K, const float* __restrict__ lse, double scale,
+                                                                       unsigned long long* __restrict__ A_fx) {
+    extern __shared__ unsigned long long kld_smem[];
+    unsigned long long* tab = kld_smem;                    // [K][J][J], two's complement
+    const int b = blockIdx.y, tid = threadIdx.x;
+    for (int i = tid; i < K * J * J; i += SPX_KLD_THREADS) tab[i] = 0ull;
+    __syncthreads();
+    const float* v = vals + (size_t)b * J * HW;
+    const int32_t* lab = labels + (size_t)b * HW;
+    const float* ls = lse + (size_t)b * K * J;
+    const int px_end = min(HW, (int)(blockIdx.x + 1) * SPX_KLD_PX_PER_WG);
+    for (int px = blockIdx.x * SPX_KLD_PX_PER_WG + tid; px - tid < px_end; px += SPX_KLD_THREADS) {
+        const int c = px < px_end ? lab[px] : -1;
+        const bool ok = c >= 0 && c < K;
+        const int c0 = __shfl(c, 0);
+        const bool uniform = __builtin_amdgcn_ballot_w64(c != c0) == 0;
+        float l[JT], p[JT];          // JT = J rounded up to a multiple of 4: static indices, padded slots contribute 0
+#pragma unroll
+        for (int j = 0; j < JT; ++j) {
+            l[j] = (ok && j < J) ? v[(size_t)j * HW + px] - ls[c * J + j] : 0.0f;
+            p[j] = (ok && j < J) ? __expf(l[j]) : 0.0f;
+        }
+#pragma unroll
+        for (int j = 0; j < JT; ++j) {
+#pragma unroll
+            for (int k = 0; k < JT; ++k) {
+                if (j < J && k < J) {             // wave-uniform
+                    const double t = (double)p[j] * (double)l[k];
+                    if (uniform) {
+                        const double s = wave_sum_f64(t);
+                        if ((tid & 63) == 0 && ok) atomicAdd(&tab[(c * J + j) * J + k], (unsigned long long)(long long)llrint(s * scale));
+                    } else if (ok) {
+                        atomicAdd(&tab[(c * J + j) * J + k], (unsigned long long)(long long)llrint(t * scale));
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < K * J * J; i += SPX_KLD_THREADS)
+        if (tab[i]) atomicAdd(&A_fx[(size_t)b * K * J * J + i], tab[i]);
+}
+
+// pass 3: gradient.  With Cf = dLoss/dA (per segment, from the host) and sum_px p_j = 1:
+//   dLoss/dd_m(px) = p_m * [ sum_k Cf[m][k] (l_k - A[m][k]) - sum_j Cf[j][m] ] + sum_j Cf[j][m] p_j
+// - per pixel, given the segment's A and Cf: no reduction.
+template <int JT>
+__global__ __launch_bounds__(SPX_KLD_THREADS) void spx_kld_backward_kernel(const float* __restrict__ vals, const int32_t* __restrict__ labels,
+                                                                          int J, int HW, int K, const float* __restrict__ lse,
+                                                                          const float* __restrict__ A, const float* __restrict__ Cf,
+                                                                          float* __restrict__ grad) {
+    extern __shared__ unsigned long long kld_smem[];
+    float* sA = (float*)kld_smem;                          // [K][J][J]
+    float* sC = sA + K * J * J;                            // [K][J][J]
+    float* sL = sC + K * J * J;                            // [K][J]
+    float* sR = sL + K * J;                                // [K][J]   sum_j Cf[j][m]
+    const int b = blockIdx.y, tid = threadIdx.x;
+    for (int i = tid; i < K * J * J; i += SPX_KLD_THREADS) {
+        sA[i] = A[(size_t)b * K * J * J + i];
+        sC[i] = Cf[(size_t)b * K * J * J + i];
+    }
+    for (int i = tid; i < K * J; i += SPX_KLD_THREADS) sL[i] = lse[(size_t)b * K * J + i];
+    __syncthreads();
+    for (int i = tid; i < K * J; i += SPX_KLD_THREADS) {
+        const int c = i / J, m = i - c * J;
+        float s = 0.0f;
+        for (int j = 0; j < J; ++j) s += sC[(c * J + j) * J + m];
+        sR[i] = s;
+    }
+    __syncthreads();
+    const float* v = vals + (size_t)b * J * HW;
+    float* g = grad + (size_t)b * J * HW;
+    const int32_t* lab = labels + (size_t)b * HW;
+    const int px_end = min(HW, (int)(blockIdx.x + 1) * SPX_KLD_PX_PER_WG);
+    for (int px = blockIdx.x * SPX_KLD_PX_PER_WG + tid; px < px_end; px += SPX_KLD_THREADS) {
+        const int c = lab[px];
+        const bool ok = c >= 0 && c < K;
+        float l[JT], p[JT];
+#pragma unroll
+        for (int j = 0; j < JT; ++j) {
+            l[j] = (ok && j < J) ? v[(size_t)j * HW + px] - sL[c * J + j] : 0.0f;
+            p[j] = (ok && j < J) ? __expf(l[j]) : 0.0f;
+        }
+#pragma unroll
+        for (int m = 0; m < JT; ++m) {
+            if (m < J) {
+                float out = 0.0f;
+                if (ok) {
+                    float s1 = -sR[c * J + m], s2 = 0.0f;
+#pragma unroll
+                    for (int k = 0; k < JT; ++k) {
+                        if (k < J) {
+                            s1 += sC[(c * J + m) * J + k] * (l[k] - sA[(c * J + m) * J + k]);
+                            s2 += sC[(c * J + k) * J + m] * p[k];
+                        }
+                    }
+                    out = p[m] * s1 + s2;
+                }
+                g[(size_t)m * HW + px] = out;
+            }
+        }
+    }
+}
+
+hipError_t spx_launch_kld(int pass, const float* vals, const int32_t* labels, int B, int J, int HW, int K, const float* t0,
+                          const float* t1, const float* t2, double scale, void* out, hipStream_t s) {
+    dim3 grid((unsigned)((HW + SPX_KLD_PX_PER_WG - 1) / SPX_KLD_PX_PER_WG), (unsigned)B);
+    dim3 blk(SPX_KLD_THREADS);
+    if (pass == 0)
+        hipLaunchKernelGGL(spx_kld_max_kernel, grid, blk, (size_t)K * J * 4, s, vals, labels, J, HW, K, (unsigned int*)out);
+    else if (pass == 1)
+        hipLaunchKernelGGL(spx_kld_sumexp_kernel, grid, blk, (size_t)K * J * 8, s, vals, labels, J, HW, K, t0, (unsigned long long*)out);
+    else if (pass == 2) {
+        const size_t lds = (size_t)K * J * J * 8;
+        unsigned long long* o = (unsigned long long*)out;
+        if (J <= 4) hipLaunchKernelGGL(spx_kld_pairs_kernel<4>, grid, blk, lds, s, vals, labels, J, HW, K, t0, scale, o);
+        else if (J <= 8) hipLaunchKernelGGL(spx_kld_pairs_kernel<8>, grid, blk, lds, s, vals, labels, J, HW, K, t0, scale, o);
+        else if (J <= 12) hipLaunchKernelGGL(spx_kld_pairs_kernel<12>, grid, blk, lds, s, vals, labels, J, HW, K, t0, scale, o);
+        else hipLaunchKernelGGL(spx_kld_pairs_kernel<16>, grid, blk, lds, s, vals, labels, J, HW, K, t0, scale, o);
+    } else {
+        const size_t lds = (size_t)(2 * K * J * J + 2 * K * J) * 4;
+        float* o = (float*)out;
+        if (J <= 4) hipLaunchKernelGGL(spx_kld_backward_kernel<4>, grid, blk, lds, s, vals, labels, J, HW, K, t0, t1, t2, o);
+        else if (J <= 8) hipLaunchKernelGGL(spx_kld_backward_kernel<8>, grid, blk, lds, s, vals, labels, J, HW, K, t0, t1, t2, o);
+        else if (J <= 12) hipLaunchKernelGGL(spx_kld_backward_kernel<12>, grid, blk, lds, s, vals, labels, J, HW, K, t0, t1, t2, o);
+        else hipLaunchKernelGGL(spx_kld_backward_kernel<16>, grid, blk, lds, s, vals, labels, J, HW, K, t0, t1, t2, o);
+    }
+    return hipGetLastError();
+}

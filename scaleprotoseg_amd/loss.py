@@ -104,6 +104,61 @@ class _SegmentGather(torch.autograd.Function):
         return torch.zeros((ctx.n, g.shape[1]), device=g.device, dtype=g.dtype).index_add_(0, seg, g), None
 
 
+def _kld_kernels_usable(vals: torch.Tensor, K: int, J: int) -> bool:
+    return vals.is_cuda and vals.dtype == torch.float32 and J <= 16 and K * J * J * 8 + K * J * 8 <= 60 * 1024
+
+
+class _KLDSegmentGram(torch.autograd.Function):
+    """(A [B,K,J,J], lse [B,K,J]) of class-gathered distances through the HIP kernels (csrc/spx_kld.hip): A[seg][j][k] =
+    sum_px p_j l_k with l the log_softmax over the segment's pixels.  Backward: dLoss/dvals from dLoss/dA, per pixel."""
+
+    @staticmethod
+    def forward(ctx, vals, labels, K):
+        import ctypes as C
+        from . import _lib
+
+        lib = _lib.load()
+        B, J, HW = vals.shape
+        v = vals.detach().contiguous()
+        lab = labels.to(device=v.device, dtype=torch.int32).contiguous()
+        dev = v.device
+        s = _lib.stream_ptr()
+        keys = torch.zeros((B, K, J), dtype=torch.int32, device=dev)
+        _lib.check(lib.spx_kld_segment_max(_lib.ptr(v), _lib.ptr(lab), B, J, HW, K, _lib.ptr(keys), s))
+        k64 = keys.to(torch.int64) & 0xFFFFFFFF
+        bits = torch.where((k64 & 0x80000000) != 0, k64 & 0x7FFFFFFF, (~k64) & 0xFFFFFFFF)
+        smax = (bits - ((bits >> 31) << 32)).to(torch.int32).view(torch.float32)     # uint32 bit pattern -> float
+        seen = k64 != 0
+        smax = torch.where(seen, smax, torch.zeros_like(smax)).contiguous()
+        ssum_fx = torch.zeros((B, K, J), dtype=torch.int64, device=dev)
+        _lib.check(lib.spx_kld_segment_sumexp(_lib.ptr(v), _lib.ptr(lab), B, J, HW, K, _lib.ptr(smax), _lib.ptr(ssum_fx), s))
+        ssum = ssum_fx.to(torch.float64) / float(1 << 40)
+        lse = (smax.double() + torch.log(ssum.clamp_min(1e-300))).float()
+        lse = torch.where(seen, lse, torch.zeros_like(lse)).contiguous()
+        # fixed-point scale of the Gram sums: |p * l| <= the value range of a slot; N terms must stay inside int64
+        span = float((v.amax() - v.amin()).item()) + 32.0
+        scale = float(2.0 ** int(torch.floor(torch.log2(torch.tensor(2.0 ** 62 / (HW * span)))).item()))
+        a_fx = torch.zeros((B, K, J, J), dtype=torch.int64, device=dev)
+        _lib.check(lib.spx_kld_pair_sums(_lib.ptr(v), _lib.ptr(lab), B, J, HW, K, _lib.ptr(lse), C.c_double(scale), _lib.ptr(a_fx), s))
+        A = (a_fx.to(torch.float64) / scale).float()
+        ctx.save_for_backward(v, lab, lse, A)
+        ctx.K = K
+        ctx.mark_non_differentiable(lse)
+        return A, lse
+
+    @staticmethod
+    def backward(ctx, gA, _g_lse):
+        from . import _lib
+
+        lib = _lib.load()
+        v, lab, lse, A = ctx.saved_tensors
+        B, J, HW = v.shape
+        grad = torch.empty_like(v)
+        cf = gA.contiguous().float()
+        _lib.check(lib.spx_kld_backward(_lib.ptr(v), _lib.ptr(lab), B, J, HW, ctx.K, _lib.ptr(lse), _lib.ptr(A.contiguous()), _lib.ptr(cf), _lib.ptr(grad), _lib.stream_ptr()))
+        return grad, None, None
+
+
 class KLDLoss(nn.Module):
     """Drop-in for segmentation/model/loss.py:51-146: same constructor, same ``forward(prototype_distances,
     target_labels)`` (labels 0 = void, 1..K = class); ``prototype_distances`` may be the [B, P, H, W] map or a
@@ -145,6 +200,13 @@ class KLDLoss(nn.Module):
         if not bool(ok.any()):
             return torch.tensor(0.0)
         nseg = B * K
+        if isinstance(prototype_distances, ClassDistances) and _kld_kernels_usable(prototype_distances.values, K, J):
+            # the gathered planes on the GPU: segment statistics and the gradient run in the HIP kernels
+            A, _ = _KLDSegmentGram.apply(prototype_distances.values, lab, K)
+            A = A.reshape(nseg, J, J)
+            seg_ids = (torch.arange(B, device=dev).unsqueeze(1) * K + lab.clamp(0, K - 1)).reshape(-1)[ok]
+            count = torch.bincount(seg_ids, minlength=nseg)[:nseg]
+            return self._loss_from_gram(A, count, table, K, nseg)
         # (image, class) segment of every pixel; pixels without a class go to a dummy segment that is dropped below
         seg = (torch.arange(B, device=dev).unsqueeze(1) * K + lab.clamp(0, K - 1)).reshape(-1)
         seg = torch.where(ok, seg, torch.full_like(seg, nseg))
@@ -175,6 +237,11 @@ class KLDLoss(nn.Module):
             z = z.scatter(1, sg.view(-1, 1, 1).expand(-1, 1, J), pp.unsqueeze(1))
             A = A + _pixel_outer(z.view(pp.shape[0], ns1 * J), lp)
         A = A.view(ns1, J, J)[:nseg]
+        return self._loss_from_gram(A, count, table, K, nseg)
+
+    def _loss_from_gram(self, A: torch.Tensor, count: torch.Tensor, table: torch.Tensor, K: int, nseg: int) -> torch.Tensor:
+        """Symmetric KL of the slot pairs from the segment Gram matrices, exp(-kld), mean (loss.py:113-142)."""
+        dev = A.device
         diag = torch.diagonal(A, dim1=1, dim2=2)
         kld = 0.5 * (diag.unsqueeze(2) + diag.unsqueeze(1) - A - A.transpose(1, 2))
         pair_ok = self._pair_mask(table).to(dev)                                    # [K, J, J]

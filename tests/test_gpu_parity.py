@@ -694,3 +694,72 @@ def test_random_gather_and_tail(seed):
     _grad_close(x.grad, c0.grad, "dX", tol=dx_tol)
     _grad_close(pv.grad, p0.grad, "dPrototypes")
 
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_kld_kernels_match_reference_golden(golden, tag):
+    """KLDLoss on class-gathered GPU planes (csrc/spx_kld.hip: integer-atomic segment reductions + per-pixel gradient)
+    against the reference's KLDLoss value and gradient (tests/golden/kld_loss.npz), and run-to-run bit-identical."""
+    import scaleprotoseg_amd as spx
+    from scaleprotoseg_amd.loss import class_slot_table, gather_class_distances
+
+    dev = _dev()
+    g = golden("kld_loss")
+    t = torch.from_numpy(g[f"{tag}_target"])
+    ident = torch.from_numpy(g[f"{tag}_ident"])
+    S = int(g[f"{tag}_S"])
+    ranges = {s: tuple(int(v) for v in g[f"{tag}_ranges"][s]) for s in range(S)}
+    d_full = torch.from_numpy(g[f"{tag}_dist"])
+    B, P, H, W = d_full.shape
+    table = class_slot_table(ident)
+    lab0 = t.reshape(B, -1) - 1
+    planes = gather_class_distances(d_full, lab0, table).permute(0, 2, 1).contiguous()     # [B, J, HW]
+    loss_fn = spx.KLDLoss(ident, S, ranges)
+
+    def run():
+        v = planes.to(dev).requires_grad_(True)
+        cd = spx.ClassDistances(v, lab0.to(dev).int(), table.to(dev), (H, W))
+        loss = loss_fn(cd, t.to(dev))
+        loss.backward()
+        torch.cuda.synchronize()
+        return loss.detach().cpu(), v.grad.detach().cpu()
+
+    l1, g1 = run()
+    l2, g2 = run()
+    assert torch.equal(l1, l2) and torch.equal(g1, g2)                     # integer atomics: order-independent
+    assert abs(l1.item() - float(g[f"{tag}_loss"])) <= 2e-6, (l1.item(), float(g[f"{tag}_loss"]))
+    # reference gradient lives on the full map: gather it the same way (other entries are exactly 0 there)
+    gref_full = torch.from_numpy(g[f"{tag}_grad"])
+    gref = gather_class_distances(gref_full, lab0, table).permute(0, 2, 1)
+    assert float((gref_full.abs().sum() - gref.abs().sum()).abs()) <= 1e-6 * float(gref_full.abs().sum())
+    scale = gref.abs().max().item()
+    assert (g1 - gref).abs().max().item() <= 2e-5 * scale + 1e-9, ((g1 - gref).abs().max().item(), scale)
+
+
+def test_kld_kernels_large_random():
+    """2048 x 1024 pixels, random (non-uniform) and patchy labels: kernels vs the torch formulation of the same loss."""
+    import scaleprotoseg_amd as spx
+
+    dev = _dev()
+    P, K, S, H, W = 190, 19, 1, 512, 1024
+    ident = O.default_class_identity(P, K, S)
+    lay = _layout(P, K, S, 16, O.default_scale_ranges(P, S))
+    keys, J, table = spx.class_gather_table(lay, ident, dev)
+    gen = torch.Generator(device=dev).manual_seed(5)
+    for patchy in (False, True):
+        if patchy:
+            t = torch.randint(0, K + 1, (1, H // 32, W // 32), device=dev, generator=gen).repeat_interleave(32, 1).repeat_interleave(32, 2)
+        else:
+            t = torch.randint(0, K + 1, (1, H, W), device=dev, generator=gen)
+        base = torch.rand(1, J, H * W, device=dev, generator=gen) * 40
+        loss_fn = spx.KLDLoss(ident, S, {0: (0, P)})
+        v1 = base.clone().requires_grad_(True)
+        l1 = loss_fn(spx.ClassDistances(v1, (t.reshape(1, -1) - 1).int(), table, (H, W)), t)
+        l1.backward()
+        v2 = base.double().clone().requires_grad_(True)                      # fp64 -> the torch path
+        l2 = loss_fn(spx.ClassDistances(v2, (t.reshape(1, -1) - 1).int(), table, (H, W)), t)
+        l2.backward()
+        torch.cuda.synchronize()
+        assert abs(l1.item() - l2.item()) <= 1e-5 * max(1.0, abs(l2.item())), (l1.item(), l2.item())
+        s = v2.grad.abs().max().item()
+        assert (v1.grad.double() - v2.grad).abs().max().item() <= 1e-4 * s + 1e-12
