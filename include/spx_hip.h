@@ -183,7 +183,8 @@ int spx_argmin_images(const float* values, int32_t N, int32_t P, int64_t* best, 
  *   spx_kld_segment_max    smax_keys uint32 [B, K, J] (caller zero-fills): ordered key of max_px vals over the segment
  *                          (key k -> float: k & 0x80000000 ? k ^ 0x80000000 : ~k)
  *   spx_kld_segment_sumexp ssum_fx uint64 [B, K, J] (zero-filled): sum_px exp(vals - smax) * 2^40
- *   spx_kld_pair_sums      a_fx int64 [B, K, J, J] (zero-filled): sum_px p_j * l_k * scale, l = vals - lse (the
+ *   spx_kld_pair_sums      a_fx int64 [B, K, J, J] (zero-filled): sum_px p_j * l_k * scale (scale: ONE double in DEVICE
+ *                          memory, so the caller can derive it from the data without a host sync), l = vals - lse (the
  *                          log_softmax over the segment's pixels, loss.py:110), p = exp(l)
  *   spx_kld_backward       grad fp32 [B, J, HW] = dLoss/dvals given A = a_fx / scale and Cf = dLoss/dA [B, K, J, J]
  * The [B, K, J, J]-sized algebra between the passes (loss.py:113-142: symmetric KL of the slot pairs of one scale,
@@ -193,7 +194,7 @@ int spx_kld_segment_max(const float* vals, const int32_t* labels, int32_t B, int
 int spx_kld_segment_sumexp(const float* vals, const int32_t* labels, int32_t B, int32_t J, int32_t HW, int32_t K,
                            const float* smax, uint64_t* ssum_fx, void* stream);
 int spx_kld_pair_sums(const float* vals, const int32_t* labels, int32_t B, int32_t J, int32_t HW, int32_t K,
-                      const float* lse, double scale, int64_t* a_fx, void* stream);
+                      const float* lse, const double* scale, int64_t* a_fx, void* stream);
 int spx_kld_backward(const float* vals, const int32_t* labels, int32_t B, int32_t J, int32_t HW, int32_t K,
                      const float* lse, const float* A, const float* Cf, float* grad, void* stream);
 

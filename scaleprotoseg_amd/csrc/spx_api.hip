@@ -365,23 +365,23 @@ static int kld_check(const char* who, const float* vals, const int32_t* labels, 
 int spx_kld_segment_max(const float* vals, const int32_t* labels, int32_t B, int32_t J, int32_t HW, int32_t K,
                         uint32_t* smax_keys, void* stream) {
     if (kld_check("spx_kld_segment_max", vals, labels, B, J, HW, K, smax_keys, 0)) return 1;
-    return hip_status(spx_launch_kld(0, vals, labels, B, J, HW, K, nullptr, nullptr, nullptr, 0.0, smax_keys, (hipStream_t)stream), "spx_kld_segment_max");
+    return hip_status(spx_launch_kld(0, vals, labels, B, J, HW, K, nullptr, nullptr, nullptr, nullptr, smax_keys, (hipStream_t)stream), "spx_kld_segment_max");
 }
 int spx_kld_segment_sumexp(const float* vals, const int32_t* labels, int32_t B, int32_t J, int32_t HW, int32_t K,
                            const float* smax, uint64_t* ssum_fx, void* stream) {
     if (kld_check("spx_kld_segment_sumexp", vals, labels, B, J, HW, K, ssum_fx, 0) || !smax) return smax ? 1 : fail("spx_kld_segment_sumexp: NULL smax");
-    return hip_status(spx_launch_kld(1, vals, labels, B, J, HW, K, smax, nullptr, nullptr, 0.0, ssum_fx, (hipStream_t)stream), "spx_kld_segment_sumexp");
+    return hip_status(spx_launch_kld(1, vals, labels, B, J, HW, K, smax, nullptr, nullptr, nullptr, ssum_fx, (hipStream_t)stream), "spx_kld_segment_sumexp");
 }
 int spx_kld_pair_sums(const float* vals, const int32_t* labels, int32_t B, int32_t J, int32_t HW, int32_t K,
-                      const float* lse, double scale, int64_t* a_fx, void* stream) {
-    if (kld_check("spx_kld_pair_sums", vals, labels, B, J, HW, K, a_fx, 1) || !lse) return lse ? 1 : fail("spx_kld_pair_sums: NULL lse");
+                      const float* lse, const double* scale, int64_t* a_fx, void* stream) {
+    if (kld_check("spx_kld_pair_sums", vals, labels, B, J, HW, K, a_fx, 1) || !lse || !scale) return (lse && scale) ? 1 : fail("spx_kld_pair_sums: NULL lse / scale");
     return hip_status(spx_launch_kld(2, vals, labels, B, J, HW, K, lse, nullptr, nullptr, scale, a_fx, (hipStream_t)stream), "spx_kld_pair_sums");
 }
 int spx_kld_backward(const float* vals, const int32_t* labels, int32_t B, int32_t J, int32_t HW, int32_t K,
                      const float* lse, const float* A, const float* Cf, float* grad, void* stream) {
     if (kld_check("spx_kld_backward", vals, labels, B, J, HW, K, grad, 1)) return 1;
     if (!lse || !A || !Cf) return fail("spx_kld_backward: NULL table");
-    return hip_status(spx_launch_kld(3, vals, labels, B, J, HW, K, lse, A, Cf, 0.0, grad, (hipStream_t)stream), "spx_kld_backward");
+    return hip_status(spx_launch_kld(3, vals, labels, B, J, HW, K, lse, A, Cf, nullptr, grad, (hipStream_t)stream), "spx_kld_backward");
 }
 
 }  // extern "C"

@@ -96,11 +96,12 @@ __global__ __launch_bounds__(SPX_KLD_THREADS) void spx_kld_sumexp_kernel(const f
 // pass 2: A_fx[b][c][j][k] = sum_px p_j * l_k in signed fixed point (scale given by the host from the pixel count)
 template <int JT>
 __global__ __launch_bounds__(SPX_KLD_THREADS) void spx_kld_pairs_kernel(const float* __restrict__ vals, const int32_t* __restrict__ labels,
-                                                                       int J, int HW, int K, const float* __restrict__ lse, double scale,
-                                                                       unsigned long long* __restrict__ A_fx) {
+                                                                       int J, int HW, int K, const float* __restrict__ lse,
+                                                                       const double* __restrict__ scale_p, unsigned long long* __restrict__ A_fx) {
     extern __shared__ unsigned long long kld_smem[];
     unsigned long long* tab = kld_smem;                    // [K][J][J], two's complement
     const int b = blockIdx.y, tid = threadIdx.x;
+    const double scale = *scale_p;                         // device-side: the host never reads the data (no sync)
     for (int i = tid; i < K * J * J; i += SPX_KLD_THREADS) tab[i] = 0ull;
     __syncthreads();
     const float* v = vals + (size_t)b * J * HW;
@@ -201,7 +202,7 @@ __global__ __launch_bounds__(SPX_KLD_THREADS) void spx_kld_backward_kernel(const
 }
 
 hipError_t spx_launch_kld(int pass, const float* vals, const int32_t* labels, int B, int J, int HW, int K, const float* t0,
-                          const float* t1, const float* t2, double scale, void* out, hipStream_t s) {
+                          const float* t1, const float* t2, const double* scale, void* out, hipStream_t s) {
     dim3 grid((unsigned)((HW + SPX_KLD_PX_PER_WG - 1) / SPX_KLD_PX_PER_WG), (unsigned)B);
     dim3 blk(SPX_KLD_THREADS);
     if (pass == 0)

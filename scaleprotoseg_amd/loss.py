@@ -114,7 +114,6 @@ class _KLDSegmentGram(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, vals, labels, K):
-        import ctypes as C
         from . import _lib
 
         lib = _lib.load()
@@ -135,11 +134,12 @@ class _KLDSegmentGram(torch.autograd.Function):
         ssum = ssum_fx.to(torch.float64) / float(1 << 40)
         lse = (smax.double() + torch.log(ssum.clamp_min(1e-300))).float()
         lse = torch.where(seen, lse, torch.zeros_like(lse)).contiguous()
-        # fixed-point scale of the Gram sums: |p * l| <= the value range of a slot; N terms must stay inside int64
-        span = float((v.amax() - v.amin()).item()) + 32.0
-        scale = float(2.0 ** int(torch.floor(torch.log2(torch.tensor(2.0 ** 62 / (HW * span)))).item()))
+        # fixed-point scale of the Gram sums (a power of two, computed on the device: no host sync): |p * l| is bounded
+        # by the value range of a slot, and HW terms must stay inside int64
+        span = (v.amax() - v.amin()).double() + 32.0
+        scale = torch.exp2(torch.floor(torch.log2((2.0 ** 62) / (HW * span)))).reshape(1).contiguous()
         a_fx = torch.zeros((B, K, J, J), dtype=torch.int64, device=dev)
-        _lib.check(lib.spx_kld_pair_sums(_lib.ptr(v), _lib.ptr(lab), B, J, HW, K, _lib.ptr(lse), C.c_double(scale), _lib.ptr(a_fx), s))
+        _lib.check(lib.spx_kld_pair_sums(_lib.ptr(v), _lib.ptr(lab), B, J, HW, K, _lib.ptr(lse), _lib.ptr(scale), _lib.ptr(a_fx), s))
         A = (a_fx.to(torch.float64) / scale).float()
         ctx.save_for_backward(v, lab, lse, A)
         ctx.K = K
@@ -197,16 +197,17 @@ class KLDLoss(nn.Module):
         B = vals.shape[0]
         lab = labels0.to(dev)
         ok = ((lab >= 0) & (lab < K)).reshape(-1)
-        if not bool(ok.any()):
-            return torch.tensor(0.0)
         nseg = B * K
         if isinstance(prototype_distances, ClassDistances) and _kld_kernels_usable(prototype_distances.values, K, J):
-            # the gathered planes on the GPU: segment statistics and the gradient run in the HIP kernels
+            # the gathered planes on the GPU: segment statistics and the gradient run in the HIP kernels; nothing on
+            # this path reads a value back to the host (capturable in a HIP graph)
             A, _ = _KLDSegmentGram.apply(prototype_distances.values, lab, K)
             A = A.reshape(nseg, J, J)
-            seg_ids = (torch.arange(B, device=dev).unsqueeze(1) * K + lab.clamp(0, K - 1)).reshape(-1)[ok]
-            count = torch.bincount(seg_ids, minlength=nseg)[:nseg]
+            seg_ids = (torch.arange(B, device=dev).unsqueeze(1) * K + lab.clamp(0, K - 1)).reshape(-1)
+            count = torch.zeros(nseg, device=dev, dtype=torch.float32).index_add_(0, seg_ids, ok.to(torch.float32))
             return self._loss_from_gram(A, count, table, K, nseg)
+        if not bool(ok.any()):
+            return torch.tensor(0.0)
         # (image, class) segment of every pixel; pixels without a class go to a dummy segment that is dropped below
         seg = (torch.arange(B, device=dev).unsqueeze(1) * K + lab.clamp(0, K - 1)).reshape(-1)
         seg = torch.where(ok, seg, torch.full_like(seg, nseg))
@@ -247,7 +248,7 @@ class KLDLoss(nn.Module):
         pair_ok = self._pair_mask(table).to(dev)                                    # [K, J, J]
         seg_cls = torch.arange(nseg, device=dev) % K
         valid = pair_ok[seg_cls] & (count >= 2).reshape(-1, 1, 1)                   # loss.py:113-127 (len < 2 skipped)
-        terms = kld[valid]
-        if terms.numel() == 0:
-            return torch.tensor(0.0)
-        return torch.exp(-terms).mean()                                              # loss.py:138-142
+        # mean of exp(-kld) over the valid terms, 0.0 when there is none (loss.py:138-144) - without a dynamic shape
+        n = valid.sum()
+        total = torch.where(valid, torch.exp(-kld), torch.zeros_like(kld)).sum()
+        return torch.where(n > 0, total / n.clamp_min(1).to(total.dtype), torch.zeros_like(total))
