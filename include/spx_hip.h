@@ -181,7 +181,8 @@ int spx_argmin_images(const float* values, int32_t N, int32_t P, int64_t* best, 
  * (the slot planes of spx_dist_fwd_cls), labels int32 [B, HW].  A segment = (image, class).  Four streaming passes,
  * each reading vals once; all segment reductions use integer atomics (run-to-run identical results):
  *   spx_kld_segment_max    smax_keys uint32 [B, K, J] (caller zero-fills): ordered key of max_px vals over the segment
- *                          (key k -> float: k & 0x80000000 ? k ^ 0x80000000 : ~k)
+ *                          (key k -> float: k & 0x80000000 ? k ^ 0x80000000 : ~k); counts uint32 [B, K] (zero-filled,
+ *                          may be NULL): pixels per segment (loss.py:113-127 skips segments of fewer than two)
  *   spx_kld_segment_sumexp ssum_fx uint64 [B, K, J] (zero-filled): sum_px exp(vals - smax) * 2^40
  *   spx_kld_pair_sums      a_fx int64 [B, K, J, J] (zero-filled): sum_px p_j * l_k * scale (scale: ONE double in DEVICE
  *                          memory, so the caller can derive it from the data without a host sync), l = vals - lse (the
@@ -190,7 +191,7 @@ int spx_argmin_images(const float* values, int32_t N, int32_t P, int64_t* best, 
  * The [B, K, J, J]-sized algebra between the passes (loss.py:113-142: symmetric KL of the slot pairs of one scale,
  * exp(-kld), mean) is left to the caller.  J <= 16 and K*J*J*8 bytes must fit the LDS table (~60 KiB). */
 int spx_kld_segment_max(const float* vals, const int32_t* labels, int32_t B, int32_t J, int32_t HW, int32_t K,
-                        uint32_t* smax_keys, void* stream);
+                        uint32_t* smax_keys, uint32_t* counts, void* stream);
 int spx_kld_segment_sumexp(const float* vals, const int32_t* labels, int32_t B, int32_t J, int32_t HW, int32_t K,
                            const float* smax, uint64_t* ssum_fx, void* stream);
 int spx_kld_pair_sums(const float* vals, const int32_t* labels, int32_t B, int32_t J, int32_t HW, int32_t K,

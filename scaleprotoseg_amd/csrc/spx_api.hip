@@ -363,9 +363,9 @@ static int kld_check(const char* who, const float* vals, const int32_t* labels, 
 }
 
 int spx_kld_segment_max(const float* vals, const int32_t* labels, int32_t B, int32_t J, int32_t HW, int32_t K,
-                        uint32_t* smax_keys, void* stream) {
+                        uint32_t* smax_keys, uint32_t* counts, void* stream) {
     if (kld_check("spx_kld_segment_max", vals, labels, B, J, HW, K, smax_keys, 0)) return 1;
-    return hip_status(spx_launch_kld(0, vals, labels, B, J, HW, K, nullptr, nullptr, nullptr, nullptr, smax_keys, (hipStream_t)stream), "spx_kld_segment_max");
+    return hip_status(spx_launch_kld(0, vals, labels, B, J, HW, K, (const float*)counts, nullptr, nullptr, nullptr, smax_keys, (hipStream_t)stream), "spx_kld_segment_max");
 }
 int spx_kld_segment_sumexp(const float* vals, const int32_t* labels, int32_t B, int32_t J, int32_t HW, int32_t K,
                            const float* smax, uint64_t* ssum_fx, void* stream) {

@@ -30,11 +30,13 @@ __device__ __forceinline__ float wave_max_f32(float v) {
 
 // pass 0: smax_key[b][c][j] = max over the segment's pixels of vals (ordered-uint key of the float)
 __global__ __launch_bounds__(SPX_KLD_THREADS) void spx_kld_max_kernel(const float* __restrict__ vals, const int32_t* __restrict__ labels,
-                                                                     int J, int HW, int K, unsigned int* __restrict__ smax_key) {
+                                                                     int J, int HW, int K, unsigned int* __restrict__ smax_key,
+                                                                     unsigned int* __restrict__ counts) {
     extern __shared__ unsigned long long kld_smem[];
     unsigned int* tab = (unsigned int*)kld_smem;          // [K][J]
+    unsigned int* cnt = tab + K * J;                      // [K] pixels of the class in this workgroup's range
     const int b = blockIdx.y, tid = threadIdx.x;
-    for (int i = tid; i < K * J; i += SPX_KLD_THREADS) tab[i] = 0u;
+    for (int i = tid; i < K * J + K; i += SPX_KLD_THREADS) tab[i] = 0u;
     __syncthreads();
     const float* v = vals + (size_t)b * J * HW;
     const int32_t* lab = labels + (size_t)b * HW;
@@ -44,6 +46,13 @@ __global__ __launch_bounds__(SPX_KLD_THREADS) void spx_kld_max_kernel(const floa
         const bool ok = c >= 0 && c < K;
         const int c0 = __shfl(c, 0);
         const bool uniform = __builtin_amdgcn_ballot_w64(c != c0) == 0;
+        if (counts) {
+            if (uniform) {
+                if ((tid & 63) == 0 && ok) atomicAdd(&cnt[c], 64u);
+            } else if (ok) {
+                atomicAdd(&cnt[c], 1u);
+            }
+        }
         for (int j = 0; j < J; ++j) {
             const float d = ok ? v[(size_t)j * HW + px] : -3.0e38f;
             if (uniform) {
@@ -57,6 +66,9 @@ __global__ __launch_bounds__(SPX_KLD_THREADS) void spx_kld_max_kernel(const floa
     __syncthreads();
     for (int i = tid; i < K * J; i += SPX_KLD_THREADS)
         if (tab[i]) atomicMax(&smax_key[(size_t)b * K * J + i], tab[i]);
+    if (counts)
+        for (int i = tid; i < K; i += SPX_KLD_THREADS)
+            if (cnt[i]) atomicAdd(&counts[(size_t)b * K + i], cnt[i]);
 }
 
 // pass 1: ssum_fx[b][c][j] = sum exp(d - smax) in 2^40 fixed point (every term is in (0, 1], the maximum contributes 1)
@@ -206,7 +218,7 @@ hipError_t spx_launch_kld(int pass, const float* vals, const int32_t* labels, in
     dim3 grid((unsigned)((HW + SPX_KLD_PX_PER_WG - 1) / SPX_KLD_PX_PER_WG), (unsigned)B);
     dim3 blk(SPX_KLD_THREADS);
     if (pass == 0)
-        hipLaunchKernelGGL(spx_kld_max_kernel, grid, blk, (size_t)K * J * 4, s, vals, labels, J, HW, K, (unsigned int*)out);
+        hipLaunchKernelGGL(spx_kld_max_kernel, grid, blk, (size_t)(K * J + K) * 4, s, vals, labels, J, HW, K, (unsigned int*)out, (unsigned int*)t0);
     else if (pass == 1)
         hipLaunchKernelGGL(spx_kld_sumexp_kernel, grid, blk, (size_t)K * J * 8, s, vals, labels, J, HW, K, t0, (unsigned long long*)out);
     else if (pass == 2) {

@@ -123,7 +123,8 @@ class _KLDSegmentGram(torch.autograd.Function):
         dev = v.device
         s = _lib.stream_ptr()
         keys = torch.zeros((B, K, J), dtype=torch.int32, device=dev)
-        _lib.check(lib.spx_kld_segment_max(_lib.ptr(v), _lib.ptr(lab), B, J, HW, K, _lib.ptr(keys), s))
+        counts = torch.zeros((B, K), dtype=torch.int32, device=dev)
+        _lib.check(lib.spx_kld_segment_max(_lib.ptr(v), _lib.ptr(lab), B, J, HW, K, _lib.ptr(keys), _lib.ptr(counts), s))
         k64 = keys.to(torch.int64) & 0xFFFFFFFF
         bits = torch.where((k64 & 0x80000000) != 0, k64 & 0x7FFFFFFF, (~k64) & 0xFFFFFFFF)
         smax = (bits - ((bits >> 31) << 32)).to(torch.int32).view(torch.float32)     # uint32 bit pattern -> float
@@ -143,11 +144,11 @@ class _KLDSegmentGram(torch.autograd.Function):
         A = (a_fx.to(torch.float64) / scale).float()
         ctx.save_for_backward(v, lab, lse, A)
         ctx.K = K
-        ctx.mark_non_differentiable(lse)
-        return A, lse
+        ctx.mark_non_differentiable(lse, counts)
+        return A, lse, counts
 
     @staticmethod
-    def backward(ctx, gA, _g_lse):
+    def backward(ctx, gA, _g_lse, _g_counts):
         from . import _lib
 
         lib = _lib.load()
@@ -201,11 +202,8 @@ class KLDLoss(nn.Module):
         if isinstance(prototype_distances, ClassDistances) and _kld_kernels_usable(prototype_distances.values, K, J):
             # the gathered planes on the GPU: segment statistics and the gradient run in the HIP kernels; nothing on
             # this path reads a value back to the host (capturable in a HIP graph)
-            A, _ = _KLDSegmentGram.apply(prototype_distances.values, lab, K)
-            A = A.reshape(nseg, J, J)
-            seg_ids = (torch.arange(B, device=dev).unsqueeze(1) * K + lab.clamp(0, K - 1)).reshape(-1)
-            count = torch.zeros(nseg, device=dev, dtype=torch.float32).index_add_(0, seg_ids, ok.to(torch.float32))
-            return self._loss_from_gram(A, count, table, K, nseg)
+            A, _, counts = _KLDSegmentGram.apply(prototype_distances.values, lab, K)
+            return self._loss_from_gram(A.reshape(nseg, J, J), counts.reshape(nseg), table, K, nseg)
         if not bool(ok.any()):
             return torch.tensor(0.0)
         # (image, class) segment of every pixel; pixels without a class go to a dummy segment that is dropped below
