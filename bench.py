@@ -87,6 +87,9 @@ def main():
     ap.add_argument("--grads", default="logits,dist", help="diagnostic only: which output gradients flow back")
     ap.add_argument("--outputs", default="logits,dist", help="diagnostic only: 'logits' = logits-only forward (no fp32 distance map); "
                     "'logits,class_dist' = class-gathered distances (SURVEY 8f-1: what the fused KLD consumes) instead of the P-wide map")
+    ap.add_argument("--kld", action="store_true", help="diagnostic only (with --outputs logits,class_dist): the gradient of the gathered "
+                    "distances comes from KLDLoss (HIP kernels) inside the timed step instead of a fixed random tensor")
+    ap.add_argument("--torch-profile", action="store_true", help="diagnostic only: print torch.profiler's top ops of one extra step to stderr")
     ap.add_argument("--group-tail", action="store_true", help="diagnostic only: group phase - the head is the dense [3K, P] grouping "
                     "matrix and exp + last_layer_group run fused in the kernels (spx_dist_fwd_group / spx_dist_bwd_group)")
     ap.add_argument("--freeze", default="", help="diagnostic only: comma list of x,bank,head to exclude from the backward")
@@ -164,6 +167,8 @@ def main():
         labels0 = patches.repeat_interleave(64, 1).repeat_interleave(64, 2)[:, :H, :W].reshape(1, H * W).contiguous()
         gather = spx.ClassGather(labels=labels0, keys=keys, width=J, table=table)
         g_cls = torch.randn(1, J, H * W, device=dev, generator=g) * 1e-3
+        kld_fn = spx.KLDLoss(ident, S, {s_: layout.scale_ranges[s_] for s_ in range(S)})
+        target1 = (labels0 + 1).reshape(1, H, W)
 
     def step():
         x.grad = None
@@ -178,7 +183,9 @@ def main():
         outs, gouts = [], []
         if "logits" in args.grads:
             outs.append(logits); gouts.append(g_logits)
-        if "dist" in args.grads and gather is not None:
+        if "dist" in args.grads and gather is not None and args.kld:
+            outs.append(kld_fn(spx.ClassDistances(dmap, gather.labels, gather.table, (H, W)), target1)); gouts.append(None)
+        elif "dist" in args.grads and gather is not None:
             outs.append(dmap); gouts.append(g_cls)
         elif "dist" in args.grads and want_d:
             outs.append(dmap); gouts.append(g_dist)
@@ -194,6 +201,13 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    if args.torch_profile and rank == 0:
+        from torch.profiler import ProfilerActivity, profile
+        torch.cuda.synchronize()
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as tp:
+            step()
+            torch.cuda.synchronize()
+        print(tp.key_averages().table(sort_by="cuda_time_total", row_limit=12, max_name_column_width=60), file=sys.stderr)
     prof = []
     fence()
     F_.set_profile(prof)
@@ -260,7 +274,7 @@ def main():
                 "features_dtype": args.x_dtype,
                 "outputs": ("logits + fp32 distance map (reference forward contract); grads dX, dPrototypes, dLastLayer"
                             if (args.outputs == "logits,dist" and not args.group_tail)
-                            else f"DIAGNOSTIC outputs={args.outputs} grads={args.grads} group_tail={args.group_tail}"),
+                            else f"DIAGNOSTIC outputs={args.outputs} grads={args.grads} group_tail={args.group_tail} kld={args.kld}"),
                 "parallelism": f"dp{world}" if world > 1 else "single",
             },
             "kernels": kernels,

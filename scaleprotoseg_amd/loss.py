@@ -173,7 +173,17 @@ class KLDLoss(nn.Module):
         self.scale_num_prototypes = scale_num_prototypes
 
     def _pair_mask(self, table: torch.Tensor) -> torch.Tensor:
-        """[K, J, J] bool: slots j < k of class c are prototypes of the same scale (loss.py:99-104, :118-121)."""
+        """[K, J, J] bool: slots j < k of class c are prototypes of the same scale (loss.py:99-104, :118-121).
+        Cached per (table, scale table): it is host-side work with a device read-back, not something to redo per step."""
+        key = (table.data_ptr(), tuple(table.shape), str(table.device), tuple(sorted((int(s), tuple(r)) for s, r in self.scale_num_prototypes.items())))
+        cached = getattr(self, "_pair_mask_cache", None)
+        if cached is not None and cached[0] == key:
+            return cached[1]
+        mask = self._pair_mask_build(table).to(table.device)
+        self._pair_mask_cache = (key, mask)
+        return mask
+
+    def _pair_mask_build(self, table: torch.Tensor) -> torch.Tensor:
         K, J = table.shape
         scale = torch.full((K, J), -1, dtype=torch.long)
         t = table.cpu()
