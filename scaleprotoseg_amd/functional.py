@@ -47,6 +47,9 @@ class _timed:
         return False
 
 
+_PLAN_CACHE: Dict[tuple, SpxPlan] = {}
+
+
 @dataclass
 class BankLayout:
     """Static description of the prototype bank that the kernels are planned for."""
@@ -58,11 +61,18 @@ class BankLayout:
     scale_ranges: Tuple[Tuple[int, int], ...]
 
     def plan(self) -> SpxPlan:
-        lo = [r[0] for r in self.scale_ranges]
-        hi = [r[1] for r in self.scale_ranges]
-        return _lib.make_plan(
-            self.num_prototypes, self.num_classes, self.num_scales, self.channels_per_scale, lo, hi
-        )
+        """The kernels' panel plan (spx_make_plan); cached per layout value - it is pure host work."""
+        key = (self.num_prototypes, self.num_classes, self.num_scales, self.channels_per_scale,
+               tuple(tuple(int(v) for v in r) for r in self.scale_ranges))
+        plan = _PLAN_CACHE.get(key)
+        if plan is None:
+            lo = [r[0] for r in self.scale_ranges]
+            hi = [r[1] for r in self.scale_ranges]
+            plan = _lib.make_plan(self.num_prototypes, self.num_classes, self.num_scales, self.channels_per_scale, lo, hi)
+            if len(_PLAN_CACHE) > 64:
+                _PLAN_CACHE.clear()
+            _PLAN_CACHE[key] = plan
+        return plan
 
 
 @dataclass

@@ -209,10 +209,13 @@ class KLDLoss(nn.Module):
         lab = labels0.to(dev)
         ok = ((lab >= 0) & (lab < K)).reshape(-1)
         nseg = B * K
-        if isinstance(prototype_distances, ClassDistances) and _kld_kernels_usable(prototype_distances.values, K, J):
+        planes = prototype_distances.values if isinstance(prototype_distances, ClassDistances) else None
+        if planes is None and _kld_kernels_usable(vals, K, J):
+            planes = vals.permute(0, 2, 1).contiguous()      # full map given: its gathered entries as [B, J, H*W] planes
+        if planes is not None and _kld_kernels_usable(planes, K, J):
             # the gathered planes on the GPU: segment statistics and the gradient run in the HIP kernels; nothing on
             # this path reads a value back to the host (capturable in a HIP graph)
-            A, _, counts = _KLDSegmentGram.apply(prototype_distances.values, lab, K)
+            A, _, counts = _KLDSegmentGram.apply(planes, lab, K)
             return self._loss_from_gram(A.reshape(nseg, J, J), counts.reshape(nseg), table, K, nseg)
         if not bool(ok.any()):
             return torch.tensor(0.0)
