@@ -374,6 +374,30 @@ def case_kld(lossmod, ms, name):
         out[f"{tag}_S"] = np.int64(S)
         out[f"{tag}_loss"] = _np(loss)
         out[f"{tag}_grad"] = _np(d.grad)
+    # KLDLossGroup (loss.py:461-545) on group activations of the group-phase module
+    torch.manual_seed(SEED + 70)
+    Kg, Sg, Gg, Pg = 5, 4, 3, 40
+    netp = _make_proto_phase(ms, P=Pg, Cs=16, S=Sg, K=Kg)
+    ident_g = netp.prototype_class_identity.clone()
+    ident_g[ident_g[:, 4] > 0] = 0                      # class 4 owns no prototype: its projection does not exist
+    present = [k for k in range(Kg) if int(ident_g[:, k].sum()) > 0]
+    gci = torch.zeros(len(present) * Gg, Kg)
+    for j, k in enumerate(present):
+        gci[j * Gg:(j + 1) * Gg, k] = 1
+    Bg, Hg, Wg = 2, 7, 9
+    acts = [torch.exp(torch.randn(Bg * Hg * Wg, Gg)).requires_grad_(True) for _ in present]
+    tgt = torch.randint(0, Kg + 1, (Bg, Hg, Wg))
+    lg_loss = lossmod.KLDLossGroup(ident_g, gci, Gg)(list_group_activation=acts, target_labels=tgt)
+    lg_loss.backward()
+    out["grp_ident"] = _np(ident_g)
+    out["grp_gci"] = _np(gci)
+    out["grp_G"] = np.int64(Gg)
+    out["grp_target"] = tgt.numpy().astype(np.int64)
+    for i, t_ in enumerate(acts):
+        out[f"grp_act{i}"] = _np(t_)
+        out[f"grp_grad{i}"] = _np(t_.grad)
+    out["grp_n"] = np.int64(len(acts))
+    out["grp_loss"] = _np(lg_loss)
     # PixelWiseCrossEntropyLoss (loss.py:9-48): the training modules construct it with ignore_index=-1 so that void
     # (label 0 -> -1 after the shift) is skipped
     torch.manual_seed(SEED + 60)

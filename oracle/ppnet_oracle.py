@@ -315,6 +315,42 @@ def kld_loss(
     return torch.exp(-torch.stack(terms)).mean()
 
 
+def kld_loss_group(
+    list_group_activation: Sequence[torch.Tensor],
+    target_labels: torch.Tensor,
+    class_identity: torch.Tensor,
+    group_class_identity_: torch.Tensor,
+    num_groups: int,
+) -> torch.Tensor:
+    """segmentation/model/loss.py:478-545 (KLDLossGroup.forward), loop for loop: per (image, class present with
+    prototypes): log_softmax over the class's pixels of each of the class's group activations, symmetric KL of every
+    group pair, exp(-kld), mean."""
+    tl = target_labels.reshape(target_labels.shape[0], -1) - 1
+    terms = []
+    for b in range(tl.shape[0]):
+        for c in torch.unique(tl[b]).tolist():
+            if c < 0 or c >= class_identity.shape[1]:
+                continue
+            if class_identity[:, c].sum() == 0:
+                continue
+            id_proj = int(group_class_identity_[:, c].argmax().item()) // num_groups
+            ga = list_group_activation[id_proj].reshape(tl.shape[0], -1, num_groups)
+            mask = tl[b] == c
+            logp = [F.log_softmax(torch.masked_select(ga[b, :, i], mask), dim=0) for i in range(num_groups)]
+            for j in range(num_groups):
+                if len(logp[j]) < 2:
+                    continue
+                for k in range(j + 1, num_groups):
+                    if len(logp[k]) < 2:
+                        continue
+                    k1 = F.kl_div(logp[j], logp[k], log_target=True, reduction="sum")
+                    k2 = F.kl_div(logp[k], logp[j], log_target=True, reduction="sum")
+                    terms.append((k1 + k2) / 2.0)
+    if not terms:
+        return torch.tensor(0.0)
+    return torch.exp(-torch.stack(terms)).mean()
+
+
 def class_slot_table(class_identity: torch.Tensor) -> torch.Tensor:
     """table [K, J]: prototype index of (class, slot), slot = rank among the class's prototypes (ascending), -1 = none."""
     P, K = class_identity.shape

@@ -7,7 +7,7 @@ Public surface mirrors the reference's module/function names for this path:
     compute_distances, min_across_dataset, global_min, push_prototypes_multiscale
                                                     (segmentation/push_multiscale_optimization.py)
     projection_simplex_sort, resize_label           (segmentation/utils.py, segmentation/data/dataset.py)
-    KLDLoss                                         (segmentation/model/loss.py; also takes the class-gathered
+    KLDLoss, KLDLossGroup                           (segmentation/model/loss.py; KLDLoss also takes the class-gathered
                                                      ClassDistances of forward_from_conv_features(target_labels=...))
 Arithmetic runs in libspx_hip.so (hand-written gfx950 HIP); there is no CPU fallback.
 """
@@ -22,7 +22,7 @@ from .functional import (  # noqa: F401
     upsample_argext,
 )
 from .checkpoint import export_state, import_state, load_reference_state_dict  # noqa: F401
-from .loss import ClassDistances, KLDLoss, PixelWiseCrossEntropyLoss  # noqa: F401
+from .loss import ClassDistances, KLDLoss, KLDLossGroup, PixelWiseCrossEntropyLoss  # noqa: F401
 from .model import PPNet  # noqa: F401
 from .model_multiscale import PPNetMultiScale, construct_PPNet  # noqa: F401
 from .model_multiscale_group import PPNetMultiScaleGroup, construct_PPNet_Group  # noqa: F401

@@ -202,6 +202,12 @@ class KLDLoss(nn.Module):
         else:
             table = class_slot_table(self.prototype_class_identity)
             vals = gather_class_distances(prototype_distances, labels0, table)
+        planes = prototype_distances.values if isinstance(prototype_distances, ClassDistances) else None
+        return self._forward_gathered(vals, planes, labels0, table)
+
+    def _forward_gathered(self, vals: torch.Tensor, planes, labels0: torch.Tensor, table: torch.Tensor) -> torch.Tensor:
+        """Loss from the class-gathered values ``vals`` [B, H*W, J] (``planes``: the same as [B, J, H*W], if the caller
+        already holds that layout)."""
         dev = vals.device
         table = table.to(dev)
         K, J = table.shape
@@ -209,7 +215,6 @@ class KLDLoss(nn.Module):
         lab = labels0.to(dev)
         ok = ((lab >= 0) & (lab < K)).reshape(-1)
         nseg = B * K
-        planes = prototype_distances.values if isinstance(prototype_distances, ClassDistances) else None
         if planes is None and _kld_kernels_usable(vals, K, J):
             planes = vals.permute(0, 2, 1).contiguous()      # full map given: its gathered entries as [B, J, H*W] planes
         if planes is not None and _kld_kernels_usable(planes, K, J):
@@ -263,3 +268,56 @@ class KLDLoss(nn.Module):
         n = valid.sum()
         total = torch.where(valid, torch.exp(-kld), torch.zeros_like(kld)).sum()
         return torch.where(n > 0, total / n.clamp_min(1).to(total.dtype), torch.zeros_like(total))
+
+
+class KLDLossGroup(KLDLoss):
+    """Drop-in for segmentation/model/loss.py:461-545: same constructor, same ``forward(list_group_activation,
+    target_labels)``.  The groups of a pixel's class play the role KLDLoss gives the class's prototypes (every group
+    pair of a class is compared, loss.py:527-536), so the segment kernels are shared; ``list_group_activation`` may
+    also be the concatenated [M, n_projections * num_groups] tensor the grouping head produces."""
+
+    def __init__(self, prototype_class_identity: torch.Tensor, group_class_identity: torch.Tensor, num_groups: int) -> None:
+        nn.Module.__init__(self)
+        self.prototype_class_identity = prototype_class_identity
+        self.group_class_identity = group_class_identity
+        self.num_groups = num_groups
+        self._tables = None
+
+    def _class_tables(self):
+        """(projection of class c or -1 [K], stand-in slot table [K, G]: slot ids where the class has a projection)."""
+        if self._tables is None:
+            ident, gci, G = self.prototype_class_identity, self.group_class_identity, self.num_groups
+            K = ident.shape[1]
+            has = ident.sum(dim=0) > 0                                              # loss.py:504
+            proj = torch.where(has, gci.argmax(dim=0) // G, torch.full((K,), -1, dtype=torch.long)).cpu()   # :507
+            table = torch.where(has.cpu().unsqueeze(1), torch.arange(G).unsqueeze(0).expand(K, G), torch.full((K, G), -1, dtype=torch.long))
+            self._tables = (proj, table.contiguous())
+        return self._tables
+
+    def _pair_mask_build(self, table: torch.Tensor) -> torch.Tensor:
+        K, J = table.shape
+        upper = torch.triu(torch.ones(J, J, dtype=torch.bool), diagonal=1)
+        return upper.unsqueeze(0) & (table.cpu()[:, :1] >= 0).unsqueeze(2)
+
+    def _pair_mask(self, table: torch.Tensor) -> torch.Tensor:
+        cached = getattr(self, "_pair_mask_cache", None)
+        if cached is None or cached[0] != str(table.device):
+            cached = (str(table.device), self._pair_mask_build(table).to(table.device))
+            self._pair_mask_cache = cached
+        return cached[1]
+
+    def forward(self, list_group_activation, target_labels: torch.Tensor) -> torch.Tensor:
+        G = self.num_groups
+        labels0 = target_labels.reshape(target_labels.shape[0], -1).long() - 1          # loss.py:493
+        B, HW = labels0.shape
+        proj, table = self._class_tables()
+        K = table.shape[0]
+        if isinstance(list_group_activation, torch.Tensor):
+            ga = list_group_activation.reshape(B, HW, -1, G)
+        else:
+            ga = torch.stack([a.reshape(B, HW, G) for a in list_group_activation], dim=2)
+        dev = ga.device
+        lab = labels0.to(dev)
+        pix_proj = proj.to(dev)[lab.clamp(0, K - 1)].clamp_min(0)                       # [B, HW]; unused where no class
+        vals = torch.gather(ga, 2, pix_proj.view(B, HW, 1, 1).expand(B, HW, 1, G)).squeeze(2)      # [B, HW, G]
+        return self._forward_gathered(vals, None, labels0, table)

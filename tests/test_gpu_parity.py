@@ -763,3 +763,30 @@ def test_kld_kernels_large_random():
         assert abs(l1.item() - l2.item()) <= 1e-5 * max(1.0, abs(l2.item())), (l1.item(), l2.item())
         s = v2.grad.abs().max().item()
         assert (v1.grad.double() - v2.grad).abs().max().item() <= 1e-4 * s + 1e-12
+
+
+def test_kld_group_kernels_match_reference_golden(golden):
+    """KLDLossGroup on the GPU (class-gathered group activations through csrc/spx_kld.hip) against the reference's
+    KLDLossGroup value and gradients (segmentation/model/loss.py:461-545), run-to-run bit-identical."""
+    import scaleprotoseg_amd as spx
+
+    dev = _dev()
+    g = golden("kld_loss")
+    n = int(g["grp_n"])
+    t = torch.from_numpy(g["grp_target"]).to(dev)
+    m = spx.KLDLossGroup(torch.from_numpy(g["grp_ident"]), torch.from_numpy(g["grp_gci"]), int(g["grp_G"]))
+
+    def run():
+        acts = [torch.from_numpy(g[f"grp_act{i}"]).to(dev).requires_grad_(True) for i in range(n)]
+        loss = m(acts, t)
+        loss.backward()
+        torch.cuda.synchronize()
+        return loss.detach().cpu(), [a.grad.cpu() for a in acts]
+
+    l1, g1 = run()
+    l2, g2 = run()
+    assert torch.equal(l1, l2) and all(torch.equal(a, b) for a, b in zip(g1, g2))
+    assert abs(l1.item() - float(g["grp_loss"])) <= 2e-6, (l1.item(), float(g["grp_loss"]))
+    for i, a in enumerate(g1):
+        ref = torch.from_numpy(g[f"grp_grad{i}"])
+        assert (a - ref).abs().max().item() <= 2e-5 * ref.abs().max().item() + 1e-9

@@ -220,3 +220,25 @@ def test_cross_entropy_matches_reference(golden):
     assert abs(ce.item() - float(g["ce_loss"])) <= 1e-6
     np.testing.assert_allclose(lg.grad.numpy(), g["ce_grad"], atol=1e-7)
     np.testing.assert_array_equal(correct.numpy().astype(np.int64), g["ce_correct"])
+
+
+def test_kld_loss_group_module_matches_reference(golden):
+    """scaleprotoseg_amd.loss.KLDLossGroup (host logic, torch formulation on the CPU) against the reference's golden
+    value and gradients; list input (the reference's) and the concatenated [M, U] tensor give the same loss."""
+    import numpy as np
+    from scaleprotoseg_amd.loss import KLDLossGroup
+
+    g = golden("kld_loss")
+    n = int(g["grp_n"])
+    acts = [torch.from_numpy(g[f"grp_act{i}"]).requires_grad_(True) for i in range(n)]
+    t = torch.from_numpy(g["grp_target"])
+    m = KLDLossGroup(torch.from_numpy(g["grp_ident"]), torch.from_numpy(g["grp_gci"]), int(g["grp_G"]))
+    loss = m(acts, t)
+    loss.backward()
+    assert abs(loss.item() - float(g["grp_loss"])) <= 1e-6
+    for i, a in enumerate(acts):
+        ref = g[f"grp_grad{i}"]
+        assert np.abs(a.grad.numpy() - ref).max() <= 1e-5 * max(np.abs(ref).max(), 1e-12)
+    cat = torch.cat([a.detach() for a in acts], dim=1)
+    assert abs(m(cat, t).item() - loss.item()) <= 1e-7
+    assert m(acts, torch.zeros_like(t)).item() == 0.0                      # void only: no term (loss.py:541-542)

@@ -143,3 +143,16 @@ def test_kld_loss_matches_reference(golden, tag):
     assert np.abs(d.grad.numpy() - g[f"{tag}_grad"]).max() <= 1e-8
     assert float(g["empty_loss"]) == 0.0
     assert O.kld_loss(torch.rand(1, 8, 3, 3), torch.zeros(1, 3, 3, dtype=torch.long), O.default_class_identity(8, 4, 1), 1, {0: (0, 8)}).item() == 0.0
+
+
+def test_kld_loss_group_matches_reference(golden):
+    """oracle.kld_loss_group vs the reference's KLDLossGroup (segmentation/model/loss.py:461-545): value and gradient;
+    one class of the fixture owns no prototypes (its pixels must contribute nothing)."""
+    g = golden("kld_loss")
+    n = int(g["grp_n"])
+    acts = [torch.from_numpy(g[f"grp_act{i}"]).requires_grad_(True) for i in range(n)]
+    loss = O.kld_loss_group(acts, torch.from_numpy(g["grp_target"]), torch.from_numpy(g["grp_ident"]), torch.from_numpy(g["grp_gci"]), int(g["grp_G"]))
+    loss.backward()
+    assert abs(loss.item() - float(g["grp_loss"])) <= 1e-7
+    for i, a in enumerate(acts):
+        assert np.abs(a.grad.numpy() - g[f"grp_grad{i}"]).max() <= 1e-8
