@@ -35,7 +35,7 @@ extern "C" {
 #endif
 
 #define SPX_MAX_PANELS 64   /* (scale, <=192-prototype block) work units per pixel tile */
-#define SPX_ABI_VERSION 4
+#define SPX_ABI_VERSION 5
 
 /* How the prototype bank is cut into MFMA panels.  Filled by spx_make_plan(). */
 typedef struct spx_plan {
@@ -184,17 +184,21 @@ int spx_argmin_images(const float* values, int32_t N, int32_t P, int64_t* best, 
  *                          (key k -> float: k & 0x80000000 ? k ^ 0x80000000 : ~k); counts uint32 [B, K] (zero-filled,
  *                          may be NULL): pixels per segment (loss.py:113-127 skips segments of fewer than two)
  *   spx_kld_segment_sumexp ssum_fx uint64 [B, K, J] (zero-filled): sum_px exp(vals - smax) * 2^40
- *   spx_kld_pair_sums      a_fx int64 [B, K, J, J] (zero-filled): sum_px p_j * l_k * scale (scale: ONE double in DEVICE
- *                          memory, so the caller can derive it from the data without a host sync), l = vals - lse (the
- *                          log_softmax over the segment's pixels, loss.py:110), p = exp(l)
+ *   spx_kld_pair_sums      a_fx int64 [B, K, J, J] (zero-filled): sum_px p_j * (l_k - l_j) * scale = -KL(j || k) of the
+ *                          segment, i.e. the Gram matrix sum_px p_j l_k minus its row's diagonal entry (diagonal 0);
+ *                          scale: ONE double in DEVICE memory, so the caller can derive it from the data without a
+ *                          host sync; l = vals - lse (the log_softmax over the segment's pixels, loss.py:110), p = exp(l).
+ *                          W: row length of the pixel grid (must divide HW) lets the kernel walk column strips, which
+ *                          cross fewer class boundaries; 0 = unknown (linear walk).  W changes only the rounding of fp32 partial sums.
  *   spx_kld_backward       grad fp32 [B, J, HW] = dLoss/dvals given A = a_fx / scale and Cf = dLoss/dA [B, K, J, J]
+ *                          (diagonal entries of Cf are not read: A's diagonal is identically 0)
  * The [B, K, J, J]-sized algebra between the passes (loss.py:113-142: symmetric KL of the slot pairs of one scale,
  * exp(-kld), mean) is left to the caller.  J <= 16 and K*J*J*8 bytes must fit the LDS table (~60 KiB). */
 int spx_kld_segment_max(const float* vals, const int32_t* labels, int32_t B, int32_t J, int32_t HW, int32_t K,
                         uint32_t* smax_keys, uint32_t* counts, void* stream);
 int spx_kld_segment_sumexp(const float* vals, const int32_t* labels, int32_t B, int32_t J, int32_t HW, int32_t K,
                            const float* smax, uint64_t* ssum_fx, void* stream);
-int spx_kld_pair_sums(const float* vals, const int32_t* labels, int32_t B, int32_t J, int32_t HW, int32_t K,
+int spx_kld_pair_sums(const float* vals, const int32_t* labels, int32_t B, int32_t J, int32_t HW, int32_t W, int32_t K,
                       const float* lse, const double* scale, int64_t* a_fx, void* stream);
 int spx_kld_backward(const float* vals, const int32_t* labels, int32_t B, int32_t J, int32_t HW, int32_t K,
                      const float* lse, const float* A, const float* Cf, float* grad, void* stream);

@@ -15,7 +15,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libspx_hip.so")
 SPX_MAX_PANELS = 64
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class SpxError(RuntimeError):
@@ -71,7 +71,7 @@ SIGNATURES = {
     "spx_argmin_images": (C.c_int, [_V, _I, _I, _V, _V]),
     "spx_kld_segment_max": (C.c_int, [_V, _V, _I, _I, _I, _I, _V, _V, _V]),
     "spx_kld_segment_sumexp": (C.c_int, [_V, _V, _I, _I, _I, _I, _V, _V, _V]),
-    "spx_kld_pair_sums": (C.c_int, [_V, _V, _I, _I, _I, _I, _V, _V, _V, _V]),
+    "spx_kld_pair_sums": (C.c_int, [_V, _V, _I, _I, _I, _I, _I, _V, _V, _V, _V]),
     "spx_kld_backward": (C.c_int, [_V, _V, _I, _I, _I, _I, _V, _V, _V, _V, _V]),
     "spx_upsample_argext": (C.c_int, [_V, _I, _I, _I, _I, _I, _I, _I, _V, _V, _V]),
 }

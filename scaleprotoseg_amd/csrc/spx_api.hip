@@ -365,23 +365,24 @@ static int kld_check(const char* who, const float* vals, const int32_t* labels, 
 int spx_kld_segment_max(const float* vals, const int32_t* labels, int32_t B, int32_t J, int32_t HW, int32_t K,
                         uint32_t* smax_keys, uint32_t* counts, void* stream) {
     if (kld_check("spx_kld_segment_max", vals, labels, B, J, HW, K, smax_keys, 0)) return 1;
-    return hip_status(spx_launch_kld(0, vals, labels, B, J, HW, K, (const float*)counts, nullptr, nullptr, nullptr, smax_keys, (hipStream_t)stream), "spx_kld_segment_max");
+    return hip_status(spx_launch_kld(0, vals, labels, B, J, HW, 0, K, (const float*)counts, nullptr, nullptr, nullptr, smax_keys, (hipStream_t)stream), "spx_kld_segment_max");
 }
 int spx_kld_segment_sumexp(const float* vals, const int32_t* labels, int32_t B, int32_t J, int32_t HW, int32_t K,
                            const float* smax, uint64_t* ssum_fx, void* stream) {
     if (kld_check("spx_kld_segment_sumexp", vals, labels, B, J, HW, K, ssum_fx, 0) || !smax) return smax ? 1 : fail("spx_kld_segment_sumexp: NULL smax");
-    return hip_status(spx_launch_kld(1, vals, labels, B, J, HW, K, smax, nullptr, nullptr, nullptr, ssum_fx, (hipStream_t)stream), "spx_kld_segment_sumexp");
+    return hip_status(spx_launch_kld(1, vals, labels, B, J, HW, 0, K, smax, nullptr, nullptr, nullptr, ssum_fx, (hipStream_t)stream), "spx_kld_segment_sumexp");
 }
-int spx_kld_pair_sums(const float* vals, const int32_t* labels, int32_t B, int32_t J, int32_t HW, int32_t K,
+int spx_kld_pair_sums(const float* vals, const int32_t* labels, int32_t B, int32_t J, int32_t HW, int32_t W, int32_t K,
                       const float* lse, const double* scale, int64_t* a_fx, void* stream) {
     if (kld_check("spx_kld_pair_sums", vals, labels, B, J, HW, K, a_fx, 1) || !lse || !scale) return (lse && scale) ? 1 : fail("spx_kld_pair_sums: NULL lse / scale");
-    return hip_status(spx_launch_kld(2, vals, labels, B, J, HW, K, lse, nullptr, nullptr, scale, a_fx, (hipStream_t)stream), "spx_kld_pair_sums");
+    if (W < 0 || (W > 0 && HW % W != 0)) return fail("spx_kld_pair_sums: W must be 0 or divide HW");
+    return hip_status(spx_launch_kld(2, vals, labels, B, J, HW, W, K, lse, nullptr, nullptr, scale, a_fx, (hipStream_t)stream), "spx_kld_pair_sums");
 }
 int spx_kld_backward(const float* vals, const int32_t* labels, int32_t B, int32_t J, int32_t HW, int32_t K,
                      const float* lse, const float* A, const float* Cf, float* grad, void* stream) {
     if (kld_check("spx_kld_backward", vals, labels, B, J, HW, K, grad, 1)) return 1;
     if (!lse || !A || !Cf) return fail("spx_kld_backward: NULL table");
-    return hip_status(spx_launch_kld(3, vals, labels, B, J, HW, K, lse, A, Cf, nullptr, grad, (hipStream_t)stream), "spx_kld_backward");
+    return hip_status(spx_launch_kld(3, vals, labels, B, J, HW, 0, K, lse, A, Cf, nullptr, grad, (hipStream_t)stream), "spx_kld_backward");
 }
 
 }  // extern "C"

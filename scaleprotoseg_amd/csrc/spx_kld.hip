@@ -4,6 +4,7 @@
 // (image, class); per segment and slot j the reference takes log_softmax of the slot's distances over the segment's
 // pixels, then the symmetric KL of every slot pair, which is a function of the segment Gram matrix
 //     A[seg][j][k] = sum_px p_j(px) * l_k(px),   l = log_softmax, p = exp(l)
+// (kept as A[j][k] - A[j][j]: see spx_kld_pairs_kernel)
 // Four streaming passes over vals (each 4 J bytes per pixel, nothing else): segment max, segment sum-exp, A, and the
 // gradient (which needs no further reduction: see spx_kld_backward_kernel).  Segment reductions use per-workgroup LDS
 // tables and INTEGER atomics (ordered float keys for the max, 64-bit fixed point for the sums), so results do not
@@ -13,6 +14,7 @@
 #define SPX_KLD_THREADS 256
 #define SPX_KLD_PX_PER_WG 2048
 #define SPX_KLD_MAXJ 16
+#define SPX_KLD_STRIP_ROWS 16           // pair sums, W given: rows of a wave's 64-pixel-wide column strip
 
 __device__ __forceinline__ double wave_sum_f64(double v) {
 #pragma unroll
@@ -105,25 +107,69 @@ __global__ __launch_bounds__(SPX_KLD_THREADS) void spx_kld_sumexp_kernel(const f
         if (tab[i]) atomicAdd(&ssum_fx[(size_t)b * K * J + i], tab[i]);
 }
 
-// pass 2: A_fx[b][c][j][k] = sum_px p_j * l_k in signed fixed point (scale given by the host from the pixel count)
+// pass 2: A_fx[b][c][j][k] = sum_px p_j * (l_k - l_j) in signed fixed point (scale given by the caller from the pixel
+// count): the Gram matrix MINUS its row's diagonal entry, i.e. -KL(j || k) of the segment.  The loss and the gradient
+// only ever use A[j][k] - A[j][j] (rows of dLoss/dA sum to zero), and in this form the sums are small numbers built
+// from small terms instead of differences of large ones, so a thread can carry them in fp32 registers across its
+// pixels: a wave walks 64-pixel steps of ONE contiguous range and reduces + publishes (wave butterfly in fp64, one
+// LDS integer atomic per entry) only when the class changes or its range ends.  Steps whose 64 pixels are not all of
+// one class take the per-lane atomic path.
 template <int JT>
 __global__ __launch_bounds__(SPX_KLD_THREADS) void spx_kld_pairs_kernel(const float* __restrict__ vals, const int32_t* __restrict__ labels,
-                                                                       int J, int HW, int K, const float* __restrict__ lse,
+                                                                       int J, int HW, int W, int K, const float* __restrict__ lse,
                                                                        const double* __restrict__ scale_p, unsigned long long* __restrict__ A_fx) {
     extern __shared__ unsigned long long kld_smem[];
     unsigned long long* tab = kld_smem;                    // [K][J][J], two's complement
-    const int b = blockIdx.y, tid = threadIdx.x;
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const double scale = *scale_p;                         // device-side: the host never reads the data (no sync)
     for (int i = tid; i < K * J * J; i += SPX_KLD_THREADS) tab[i] = 0ull;
     __syncthreads();
     const float* v = vals + (size_t)b * J * HW;
     const int32_t* lab = labels + (size_t)b * HW;
     const float* ls = lse + (size_t)b * K * J;
-    const int px_end = min(HW, (int)(blockIdx.x + 1) * SPX_KLD_PX_PER_WG);
-    for (int px = blockIdx.x * SPX_KLD_PX_PER_WG + tid; px - tid < px_end; px += SPX_KLD_THREADS) {
-        const int c = px < px_end ? lab[px] : -1;
+    // W > 0: the pixels are rows of W and a wave walks DOWN a 64-pixel-wide column strip (label maps are coherent in both
+    // directions; a strip crosses far fewer class boundaries than the same pixels taken along one row).  W == 0: linear.
+    int first, stride, nsteps, nvalid;                     // this lane's pixel of step s is first + s*stride, s < nsteps
+    if (W > 0) {
+        const int tiles_x = (W + SPX_KLD_THREADS - 1) / SPX_KLD_THREADS, H = HW / W;
+        const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+        const int col = tx * SPX_KLD_THREADS + wave * 64 + lane, row0 = ty * SPX_KLD_STRIP_ROWS;
+        nsteps = min(SPX_KLD_STRIP_ROWS, H - row0);
+        if (tx * SPX_KLD_THREADS + wave * 64 >= W) nsteps = 0;          // wave-uniform
+        first = row0 * W + col;
+        stride = W;
+        nvalid = col < W ? nsteps : 0;
+    } else {
+        constexpr int PX_PER_WAVE = SPX_KLD_PX_PER_WG / (SPX_KLD_THREADS / 64);
+        const int px0 = blockIdx.x * SPX_KLD_PX_PER_WG + wave * PX_PER_WAVE;
+        nsteps = px0 < HW ? min(PX_PER_WAVE / 64, (HW - px0 + 63) / 64) : 0;
+        first = px0 + lane;
+        stride = 64;
+        nvalid = first < HW ? (HW - first + 63) / 64 : 0;
+    }
+    float acc[JT][JT];
+#pragma unroll
+    for (int j = 0; j < JT; ++j)
+#pragma unroll
+        for (int k = 0; k < JT; ++k) acc[j][k] = 0.0f;
+    int cur = -1;                                          // class the accumulators belong to (wave-uniform)
+    auto publish = [&]() {
+        if (cur < 0) return;
+#pragma unroll
+        for (int j = 0; j < JT; ++j)
+#pragma unroll
+            for (int k = 0; k < JT; ++k)
+                if (j != k && j < J && k < J) {
+                    const double s = wave_sum_f64((double)acc[j][k]);
+                    if (lane == 0) atomicAdd(&tab[(cur * J + j) * J + k], (unsigned long long)(long long)llrint(s * scale));
+                    acc[j][k] = 0.0f;
+                }
+    };
+    for (int step = 0; step < nsteps; ++step) {
+        const int px = first + step * stride;
+        const int c = step < nvalid ? lab[px] : -1;
         const bool ok = c >= 0 && c < K;
-        const int c0 = __shfl(c, 0);
+        const int c0 = __builtin_amdgcn_readfirstlane(c);
         const bool uniform = __builtin_amdgcn_ballot_w64(c != c0) == 0;
         float l[JT], p[JT];          // JT = J rounded up to a multiple of 4: static indices, padded slots contribute 0
 #pragma unroll
@@ -131,28 +177,35 @@ __global__ __launch_bounds__(SPX_KLD_THREADS) void spx_kld_pairs_kernel(const fl
             l[j] = (ok && j < J) ? v[(size_t)j * HW + px] - ls[c * J + j] : 0.0f;
             p[j] = (ok && j < J) ? __expf(l[j]) : 0.0f;
         }
+        if (uniform) {
+            if (!ok) continue;                             // a step of void pixels
+            if (c0 != cur) {
+                publish();
+                cur = c0;
+            }
 #pragma unroll
-        for (int j = 0; j < JT; ++j) {
+            for (int j = 0; j < JT; ++j)
 #pragma unroll
-            for (int k = 0; k < JT; ++k) {
-                if (j < J && k < J) {             // wave-uniform
-                    const double t = (double)p[j] * (double)l[k];
-                    if (uniform) {
-                        const double s = wave_sum_f64(t);
-                        if ((tid & 63) == 0 && ok) atomicAdd(&tab[(c * J + j) * J + k], (unsigned long long)(long long)llrint(s * scale));
-                    } else if (ok) {
+                for (int k = 0; k < JT; ++k)
+                    if (j != k) acc[j][k] = fmaf(p[j], l[k] - l[j], acc[j][k]);
+        } else if (ok) {
+#pragma unroll
+            for (int j = 0; j < JT; ++j)
+#pragma unroll
+                for (int k = 0; k < JT; ++k)
+                    if (j != k && j < J && k < J) {
+                        const double t = (double)p[j] * (double)(l[k] - l[j]);
                         atomicAdd(&tab[(c * J + j) * J + k], (unsigned long long)(long long)llrint(t * scale));
                     }
-                }
-            }
         }
     }
+    publish();
     __syncthreads();
     for (int i = tid; i < K * J * J; i += SPX_KLD_THREADS)
         if (tab[i]) atomicAdd(&A_fx[(size_t)b * K * J * J + i], tab[i]);
 }
 
-// pass 3: gradient.  With Cf = dLoss/dA (per segment, from the host) and sum_px p_j = 1:
+// pass 3: gradient.  With Cf = dLoss/d(Gram) (per segment; built below from the caller's dLoss/dA) and sum_px p_j = 1:
 //   dLoss/dd_m(px) = p_m * [ sum_k Cf[m][k] (l_k - A[m][k]) - sum_j Cf[j][m] ] + sum_j Cf[j][m] p_j
 // - per pixel, given the segment's A and Cf: no reduction.
 template <int JT>
@@ -171,6 +224,16 @@ __global__ __launch_bounds__(SPX_KLD_THREADS) void spx_kld_backward_kernel(const
         sC[i] = Cf[(size_t)b * K * J * J + i];
     }
     for (int i = tid; i < K * J; i += SPX_KLD_THREADS) sL[i] = lse[(size_t)b * K * J + i];
+    __syncthreads();
+    // A holds A[j][k] - A[j][j] (pass 2), so dLoss/d(Gram) has the off-diagonal entries of Cf and zero row sums;
+    // with zero row sums the A[m][m] offset drops out of sum_k Cf[m][k] (l_k - A[m][k]) below
+    for (int i = tid; i < K * J; i += SPX_KLD_THREADS) {
+        const int c = i / J, m = i - c * J;
+        float s = 0.0f;
+        for (int k = 0; k < J; ++k)
+            if (k != m) s += sC[(c * J + m) * J + k];
+        sC[(c * J + m) * J + m] = -s;
+    }
     __syncthreads();
     for (int i = tid; i < K * J; i += SPX_KLD_THREADS) {
         const int c = i / J, m = i - c * J;
@@ -213,7 +276,7 @@ __global__ __launch_bounds__(SPX_KLD_THREADS) void spx_kld_backward_kernel(const
     }
 }
 
-hipError_t spx_launch_kld(int pass, const float* vals, const int32_t* labels, int B, int J, int HW, int K, const float* t0,
+hipError_t spx_launch_kld(int pass, const float* vals, const int32_t* labels, int B, int J, int HW, int W, int K, const float* t0,
                           const float* t1, const float* t2, const double* scale, void* out, hipStream_t s) {
     dim3 grid((unsigned)((HW + SPX_KLD_PX_PER_WG - 1) / SPX_KLD_PX_PER_WG), (unsigned)B);
     dim3 blk(SPX_KLD_THREADS);
@@ -224,10 +287,11 @@ hipError_t spx_launch_kld(int pass, const float* vals, const int32_t* labels, in
     else if (pass == 2) {
         const size_t lds = (size_t)K * J * J * 8;
         unsigned long long* o = (unsigned long long*)out;
-        if (J <= 4) hipLaunchKernelGGL(spx_kld_pairs_kernel<4>, grid, blk, lds, s, vals, labels, J, HW, K, t0, scale, o);
-        else if (J <= 8) hipLaunchKernelGGL(spx_kld_pairs_kernel<8>, grid, blk, lds, s, vals, labels, J, HW, K, t0, scale, o);
-        else if (J <= 12) hipLaunchKernelGGL(spx_kld_pairs_kernel<12>, grid, blk, lds, s, vals, labels, J, HW, K, t0, scale, o);
-        else hipLaunchKernelGGL(spx_kld_pairs_kernel<16>, grid, blk, lds, s, vals, labels, J, HW, K, t0, scale, o);
+        if (W > 0) grid.x = (unsigned)(((W + SPX_KLD_THREADS - 1) / SPX_KLD_THREADS) * ((HW / W + SPX_KLD_STRIP_ROWS - 1) / SPX_KLD_STRIP_ROWS));
+        if (J <= 4) hipLaunchKernelGGL(spx_kld_pairs_kernel<4>, grid, blk, lds, s, vals, labels, J, HW, W, K, t0, scale, o);
+        else if (J <= 8) hipLaunchKernelGGL(spx_kld_pairs_kernel<8>, grid, blk, lds, s, vals, labels, J, HW, W, K, t0, scale, o);
+        else if (J <= 12) hipLaunchKernelGGL(spx_kld_pairs_kernel<12>, grid, blk, lds, s, vals, labels, J, HW, W, K, t0, scale, o);
+        else hipLaunchKernelGGL(spx_kld_pairs_kernel<16>, grid, blk, lds, s, vals, labels, J, HW, W, K, t0, scale, o);
     } else {
         const size_t lds = (size_t)(2 * K * J * J + 2 * K * J) * 4;
         float* o = (float*)out;

@@ -110,10 +110,11 @@ def _kld_kernels_usable(vals: torch.Tensor, K: int, J: int) -> bool:
 
 class _KLDSegmentGram(torch.autograd.Function):
     """(A [B,K,J,J], lse [B,K,J]) of class-gathered distances through the HIP kernels (csrc/spx_kld.hip): A[seg][j][k] =
-    sum_px p_j l_k with l the log_softmax over the segment's pixels.  Backward: dLoss/dvals from dLoss/dA, per pixel."""
+    sum_px p_j (l_k - l_j) = -KL(j || k), l the log_softmax over the segment's pixels (the Gram matrix sum p_j l_k of
+    the torch path minus its row's diagonal entry: the loss only uses those differences).  Backward: dLoss/dvals from dLoss/dA, per pixel."""
 
     @staticmethod
-    def forward(ctx, vals, labels, K):
+    def forward(ctx, vals, labels, K, W=0):
         from . import _lib
 
         lib = _lib.load()
@@ -136,11 +137,11 @@ class _KLDSegmentGram(torch.autograd.Function):
         lse = (smax.double() + torch.log(ssum.clamp_min(1e-300))).float()
         lse = torch.where(seen, lse, torch.zeros_like(lse)).contiguous()
         # fixed-point scale of the Gram sums (a power of two, computed on the device: no host sync): |p * l| is bounded
-        # by the value range of a slot, and HW terms must stay inside int64
+        # by twice the value range of a slot (the sums are p_j (l_k - l_j)), and HW terms must stay inside int64
         span = (v.amax() - v.amin()).double() + 32.0
-        scale = torch.exp2(torch.floor(torch.log2((2.0 ** 62) / (HW * span)))).reshape(1).contiguous()
+        scale = torch.exp2(torch.floor(torch.log2((2.0 ** 61) / (HW * span)))).reshape(1).contiguous()
         a_fx = torch.zeros((B, K, J, J), dtype=torch.int64, device=dev)
-        _lib.check(lib.spx_kld_pair_sums(_lib.ptr(v), _lib.ptr(lab), B, J, HW, K, _lib.ptr(lse), _lib.ptr(scale), _lib.ptr(a_fx), s))
+        _lib.check(lib.spx_kld_pair_sums(_lib.ptr(v), _lib.ptr(lab), B, J, HW, int(W) if W and HW % int(W) == 0 else 0, K, _lib.ptr(lse), _lib.ptr(scale), _lib.ptr(a_fx), s))
         A = (a_fx.to(torch.float64) / scale).float()
         ctx.save_for_backward(v, lab, lse, A)
         ctx.K = K
@@ -157,7 +158,7 @@ class _KLDSegmentGram(torch.autograd.Function):
         grad = torch.empty_like(v)
         cf = gA.contiguous().float()
         _lib.check(lib.spx_kld_backward(_lib.ptr(v), _lib.ptr(lab), B, J, HW, ctx.K, _lib.ptr(lse), _lib.ptr(A.contiguous()), _lib.ptr(cf), _lib.ptr(grad), _lib.stream_ptr()))
-        return grad, None, None
+        return grad, None, None, None
 
 
 class KLDLoss(nn.Module):
@@ -203,11 +204,12 @@ class KLDLoss(nn.Module):
             table = class_slot_table(self.prototype_class_identity)
             vals = gather_class_distances(prototype_distances, labels0, table)
         planes = prototype_distances.values if isinstance(prototype_distances, ClassDistances) else None
-        return self._forward_gathered(vals, planes, labels0, table)
+        width = prototype_distances.grid[-1] if isinstance(prototype_distances, ClassDistances) else prototype_distances.shape[-1]
+        return self._forward_gathered(vals, planes, labels0, table, width)
 
-    def _forward_gathered(self, vals: torch.Tensor, planes, labels0: torch.Tensor, table: torch.Tensor) -> torch.Tensor:
+    def _forward_gathered(self, vals: torch.Tensor, planes, labels0: torch.Tensor, table: torch.Tensor, width: int = 0) -> torch.Tensor:
         """Loss from the class-gathered values ``vals`` [B, H*W, J] (``planes``: the same as [B, J, H*W], if the caller
-        already holds that layout)."""
+        already holds that layout; ``width``: W of the pixel grid if known, a traversal hint for the kernels)."""
         dev = vals.device
         table = table.to(dev)
         K, J = table.shape
@@ -220,7 +222,7 @@ class KLDLoss(nn.Module):
         if planes is not None and _kld_kernels_usable(planes, K, J):
             # the gathered planes on the GPU: segment statistics and the gradient run in the HIP kernels; nothing on
             # this path reads a value back to the host (capturable in a HIP graph)
-            A, _, counts = _KLDSegmentGram.apply(planes, lab, K)
+            A, _, counts = _KLDSegmentGram.apply(planes, lab, K, width)
             return self._loss_from_gram(A.reshape(nseg, J, J), counts.reshape(nseg), table, K, nseg)
         if not bool(ok.any()):
             return torch.tensor(0.0)
@@ -320,4 +322,4 @@ class KLDLossGroup(KLDLoss):
         lab = labels0.to(dev)
         pix_proj = proj.to(dev)[lab.clamp(0, K - 1)].clamp_min(0)                       # [B, HW]; unused where no class
         vals = torch.gather(ga, 2, pix_proj.view(B, HW, 1, 1).expand(B, HW, 1, G)).squeeze(2)      # [B, HW, G]
-        return self._forward_gathered(vals, None, labels0, table)
+        return self._forward_gathered(vals, None, labels0, table, target_labels.shape[-1] if target_labels.dim() >= 3 else 0)

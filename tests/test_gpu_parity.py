@@ -790,3 +790,37 @@ def test_kld_group_kernels_match_reference_golden(golden):
     for i, a in enumerate(g1):
         ref = torch.from_numpy(g[f"grp_grad{i}"])
         assert (a - ref).abs().max().item() <= 2e-5 * ref.abs().max().item() + 1e-9
+
+
+@pytest.mark.parametrize("H,W", [(67, 333), (5, 64), (130, 257), (1, 1000)])
+def test_kld_kernels_ragged_grids(H, W):
+    """Pair-sum kernel on grids that do not fill its 256-column x 16-row strips (and the linear walk, W unknown):
+    against the fp64 torch formulation of the same loss, value and gradient."""
+    import scaleprotoseg_amd as spx
+    from scaleprotoseg_amd import loss as L
+
+    dev = _dev()
+    P, K, S = 60, 6, 1
+    ident = O.default_class_identity(P, K, S)
+    lay = _layout(P, K, S, 16, O.default_scale_ranges(P, S))
+    keys, J, table = spx.class_gather_table(lay, ident, dev)
+    gen = torch.Generator(device=dev).manual_seed(H * 1000 + W)
+    t = torch.randint(0, K + 1, (2, (H + 7) // 8, (W + 15) // 16), device=dev, generator=gen).repeat_interleave(8, 1).repeat_interleave(16, 2)[:, :H, :W].contiguous()
+    base = torch.rand(2, J, H * W, device=dev, generator=gen) * 30
+    loss_fn = spx.KLDLoss(ident, S, {0: (0, P)})
+    lab = (t.reshape(2, -1) - 1).int()
+    v2 = base.double().clone().requires_grad_(True)
+    l2 = loss_fn(spx.ClassDistances(v2, lab, table, (H, W)), t)
+    l2.backward()
+    for grid in ((H, W), (1, H * W)):               # column strips / one row (= the linear order)
+        v1 = base.clone().requires_grad_(True)
+        l1 = loss_fn(spx.ClassDistances(v1, lab, table, grid), t)
+        l1.backward()
+        torch.cuda.synchronize()
+        assert abs(l1.item() - l2.item()) <= 1e-5 * max(1.0, abs(l2.item())), (grid, l1.item(), l2.item())
+        s = v2.grad.abs().max().item()
+        assert (v1.grad.double() - v2.grad).abs().max().item() <= 1e-4 * s + 1e-12
+    # W = 0 through the C ABI gives the same sums as the column walk up to fp32 rounding of partial sums
+    A_w, _, _ = L._KLDSegmentGram.apply(base, lab, K, W)
+    A_0, _, _ = L._KLDSegmentGram.apply(base, lab, K, 0)
+    assert (A_w - A_0).abs().max().item() <= 1e-5 * (1.0 + A_0.abs().max().item())
