@@ -118,8 +118,8 @@ __global__ __launch_bounds__(SPX_BK_THREADS, 2) void spx_bank_bwd_kernel(const S
 #pragma unroll
         for (int i = 0; i < FP; ++i) {
             const uint32_t off = (uint32_t)((i * SPX_BK_THREADS + tid) * 16);
-            gr[i] = buf_load_b128(grs, (want_p && off < (uint32_t)FBYTES) ? off : SPX_OOB, 0);
-            ar[i] = buf_load_b128(ars, (want_w && off < (uint32_t)FBYTES) ? off : SPX_OOB, 0);
+            gr[i] = buf_load_b128_p<SPX_AUX_BLOB_LD>(grs, (want_p && off < (uint32_t)FBYTES) ? off : SPX_OOB, 0);
+            ar[i] = buf_load_b128_p<SPX_AUX_BLOB_LD>(ars, (want_w && off < (uint32_t)FBYTES) ? off : SPX_OOB, 0);
         }
         const int px = ci * SPX_BK_PX + piece * 8;
 #pragma unroll

@@ -337,13 +337,13 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) {
                     const int rb = (reg & 3) + 8 * (reg >> 2);
-                    dst[reg] = buf_load_f32(ddr, voff_d, (uint32_t)rb * HW * 4u);
+                    dst[reg] = buf_load_f32_p<SPX_AUX_DDIST_LD>(ddr, voff_d, (uint32_t)rb * HW * 4u);
                 }
             } else {
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) {
                     const int rb = (reg & 3) + 8 * (reg >> 2);
-                    dst[reg] = buf_load_f32(ddr, (pb * 32 + rb + 4 * h < np) ? voff_d : SPX_OOB, (uint32_t)rb * HW * 4u);
+                    dst[reg] = buf_load_f32_p<SPX_AUX_DDIST_LD>(ddr, (pb * 32 + rb + 4 * h < np) ? voff_d : SPX_OOB, (uint32_t)rb * HW * 4u);
                 }
             }
         };
@@ -459,8 +459,8 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
             for (int s2 = 0; s2 < 2; ++s2) {
                 const uint32_t so = (uint32_t)(((wave * NPB + pb) * 2 + s2) * 1024);
                 const uint32_t vo = spx_blob_slot(r, h, s2) * 16u;
-                if (a.g_out) buf_store_b128(__builtin_bit_cast(u32x4, gout[s2]), gr, vo, so);
-                if (a.a_out) buf_store_b128(__builtin_bit_cast(u32x4, anew[s2]), ar, vo, so);
+                if (a.g_out) buf_store_b128_p<SPX_AUX_BLOB_ST>(__builtin_bit_cast(u32x4, gout[s2]), gr, vo, so);
+                if (a.a_out) buf_store_b128_p<SPX_AUX_BLOB_ST>(__builtin_bit_cast(u32x4, anew[s2]), ar, vo, so);
             }
         };
         auto put_g = [&](f32x16& dst, const bf16x8 (&g)[2]) {
@@ -638,7 +638,7 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
                             w[e] = __builtin_bit_cast(uint32_t, p);
                         }
                     }
-                    buf_store_b128(w, dxr, ok ? fvo + 16u * v : SPX_OOB, 0);
+                    buf_store_b128_p<SPX_AUX_DX_ST>(w, dxr, ok ? fvo + 16u * v : SPX_OOB, 0);
                 }
             } else {
 #pragma unroll

@@ -63,6 +63,41 @@ __device__ __forceinline__ void buf_store_b64(u32x2 v, spx_rsrc r, uint32_t voff
     __builtin_amdgcn_raw_buffer_store_b64(v, r, voff, soff, 0);
 }
 
+// Cache policy (the builtins' aux operand; 2 = nt) of the streams that are touched once per launch: the distance map
+// written by the forward, dDist read and dX / blobs written by the pixel-side backward, the blobs read by the bank-side
+// backward.  Compile-time switches so that a policy can be A/B-timed on one box (tools/probes/ab_libs.sh).
+#ifndef SPX_AUX_MAP_ST
+#define SPX_AUX_MAP_ST 0
+#endif
+#ifndef SPX_AUX_DDIST_LD
+#define SPX_AUX_DDIST_LD 0
+#endif
+#ifndef SPX_AUX_BLOB_ST
+#define SPX_AUX_BLOB_ST 0
+#endif
+#ifndef SPX_AUX_DX_ST
+#define SPX_AUX_DX_ST 0
+#endif
+#ifndef SPX_AUX_BLOB_LD
+#define SPX_AUX_BLOB_LD 0
+#endif
+template <int AUX>
+__device__ __forceinline__ float buf_load_f32_p(spx_rsrc r, uint32_t voff, uint32_t soff) {
+    return __uint_as_float((uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, AUX));
+}
+template <int AUX>
+__device__ __forceinline__ void buf_store_f32_p(float v, spx_rsrc r, uint32_t voff, uint32_t soff) {
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, AUX);
+}
+template <int AUX>
+__device__ __forceinline__ u32x4 buf_load_b128_p(spx_rsrc r, uint32_t voff, uint32_t soff) {
+    return __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, AUX);
+}
+template <int AUX>
+__device__ __forceinline__ void buf_store_b128_p(u32x4 v, spx_rsrc r, uint32_t voff, uint32_t soff) {
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, voff + soff, 0, AUX);      // see buf_store_b128
+}
+
 // Row of a 32x32 MFMA accumulator held in register `reg` of lane half `h`
 // (cdna guide §3: row = (reg&3) + 8*(reg>>2) + 4*(lane>>5), col = lane&31).
 __device__ __forceinline__ int acc_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
