@@ -183,7 +183,8 @@ int spx_argmin_images(const float* values, int32_t N, int32_t P, int64_t* best, 
  *   spx_kld_segment_max    smax_keys uint32 [B, K, J] (caller zero-fills): ordered key of max_px vals over the segment
  *                          (key k -> float: k & 0x80000000 ? k ^ 0x80000000 : ~k); counts uint32 [B, K] (zero-filled,
  *                          may be NULL): pixels per segment (loss.py:113-127 skips segments of fewer than two)
- *   spx_kld_segment_sumexp ssum_fx uint64 [B, K, J] (zero-filled): sum_px exp(vals - smax) * 2^40
+ *   spx_kld_segment_sumexp ssum_fx uint64 [B, K, J] (zero-filled): sum_px exp(vals - smax) * 2^40, smax from the keys
+ *   spx_kld_segment_lse    lse fp32 [n = B*K*J]: smax + log(ssum_fx / 2^40), 0 for a segment without pixels
  *   spx_kld_pair_sums      a_fx int64 [B, K, J, J] (zero-filled): sum_px p_j * (l_k - l_j) * scale = -KL(j || k) of the
  *                          segment, i.e. the Gram matrix sum_px p_j l_k minus its row's diagonal entry (diagonal 0);
  *                          scale: ONE double in DEVICE memory, so the caller can derive it from the data without a
@@ -197,7 +198,8 @@ int spx_argmin_images(const float* values, int32_t N, int32_t P, int64_t* best, 
 int spx_kld_segment_max(const float* vals, const int32_t* labels, int32_t B, int32_t J, int32_t HW, int32_t K,
                         uint32_t* smax_keys, uint32_t* counts, void* stream);
 int spx_kld_segment_sumexp(const float* vals, const int32_t* labels, int32_t B, int32_t J, int32_t HW, int32_t K,
-                           const float* smax, uint64_t* ssum_fx, void* stream);
+                           const uint32_t* smax_keys, uint64_t* ssum_fx, void* stream);
+int spx_kld_segment_lse(const uint32_t* smax_keys, const uint64_t* ssum_fx, int32_t n, float* lse, void* stream);
 int spx_kld_pair_sums(const float* vals, const int32_t* labels, int32_t B, int32_t J, int32_t HW, int32_t W, int32_t K,
                       const float* lse, const double* scale, int64_t* a_fx, void* stream);
 int spx_kld_backward(const float* vals, const int32_t* labels, int32_t B, int32_t J, int32_t HW, int32_t K,

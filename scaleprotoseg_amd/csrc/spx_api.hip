@@ -368,9 +368,15 @@ int spx_kld_segment_max(const float* vals, const int32_t* labels, int32_t B, int
     return hip_status(spx_launch_kld(0, vals, labels, B, J, HW, 0, K, (const float*)counts, nullptr, nullptr, nullptr, smax_keys, (hipStream_t)stream), "spx_kld_segment_max");
 }
 int spx_kld_segment_sumexp(const float* vals, const int32_t* labels, int32_t B, int32_t J, int32_t HW, int32_t K,
-                           const float* smax, uint64_t* ssum_fx, void* stream) {
-    if (kld_check("spx_kld_segment_sumexp", vals, labels, B, J, HW, K, ssum_fx, 0) || !smax) return smax ? 1 : fail("spx_kld_segment_sumexp: NULL smax");
-    return hip_status(spx_launch_kld(1, vals, labels, B, J, HW, 0, K, smax, nullptr, nullptr, nullptr, ssum_fx, (hipStream_t)stream), "spx_kld_segment_sumexp");
+                           const uint32_t* smax_keys, uint64_t* ssum_fx, void* stream) {
+    if (kld_check("spx_kld_segment_sumexp", vals, labels, B, J, HW, K, ssum_fx, 0) || !smax_keys) return smax_keys ? 1 : fail("spx_kld_segment_sumexp: NULL smax_keys");
+    return hip_status(spx_launch_kld(1, vals, labels, B, J, HW, 0, K, (const float*)smax_keys, nullptr, nullptr, nullptr, ssum_fx, (hipStream_t)stream), "spx_kld_segment_sumexp");
+}
+int spx_kld_segment_lse(const uint32_t* smax_keys, const uint64_t* ssum_fx, int32_t n, float* lse, void* stream) {
+    if (!smax_keys || !ssum_fx || !lse) return fail("spx_kld_segment_lse: NULL pointer");
+    if (n < 0) return fail("spx_kld_segment_lse: n < 0");
+    if (n == 0) return 0;
+    return hip_status(spx_launch_kld_lse(smax_keys, ssum_fx, n, lse, (hipStream_t)stream), "spx_kld_segment_lse");
 }
 int spx_kld_pair_sums(const float* vals, const int32_t* labels, int32_t B, int32_t J, int32_t HW, int32_t W, int32_t K,
                       const float* lse, const double* scale, int64_t* a_fx, void* stream) {

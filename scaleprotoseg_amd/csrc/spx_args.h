@@ -89,5 +89,6 @@ hipError_t spx_launch_push_argmin(const float* dist, const int32_t* labels, cons
 hipError_t spx_launch_argmin_images(const float* values, int N, int P, int64_t* best, hipStream_t s);
 hipError_t spx_launch_upsample_argext(const float* src, int N, int C, int h, int w, int H, int W, int take_max,
                                       int64_t* idx, float* val, hipStream_t s);
+hipError_t spx_launch_kld_lse(const uint32_t* keys, const uint64_t* ssum_fx, int n, float* lse, hipStream_t s);
 hipError_t spx_launch_kld(int pass, const float* vals, const int32_t* labels, int B, int J, int HW, int W, int K, const float* t0,
                           const float* t1, const float* t2, const double* scale, void* out, hipStream_t s);

@@ -75,7 +75,7 @@ __global__ __launch_bounds__(SPX_KLD_THREADS) void spx_kld_max_kernel(const floa
 
 // pass 1: ssum_fx[b][c][j] = sum exp(d - smax) in 2^40 fixed point (every term is in (0, 1], the maximum contributes 1)
 __global__ __launch_bounds__(SPX_KLD_THREADS) void spx_kld_sumexp_kernel(const float* __restrict__ vals, const int32_t* __restrict__ labels,
-                                                                        int J, int HW, int K, const float* __restrict__ smax,
+                                                                        int J, int HW, int K, const unsigned int* __restrict__ smax_key,
                                                                         unsigned long long* __restrict__ ssum_fx) {
     extern __shared__ unsigned long long kld_smem[];
     unsigned long long* tab = kld_smem;                    // [K][J]
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(SPX_KLD_THREADS) void spx_kld_sumexp_kernel(const f
     __syncthreads();
     const float* v = vals + (size_t)b * J * HW;
     const int32_t* lab = labels + (size_t)b * HW;
-    const float* sm = smax + (size_t)b * K * J;
+    const unsigned int* sm = smax_key + (size_t)b * K * J;     // a pixel of the segment exists => its key is set
     const int px_end = min(HW, (int)(blockIdx.x + 1) * SPX_KLD_PX_PER_WG);
     const double FX = 1099511627776.0;                     // 2^40
     for (int px = blockIdx.x * SPX_KLD_PX_PER_WG + tid; px - tid < px_end; px += SPX_KLD_THREADS) {
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(SPX_KLD_THREADS) void spx_kld_sumexp_kernel(const f
         const int c0 = __shfl(c, 0);
         const bool uniform = __builtin_amdgcn_ballot_w64(c != c0) == 0;
         for (int j = 0; j < J; ++j) {
-            const double e = ok ? (double)__expf(v[(size_t)j * HW + px] - sm[c * J + j]) : 0.0;
+            const double e = ok ? (double)__expf(v[(size_t)j * HW + px] - key_float(sm[c * J + j])) : 0.0;
             if (uniform) {
                 const double s = wave_sum_f64(e);
                 if ((tid & 63) == 0 && ok) atomicAdd(&tab[c * J + j], (unsigned long long)(s * FX + 0.5));
@@ -276,6 +276,20 @@ __global__ __launch_bounds__(SPX_KLD_THREADS) void spx_kld_backward_kernel(const
     }
 }
 
+// lse[i] = smax + log(sum exp(v - smax)) of segment slot i from passes 0 and 1; 0 where the segment has no pixel
+__global__ void spx_kld_lse_kernel(const unsigned int* __restrict__ smax_key, const unsigned long long* __restrict__ ssum_fx, int n,
+                                   float* __restrict__ lse) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned int k = smax_key[i];
+    const double s = (double)ssum_fx[i] * (1.0 / 1099511627776.0);
+    lse[i] = (k != 0u && s > 0.0) ? (float)((double)key_float(k) + log(s)) : 0.0f;
+}
+hipError_t spx_launch_kld_lse(const uint32_t* keys, const uint64_t* ssum_fx, int n, float* lse, hipStream_t s) {
+    hipLaunchKernelGGL(spx_kld_lse_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, keys, (const unsigned long long*)ssum_fx, n, lse);
+    return hipGetLastError();
+}
+
 hipError_t spx_launch_kld(int pass, const float* vals, const int32_t* labels, int B, int J, int HW, int W, int K, const float* t0,
                           const float* t1, const float* t2, const double* scale, void* out, hipStream_t s) {
     dim3 grid((unsigned)((HW + SPX_KLD_PX_PER_WG - 1) / SPX_KLD_PX_PER_WG), (unsigned)B);
@@ -283,7 +297,7 @@ hipError_t spx_launch_kld(int pass, const float* vals, const int32_t* labels, in
     if (pass == 0)
         hipLaunchKernelGGL(spx_kld_max_kernel, grid, blk, (size_t)(K * J + K) * 4, s, vals, labels, J, HW, K, (unsigned int*)out, (unsigned int*)t0);
     else if (pass == 1)
-        hipLaunchKernelGGL(spx_kld_sumexp_kernel, grid, blk, (size_t)K * J * 8, s, vals, labels, J, HW, K, t0, (unsigned long long*)out);
+        hipLaunchKernelGGL(spx_kld_sumexp_kernel, grid, blk, (size_t)K * J * 8, s, vals, labels, J, HW, K, (const unsigned int*)t0, (unsigned long long*)out);
     else if (pass == 2) {
         const size_t lds = (size_t)K * J * J * 8;
         unsigned long long* o = (unsigned long long*)out;
