@@ -121,8 +121,12 @@ def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
 
 
 def stream_ptr() -> int:
-    """hipStream_t of torch's current stream."""
-    return torch.cuda.current_stream().cuda_stream
+    """hipStream_t of torch's current stream (the raw getter: ``torch.cuda.current_stream()`` builds a Stream object,
+    ~20 us per call, which is visible at the launch-bound training shapes)."""
+    raw = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+    if raw is None:
+        return torch.cuda.current_stream().cuda_stream
+    return raw(torch.cuda.current_device())
 
 
 def make_plan(P: int, K: int, S: int, Cs: int, scale_lo, scale_hi) -> SpxPlan:

@@ -2,10 +2,16 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import scaleprotoseg_amd as spx
-from oracle import ppnet_oracle as O
+def _identity(P, K, S):
+    ident = torch.zeros(P, K)
+    per_scale, per_cs = P // S, P // K // S
+    for s in range(S):
+        for k in range(K):
+            ident[s * per_scale + k * per_cs : s * per_scale + (k + 1) * per_cs, k] = 1
+    return ident
 dev = torch.device("cuda:0")
 P, K, S, H, W = 190, 19, 1, 1024, 2048
-ident = O.default_class_identity(P, K, S)
+ident = _identity(P, K, S)
 lay = spx.BankLayout(P, K, S, 256, ((0, P),))
 keys, J, table = spx.class_gather_table(lay, ident, dev)
 patches = torch.randint(0, K + 1, (1, H // 64, W // 64), device=dev)
