@@ -189,15 +189,16 @@ int spx_argmin_images(const float* values, int32_t N, int32_t P, int64_t* best, 
  *                          segment, i.e. the Gram matrix sum_px p_j l_k minus its row's diagonal entry (diagonal 0);
  *                          scale: ONE double in DEVICE memory, so the caller can derive it from the data without a
  *                          host sync; l = vals - lse (the log_softmax over the segment's pixels, loss.py:110), p = exp(l).
- *                          W: row length of the pixel grid (must divide HW) lets the kernel walk column strips, which
- *                          cross fewer class boundaries; 0 = unknown (linear walk).  W changes only the rounding of fp32 partial sums.
  *   spx_kld_backward       grad fp32 [B, J, HW] = dLoss/dvals given A = a_fx / scale and Cf = dLoss/dA [B, K, J, J]
  *                          (diagonal entries of Cf are not read: A's diagonal is identically 0)
+ * W (the three reduction passes): row length of the pixel grid (must divide HW) lets a wave walk down a 64-pixel column
+ * strip, which crosses fewer class boundaries than a row (partial results are published per class run); 0 = unknown
+ * (linear walk).  W changes only the rounding of fp32 partial sums.
  * The [B, K, J, J]-sized algebra between the passes (loss.py:113-142: symmetric KL of the slot pairs of one scale,
  * exp(-kld), mean) is left to the caller.  J <= 16 and K*J*J*8 bytes must fit the LDS table (~60 KiB). */
-int spx_kld_segment_max(const float* vals, const int32_t* labels, int32_t B, int32_t J, int32_t HW, int32_t K,
+int spx_kld_segment_max(const float* vals, const int32_t* labels, int32_t B, int32_t J, int32_t HW, int32_t W, int32_t K,
                         uint32_t* smax_keys, uint32_t* counts, void* stream);
-int spx_kld_segment_sumexp(const float* vals, const int32_t* labels, int32_t B, int32_t J, int32_t HW, int32_t K,
+int spx_kld_segment_sumexp(const float* vals, const int32_t* labels, int32_t B, int32_t J, int32_t HW, int32_t W, int32_t K,
                            const uint32_t* smax_keys, uint64_t* ssum_fx, void* stream);
 int spx_kld_segment_lse(const uint32_t* smax_keys, const uint64_t* ssum_fx, int32_t n, float* lse, void* stream);
 int spx_kld_pair_sums(const float* vals, const int32_t* labels, int32_t B, int32_t J, int32_t HW, int32_t W, int32_t K,

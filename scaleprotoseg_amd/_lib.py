@@ -69,8 +69,8 @@ SIGNATURES = {
     "spx_bank_bwd": (C.c_int, [_PP, _V, _I, _I, _I, _V, _V, _V, _V, _V, _V, _V, _V]),
     "spx_push_argmin": (C.c_int, [_V, _V, _V, _I, _I, _I, _I, _I, _F, _V, _V, _V, _V]),
     "spx_argmin_images": (C.c_int, [_V, _I, _I, _V, _V]),
-    "spx_kld_segment_max": (C.c_int, [_V, _V, _I, _I, _I, _I, _V, _V, _V]),
-    "spx_kld_segment_sumexp": (C.c_int, [_V, _V, _I, _I, _I, _I, _V, _V, _V]),
+    "spx_kld_segment_max": (C.c_int, [_V, _V, _I, _I, _I, _I, _I, _V, _V, _V]),
+    "spx_kld_segment_sumexp": (C.c_int, [_V, _V, _I, _I, _I, _I, _I, _V, _V, _V]),
     "spx_kld_segment_lse": (C.c_int, [_V, _V, _I, _V, _V]),
     "spx_kld_pair_sums": (C.c_int, [_V, _V, _I, _I, _I, _I, _I, _V, _V, _V, _V]),
     "spx_kld_backward": (C.c_int, [_V, _V, _I, _I, _I, _I, _V, _V, _V, _V, _V]),

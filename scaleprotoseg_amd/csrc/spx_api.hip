@@ -362,15 +362,20 @@ static int kld_check(const char* who, const float* vals, const int32_t* labels, 
     return 0;
 }
 
-int spx_kld_segment_max(const float* vals, const int32_t* labels, int32_t B, int32_t J, int32_t HW, int32_t K,
-                        uint32_t* smax_keys, uint32_t* counts, void* stream) {
-    if (kld_check("spx_kld_segment_max", vals, labels, B, J, HW, K, smax_keys, 0)) return 1;
-    return hip_status(spx_launch_kld(0, vals, labels, B, J, HW, 0, K, (const float*)counts, nullptr, nullptr, nullptr, smax_keys, (hipStream_t)stream), "spx_kld_segment_max");
+static int kld_check_w(const char* fn, int32_t HW, int32_t W) {
+    if (W < 0 || (W > 0 && HW % W != 0)) return fail("%s: W must be 0 or divide HW", fn);
+    return 0;
 }
-int spx_kld_segment_sumexp(const float* vals, const int32_t* labels, int32_t B, int32_t J, int32_t HW, int32_t K,
+int spx_kld_segment_max(const float* vals, const int32_t* labels, int32_t B, int32_t J, int32_t HW, int32_t W, int32_t K,
+                        uint32_t* smax_keys, uint32_t* counts, void* stream) {
+    if (kld_check("spx_kld_segment_max", vals, labels, B, J, HW, K, smax_keys, 0) || kld_check_w("spx_kld_segment_max", HW, W)) return 1;
+    return hip_status(spx_launch_kld(0, vals, labels, B, J, HW, W, K, (const float*)counts, nullptr, nullptr, nullptr, smax_keys, (hipStream_t)stream), "spx_kld_segment_max");
+}
+int spx_kld_segment_sumexp(const float* vals, const int32_t* labels, int32_t B, int32_t J, int32_t HW, int32_t W, int32_t K,
                            const uint32_t* smax_keys, uint64_t* ssum_fx, void* stream) {
     if (kld_check("spx_kld_segment_sumexp", vals, labels, B, J, HW, K, ssum_fx, 0) || !smax_keys) return smax_keys ? 1 : fail("spx_kld_segment_sumexp: NULL smax_keys");
-    return hip_status(spx_launch_kld(1, vals, labels, B, J, HW, 0, K, (const float*)smax_keys, nullptr, nullptr, nullptr, ssum_fx, (hipStream_t)stream), "spx_kld_segment_sumexp");
+    if (kld_check_w("spx_kld_segment_sumexp", HW, W)) return 1;
+    return hip_status(spx_launch_kld(1, vals, labels, B, J, HW, W, K, (const float*)smax_keys, nullptr, nullptr, nullptr, ssum_fx, (hipStream_t)stream), "spx_kld_segment_sumexp");
 }
 int spx_kld_segment_lse(const uint32_t* smax_keys, const uint64_t* ssum_fx, int32_t n, float* lse, void* stream) {
     if (!smax_keys || !ssum_fx || !lse) return fail("spx_kld_segment_lse: NULL pointer");
@@ -381,7 +386,7 @@ int spx_kld_segment_lse(const uint32_t* smax_keys, const uint64_t* ssum_fx, int3
 int spx_kld_pair_sums(const float* vals, const int32_t* labels, int32_t B, int32_t J, int32_t HW, int32_t W, int32_t K,
                       const float* lse, const double* scale, int64_t* a_fx, void* stream) {
     if (kld_check("spx_kld_pair_sums", vals, labels, B, J, HW, K, a_fx, 1) || !lse || !scale) return (lse && scale) ? 1 : fail("spx_kld_pair_sums: NULL lse / scale");
-    if (W < 0 || (W > 0 && HW % W != 0)) return fail("spx_kld_pair_sums: W must be 0 or divide HW");
+    if (kld_check_w("spx_kld_pair_sums", HW, W)) return 1;
     return hip_status(spx_launch_kld(2, vals, labels, B, J, HW, W, K, lse, nullptr, nullptr, scale, a_fx, (hipStream_t)stream), "spx_kld_pair_sums");
 }
 int spx_kld_backward(const float* vals, const int32_t* labels, int32_t B, int32_t J, int32_t HW, int32_t K,

@@ -30,41 +30,93 @@ __device__ __forceinline__ float wave_max_f32(float v) {
     return v;
 }
 
+// The pixels a wave visits in the reduction passes.  W > 0: the pixels are rows of W and a wave walks DOWN a 64-pixel-wide
+// column strip (label maps are coherent in both directions; a strip crosses far fewer class boundaries than the same
+// pixels taken along one row).  W == 0: a linear walk.  This lane's pixel of step s is first + s*stride (s < nsteps,
+// real for s < nvalid).  The passes keep per-thread partial results while all 64 pixels of a step share one class and
+// reduce + publish them (wave butterfly, one LDS integer atomic per entry) only when the class changes or the walk ends;
+// steps whose pixels are not all of one class take the per-lane atomic path.
+struct SpxKldWalk {
+    int first, stride, nsteps, nvalid;
+};
+__device__ __forceinline__ SpxKldWalk spx_kld_walk(int HW, int W, int lane, int wave) {
+    SpxKldWalk w;
+    if (W > 0) {
+        const int tiles_x = (W + SPX_KLD_THREADS - 1) / SPX_KLD_THREADS, H = HW / W;
+        const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+        const int col = tx * SPX_KLD_THREADS + wave * 64 + lane, row0 = ty * SPX_KLD_STRIP_ROWS;
+        w.nsteps = min(SPX_KLD_STRIP_ROWS, H - row0);
+        if (tx * SPX_KLD_THREADS + wave * 64 >= W) w.nsteps = 0;          // wave-uniform
+        w.first = row0 * W + col;
+        w.stride = W;
+        w.nvalid = col < W ? w.nsteps : 0;
+    } else {
+        constexpr int PX_PER_WAVE = SPX_KLD_PX_PER_WG / (SPX_KLD_THREADS / 64);
+        const int px0 = blockIdx.x * SPX_KLD_PX_PER_WG + wave * PX_PER_WAVE;
+        w.nsteps = px0 < HW ? min(PX_PER_WAVE / 64, (HW - px0 + 63) / 64) : 0;
+        w.first = px0 + lane;
+        w.stride = 64;
+        w.nvalid = w.first < HW ? (HW - w.first + 63) / 64 : 0;
+    }
+    return w;
+}
+
 // pass 0: smax_key[b][c][j] = max over the segment's pixels of vals (ordered-uint key of the float)
 __global__ __launch_bounds__(SPX_KLD_THREADS) void spx_kld_max_kernel(const float* __restrict__ vals, const int32_t* __restrict__ labels,
-                                                                     int J, int HW, int K, unsigned int* __restrict__ smax_key,
+                                                                     int J, int HW, int W, int K, unsigned int* __restrict__ smax_key,
                                                                      unsigned int* __restrict__ counts) {
     extern __shared__ unsigned long long kld_smem[];
     unsigned int* tab = (unsigned int*)kld_smem;          // [K][J]
     unsigned int* cnt = tab + K * J;                      // [K] pixels of the class in this workgroup's range
-    const int b = blockIdx.y, tid = threadIdx.x;
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < K * J + K; i += SPX_KLD_THREADS) tab[i] = 0u;
     __syncthreads();
     const float* v = vals + (size_t)b * J * HW;
     const int32_t* lab = labels + (size_t)b * HW;
-    const int px_end = min(HW, (int)(blockIdx.x + 1) * SPX_KLD_PX_PER_WG);
-    for (int px = blockIdx.x * SPX_KLD_PX_PER_WG + tid; px - tid < px_end; px += SPX_KLD_THREADS) {
-        const int c = px < px_end ? lab[px] : -1;
+    const SpxKldWalk w = spx_kld_walk(HW, W, lane, wave);
+    float m[SPX_KLD_MAXJ];
+#pragma unroll
+    for (int j = 0; j < SPX_KLD_MAXJ; ++j) m[j] = -3.0e38f;
+    int cur = -1;                                          // class of the running maxima (wave-uniform)
+    unsigned int run = 0;                                  // its pixels so far
+    auto publish = [&]() {
+        if (cur < 0) return;
+#pragma unroll
+        for (int j = 0; j < SPX_KLD_MAXJ; ++j)
+            if (j < J) {
+                const float wm = wave_max_f32(m[j]);
+                if (lane == 0) atomicMax(&tab[cur * J + j], float_key(wm));
+                m[j] = -3.0e38f;
+            }
+        if (lane == 0) atomicAdd(&cnt[cur], run);
+        run = 0;
+    };
+    for (int step = 0; step < w.nsteps; ++step) {
+        const int px = w.first + step * w.stride;
+        const int c = step < w.nvalid ? lab[px] : -1;
         const bool ok = c >= 0 && c < K;
-        const int c0 = __shfl(c, 0);
+        const int c0 = __builtin_amdgcn_readfirstlane(c);
         const bool uniform = __builtin_amdgcn_ballot_w64(c != c0) == 0;
-        if (counts) {
-            if (uniform) {
-                if ((tid & 63) == 0 && ok) atomicAdd(&cnt[c], 64u);
-            } else if (ok) {
-                atomicAdd(&cnt[c], 1u);
+        float d[SPX_KLD_MAXJ];
+#pragma unroll
+        for (int j = 0; j < SPX_KLD_MAXJ; ++j) d[j] = (ok && j < J) ? v[(size_t)j * HW + px] : -3.0e38f;
+        if (uniform) {
+            if (!ok) continue;                             // a step of void pixels
+            if (c0 != cur) {
+                publish();
+                cur = c0;
             }
-        }
-        for (int j = 0; j < J; ++j) {
-            const float d = ok ? v[(size_t)j * HW + px] : -3.0e38f;
-            if (uniform) {
-                const float m = wave_max_f32(d);
-                if ((tid & 63) == 0 && ok) atomicMax(&tab[c * J + j], float_key(m));
-            } else if (ok) {
-                atomicMax(&tab[c * J + j], float_key(d));
-            }
+            run += 64u;
+#pragma unroll
+            for (int j = 0; j < SPX_KLD_MAXJ; ++j) m[j] = fmaxf(m[j], d[j]);
+        } else if (ok) {
+            atomicAdd(&cnt[c], 1u);
+#pragma unroll
+            for (int j = 0; j < SPX_KLD_MAXJ; ++j)
+                if (j < J) atomicMax(&tab[c * J + j], float_key(d[j]));
         }
     }
+    publish();
     __syncthreads();
     for (int i = tid; i < K * J; i += SPX_KLD_THREADS)
         if (tab[i]) atomicMax(&smax_key[(size_t)b * K * J + i], tab[i]);
@@ -75,33 +127,56 @@ __global__ __launch_bounds__(SPX_KLD_THREADS) void spx_kld_max_kernel(const floa
 
 // pass 1: ssum_fx[b][c][j] = sum exp(d - smax) in 2^40 fixed point (every term is in (0, 1], the maximum contributes 1)
 __global__ __launch_bounds__(SPX_KLD_THREADS) void spx_kld_sumexp_kernel(const float* __restrict__ vals, const int32_t* __restrict__ labels,
-                                                                        int J, int HW, int K, const unsigned int* __restrict__ smax_key,
+                                                                        int J, int HW, int W, int K, const unsigned int* __restrict__ smax_key,
                                                                         unsigned long long* __restrict__ ssum_fx) {
     extern __shared__ unsigned long long kld_smem[];
     unsigned long long* tab = kld_smem;                    // [K][J]
-    const int b = blockIdx.y, tid = threadIdx.x;
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < K * J; i += SPX_KLD_THREADS) tab[i] = 0ull;
     __syncthreads();
     const float* v = vals + (size_t)b * J * HW;
     const int32_t* lab = labels + (size_t)b * HW;
     const unsigned int* sm = smax_key + (size_t)b * K * J;     // a pixel of the segment exists => its key is set
-    const int px_end = min(HW, (int)(blockIdx.x + 1) * SPX_KLD_PX_PER_WG);
     const double FX = 1099511627776.0;                     // 2^40
-    for (int px = blockIdx.x * SPX_KLD_PX_PER_WG + tid; px - tid < px_end; px += SPX_KLD_THREADS) {
-        const int c = px < px_end ? lab[px] : -1;
-        const bool ok = c >= 0 && c < K;
-        const int c0 = __shfl(c, 0);
-        const bool uniform = __builtin_amdgcn_ballot_w64(c != c0) == 0;
-        for (int j = 0; j < J; ++j) {
-            const double e = ok ? (double)__expf(v[(size_t)j * HW + px] - key_float(sm[c * J + j])) : 0.0;
-            if (uniform) {
-                const double s = wave_sum_f64(e);
-                if ((tid & 63) == 0 && ok) atomicAdd(&tab[c * J + j], (unsigned long long)(s * FX + 0.5));
-            } else if (ok) {
-                atomicAdd(&tab[c * J + j], (unsigned long long)(e * FX + 0.5));
+    const SpxKldWalk w = spx_kld_walk(HW, W, lane, wave);
+    float acc[SPX_KLD_MAXJ];                               // <= SPX_KLD_STRIP_ROWS terms of (0, 1] each: fp32 is ample
+#pragma unroll
+    for (int j = 0; j < SPX_KLD_MAXJ; ++j) acc[j] = 0.0f;
+    int cur = -1;
+    auto publish = [&]() {
+        if (cur < 0) return;
+#pragma unroll
+        for (int j = 0; j < SPX_KLD_MAXJ; ++j)
+            if (j < J) {
+                const double s = wave_sum_f64((double)acc[j]);
+                if (lane == 0) atomicAdd(&tab[cur * J + j], (unsigned long long)(s * FX + 0.5));
+                acc[j] = 0.0f;
             }
+    };
+    for (int step = 0; step < w.nsteps; ++step) {
+        const int px = w.first + step * w.stride;
+        const int c = step < w.nvalid ? lab[px] : -1;
+        const bool ok = c >= 0 && c < K;
+        const int c0 = __builtin_amdgcn_readfirstlane(c);
+        const bool uniform = __builtin_amdgcn_ballot_w64(c != c0) == 0;
+        float e[SPX_KLD_MAXJ];
+#pragma unroll
+        for (int j = 0; j < SPX_KLD_MAXJ; ++j) e[j] = (ok && j < J) ? __expf(v[(size_t)j * HW + px] - key_float(sm[c * J + j])) : 0.0f;
+        if (uniform) {
+            if (!ok) continue;
+            if (c0 != cur) {
+                publish();
+                cur = c0;
+            }
+#pragma unroll
+            for (int j = 0; j < SPX_KLD_MAXJ; ++j) acc[j] += e[j];
+        } else if (ok) {
+#pragma unroll
+            for (int j = 0; j < SPX_KLD_MAXJ; ++j)
+                if (j < J) atomicAdd(&tab[c * J + j], (unsigned long long)((double)e[j] * FX + 0.5));
         }
     }
+    publish();
     __syncthreads();
     for (int i = tid; i < K * J; i += SPX_KLD_THREADS)
         if (tab[i]) atomicAdd(&ssum_fx[(size_t)b * K * J + i], tab[i]);
@@ -111,9 +186,7 @@ __global__ __launch_bounds__(SPX_KLD_THREADS) void spx_kld_sumexp_kernel(const f
 // count): the Gram matrix MINUS its row's diagonal entry, i.e. -KL(j || k) of the segment.  The loss and the gradient
 // only ever use A[j][k] - A[j][j] (rows of dLoss/dA sum to zero), and in this form the sums are small numbers built
 // from small terms instead of differences of large ones, so a thread can carry them in fp32 registers across its
-// pixels: a wave walks 64-pixel steps of ONE contiguous range and reduces + publishes (wave butterfly in fp64, one
-// LDS integer atomic per entry) only when the class changes or its range ends.  Steps whose 64 pixels are not all of
-// one class take the per-lane atomic path.
+// pixels (see SpxKldWalk).
 template <int JT>
 __global__ __launch_bounds__(SPX_KLD_THREADS) void spx_kld_pairs_kernel(const float* __restrict__ vals, const int32_t* __restrict__ labels,
                                                                        int J, int HW, int W, int K, const float* __restrict__ lse,
@@ -127,26 +200,7 @@ __global__ __launch_bounds__(SPX_KLD_THREADS) void spx_kld_pairs_kernel(const fl
     const float* v = vals + (size_t)b * J * HW;
     const int32_t* lab = labels + (size_t)b * HW;
     const float* ls = lse + (size_t)b * K * J;
-    // W > 0: the pixels are rows of W and a wave walks DOWN a 64-pixel-wide column strip (label maps are coherent in both
-    // directions; a strip crosses far fewer class boundaries than the same pixels taken along one row).  W == 0: linear.
-    int first, stride, nsteps, nvalid;                     // this lane's pixel of step s is first + s*stride, s < nsteps
-    if (W > 0) {
-        const int tiles_x = (W + SPX_KLD_THREADS - 1) / SPX_KLD_THREADS, H = HW / W;
-        const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
-        const int col = tx * SPX_KLD_THREADS + wave * 64 + lane, row0 = ty * SPX_KLD_STRIP_ROWS;
-        nsteps = min(SPX_KLD_STRIP_ROWS, H - row0);
-        if (tx * SPX_KLD_THREADS + wave * 64 >= W) nsteps = 0;          // wave-uniform
-        first = row0 * W + col;
-        stride = W;
-        nvalid = col < W ? nsteps : 0;
-    } else {
-        constexpr int PX_PER_WAVE = SPX_KLD_PX_PER_WG / (SPX_KLD_THREADS / 64);
-        const int px0 = blockIdx.x * SPX_KLD_PX_PER_WG + wave * PX_PER_WAVE;
-        nsteps = px0 < HW ? min(PX_PER_WAVE / 64, (HW - px0 + 63) / 64) : 0;
-        first = px0 + lane;
-        stride = 64;
-        nvalid = first < HW ? (HW - first + 63) / 64 : 0;
-    }
+    const SpxKldWalk w = spx_kld_walk(HW, W, lane, wave);
     float acc[JT][JT];
 #pragma unroll
     for (int j = 0; j < JT; ++j)
@@ -165,9 +219,9 @@ __global__ __launch_bounds__(SPX_KLD_THREADS) void spx_kld_pairs_kernel(const fl
                     acc[j][k] = 0.0f;
                 }
     };
-    for (int step = 0; step < nsteps; ++step) {
-        const int px = first + step * stride;
-        const int c = step < nvalid ? lab[px] : -1;
+    for (int step = 0; step < w.nsteps; ++step) {
+        const int px = w.first + step * w.stride;
+        const int c = step < w.nvalid ? lab[px] : -1;
         const bool ok = c >= 0 && c < K;
         const int c0 = __builtin_amdgcn_readfirstlane(c);
         const bool uniform = __builtin_amdgcn_ballot_w64(c != c0) == 0;
@@ -294,14 +348,14 @@ hipError_t spx_launch_kld(int pass, const float* vals, const int32_t* labels, in
                           const float* t1, const float* t2, const double* scale, void* out, hipStream_t s) {
     dim3 grid((unsigned)((HW + SPX_KLD_PX_PER_WG - 1) / SPX_KLD_PX_PER_WG), (unsigned)B);
     dim3 blk(SPX_KLD_THREADS);
+    if (W > 0 && pass != 3) grid.x = (unsigned)(((W + SPX_KLD_THREADS - 1) / SPX_KLD_THREADS) * ((HW / W + SPX_KLD_STRIP_ROWS - 1) / SPX_KLD_STRIP_ROWS));
     if (pass == 0)
-        hipLaunchKernelGGL(spx_kld_max_kernel, grid, blk, (size_t)(K * J + K) * 4, s, vals, labels, J, HW, K, (unsigned int*)out, (unsigned int*)t0);
+        hipLaunchKernelGGL(spx_kld_max_kernel, grid, blk, (size_t)(K * J + K) * 4, s, vals, labels, J, HW, W, K, (unsigned int*)out, (unsigned int*)t0);
     else if (pass == 1)
-        hipLaunchKernelGGL(spx_kld_sumexp_kernel, grid, blk, (size_t)K * J * 8, s, vals, labels, J, HW, K, (const unsigned int*)t0, (unsigned long long*)out);
+        hipLaunchKernelGGL(spx_kld_sumexp_kernel, grid, blk, (size_t)K * J * 8, s, vals, labels, J, HW, W, K, (const unsigned int*)t0, (unsigned long long*)out);
     else if (pass == 2) {
         const size_t lds = (size_t)K * J * J * 8;
         unsigned long long* o = (unsigned long long*)out;
-        if (W > 0) grid.x = (unsigned)(((W + SPX_KLD_THREADS - 1) / SPX_KLD_THREADS) * ((HW / W + SPX_KLD_STRIP_ROWS - 1) / SPX_KLD_STRIP_ROWS));
         if (J <= 4) hipLaunchKernelGGL(spx_kld_pairs_kernel<4>, grid, blk, lds, s, vals, labels, J, HW, W, K, t0, scale, o);
         else if (J <= 8) hipLaunchKernelGGL(spx_kld_pairs_kernel<8>, grid, blk, lds, s, vals, labels, J, HW, W, K, t0, scale, o);
         else if (J <= 12) hipLaunchKernelGGL(spx_kld_pairs_kernel<12>, grid, blk, lds, s, vals, labels, J, HW, W, K, t0, scale, o);

@@ -123,14 +123,15 @@ class _KLDSegmentGram(torch.autograd.Function):
         lab = labels.to(device=v.device, dtype=torch.int32).contiguous()
         dev = v.device
         s = _lib.stream_ptr()
+        Wk = int(W) if W and HW % int(W) == 0 else 0          # traversal hint of the reduction passes
         # one zero-filled workspace for the integer tables of the passes: [a_fx | ssum_fx | keys | counts]
         n_a, n_s = B * K * J * J, B * K * J
         ws = torch.zeros(n_a + n_s + (n_s + B * K + 1) // 2, dtype=torch.int64, device=dev)
         a_fx, ssum_fx = ws[:n_a].view(B, K, J, J), ws[n_a:n_a + n_s]
         tail32 = ws[n_a + n_s:].view(torch.int32)
         keys, counts = tail32[:n_s], tail32[n_s:n_s + B * K].view(B, K)
-        _lib.check(lib.spx_kld_segment_max(_lib.ptr(v), _lib.ptr(lab), B, J, HW, K, _lib.ptr(keys), _lib.ptr(counts), s))
-        _lib.check(lib.spx_kld_segment_sumexp(_lib.ptr(v), _lib.ptr(lab), B, J, HW, K, _lib.ptr(keys), _lib.ptr(ssum_fx), s))
+        _lib.check(lib.spx_kld_segment_max(_lib.ptr(v), _lib.ptr(lab), B, J, HW, Wk, K, _lib.ptr(keys), _lib.ptr(counts), s))
+        _lib.check(lib.spx_kld_segment_sumexp(_lib.ptr(v), _lib.ptr(lab), B, J, HW, Wk, K, _lib.ptr(keys), _lib.ptr(ssum_fx), s))
         lse = torch.empty((B, K, J), dtype=torch.float32, device=dev)
         _lib.check(lib.spx_kld_segment_lse(_lib.ptr(keys), _lib.ptr(ssum_fx), n_s, _lib.ptr(lse), s))
         # fixed-point scale of the Gram sums (a power of two, computed on the device: no host sync): |p * l| is bounded
@@ -138,7 +139,7 @@ class _KLDSegmentGram(torch.autograd.Function):
         vmin, vmax = torch.aminmax(v)
         span = (vmax - vmin).double() + 32.0
         scale = torch.exp2(torch.floor(torch.log2((2.0 ** 61) / (HW * span)))).reshape(1).contiguous()
-        _lib.check(lib.spx_kld_pair_sums(_lib.ptr(v), _lib.ptr(lab), B, J, HW, int(W) if W and HW % int(W) == 0 else 0, K, _lib.ptr(lse), _lib.ptr(scale), _lib.ptr(a_fx), s))
+        _lib.check(lib.spx_kld_pair_sums(_lib.ptr(v), _lib.ptr(lab), B, J, HW, Wk, K, _lib.ptr(lse), _lib.ptr(scale), _lib.ptr(a_fx), s))
         A = (a_fx.to(torch.float64) / scale).float()
         ctx.save_for_backward(v, lab, lse, A)
         ctx.K = K
