@@ -258,16 +258,32 @@ class KLDLoss(nn.Module):
 
     def _loss_from_gram(self, A: torch.Tensor, count: torch.Tensor, table: torch.Tensor, K: int, nseg: int) -> torch.Tensor:
         """Symmetric KL of the slot pairs from the segment Gram matrices, exp(-kld), mean (loss.py:113-142)."""
-        dev = A.device
+        pair_ok = self._pair_mask(table).to(A.device)                               # [K, J, J]
+        J = pair_ok.shape[-1]
+        valid = (pair_ok.unsqueeze(0) & (count.reshape(-1, K, 1, 1) >= 2)).reshape(nseg, J, J)   # loss.py:113-127 (len < 2 skipped)
+        return _GramLoss.apply(A, valid)
+
+
+class _GramLoss(torch.autograd.Function):
+    """mean over the valid (segment, j < k) entries of exp(-kld), kld = (A_jj + A_kk - A_jk - A_kj) / 2, 0.0 when there is
+    none (loss.py:129-144) - without a dynamic shape, and with the closed-form gradient (autograd through the dozen
+    tiny ops costs more GPU time than the segment kernels at 2 Mpx)."""
+
+    @staticmethod
+    def forward(ctx, A, valid):
         diag = torch.diagonal(A, dim1=1, dim2=2)
         kld = 0.5 * (diag.unsqueeze(2) + diag.unsqueeze(1) - A - A.transpose(1, 2))
-        pair_ok = self._pair_mask(table).to(dev)                                    # [K, J, J]
-        seg_cls = torch.arange(nseg, device=dev) % K
-        valid = pair_ok[seg_cls] & (count >= 2).reshape(-1, 1, 1)                   # loss.py:113-127 (len < 2 skipped)
-        # mean of exp(-kld) over the valid terms, 0.0 when there is none (loss.py:138-144) - without a dynamic shape
         n = valid.sum()
-        total = torch.where(valid, torch.exp(-kld), torch.zeros_like(kld)).sum()
-        return torch.where(n > 0, total / n.clamp_min(1).to(total.dtype), torch.zeros_like(total))
+        e = torch.where(valid, torch.exp(-kld), torch.zeros_like(kld))
+        inv = 1.0 / n.clamp_min(1).to(e.dtype)
+        ctx.save_for_backward(e * inv)
+        return e.sum() * inv                                   # n == 0: every term is masked, the sum is 0.0
+
+    @staticmethod
+    def backward(ctx, g):
+        (e,) = ctx.saved_tensors                               # E_jk = valid * exp(-kld_jk) / n;  dLoss/dkld_jk = -E_jk
+        es = e + e.transpose(1, 2)
+        return g * 0.5 * (es - torch.diag_embed(es.sum(dim=2))), None
 
 
 class KLDLossGroup(KLDLoss):
