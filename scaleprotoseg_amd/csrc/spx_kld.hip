@@ -36,6 +36,16 @@ __device__ __forceinline__ float wave_max_f32(float v) {
 // real for s < nvalid).  The passes keep per-thread partial results while all 64 pixels of a step share one class and
 // reduce + publish them (wave butterfly, one LDS integer atomic per entry) only when the class changes or the walk ends;
 // steps whose pixels are not all of one class take the per-lane atomic path.
+// The J plane values of one pixel, loaded UNCONDITIONALLY (a padded slot re-reads slot J-1, a lane without a pixel reads
+// pixel `px_safe`): a load under a per-lane condition becomes its own basic block with a full s_waitcnt in front of
+// its use, i.e. one exposed memory round trip per slot instead of one per pixel step (measured: 10 round trips per
+// step made the pair-sum pass 170 us for 84 MB).
+template <int JT>
+__device__ __forceinline__ void spx_kld_load_planes(float (&raw)[JT], const float* __restrict__ v, int J, int HW, int px_safe) {
+#pragma unroll
+    for (int j = 0; j < JT; ++j) raw[j] = v[(size_t)min(j, J - 1) * HW + px_safe];
+}
+
 struct SpxKldWalk {
     int first, stride, nsteps, nvalid;
 };
@@ -98,8 +108,9 @@ __global__ __launch_bounds__(SPX_KLD_THREADS) void spx_kld_max_kernel(const floa
         const int c0 = __builtin_amdgcn_readfirstlane(c);
         const bool uniform = __builtin_amdgcn_ballot_w64(c != c0) == 0;
         float d[SPX_KLD_MAXJ];
+        spx_kld_load_planes(d, v, J, HW, step < w.nvalid ? px : 0);
 #pragma unroll
-        for (int j = 0; j < SPX_KLD_MAXJ; ++j) d[j] = (ok && j < J) ? v[(size_t)j * HW + px] : -3.0e38f;
+        for (int j = 0; j < SPX_KLD_MAXJ; ++j) d[j] = (ok && j < J) ? d[j] : -3.0e38f;
         if (uniform) {
             if (!ok) continue;                             // a step of void pixels
             if (c0 != cur) {
@@ -131,12 +142,15 @@ __global__ __launch_bounds__(SPX_KLD_THREADS) void spx_kld_sumexp_kernel(const f
                                                                         unsigned long long* __restrict__ ssum_fx) {
     extern __shared__ unsigned long long kld_smem[];
     unsigned long long* tab = kld_smem;                    // [K][J]
+    float* sm = (float*)(tab + K * J);                     // [K][J] segment maxima (a pixel of the segment exists => its key is set)
     const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < K * J; i += SPX_KLD_THREADS) tab[i] = 0ull;
+    for (int i = tid; i < K * J; i += SPX_KLD_THREADS) {
+        tab[i] = 0ull;
+        sm[i] = key_float(smax_key[(size_t)b * K * J + i]);
+    }
     __syncthreads();
     const float* v = vals + (size_t)b * J * HW;
     const int32_t* lab = labels + (size_t)b * HW;
-    const unsigned int* sm = smax_key + (size_t)b * K * J;     // a pixel of the segment exists => its key is set
     const double FX = 1099511627776.0;                     // 2^40
     const SpxKldWalk w = spx_kld_walk(HW, W, lane, wave);
     float acc[SPX_KLD_MAXJ];                               // <= SPX_KLD_STRIP_ROWS terms of (0, 1] each: fp32 is ample
@@ -160,8 +174,10 @@ __global__ __launch_bounds__(SPX_KLD_THREADS) void spx_kld_sumexp_kernel(const f
         const int c0 = __builtin_amdgcn_readfirstlane(c);
         const bool uniform = __builtin_amdgcn_ballot_w64(c != c0) == 0;
         float e[SPX_KLD_MAXJ];
+        spx_kld_load_planes(e, v, J, HW, step < w.nvalid ? px : 0);
+        const float* smc = sm + (ok ? c : 0) * J;
 #pragma unroll
-        for (int j = 0; j < SPX_KLD_MAXJ; ++j) e[j] = (ok && j < J) ? __expf(v[(size_t)j * HW + px] - key_float(sm[c * J + j])) : 0.0f;
+        for (int j = 0; j < SPX_KLD_MAXJ; ++j) e[j] = (ok && j < J) ? __expf(e[j] - smc[min(j, J - 1)]) : 0.0f;
         if (uniform) {
             if (!ok) continue;
             if (c0 != cur) {
@@ -193,13 +209,14 @@ __global__ __launch_bounds__(SPX_KLD_THREADS) void spx_kld_pairs_kernel(const fl
                                                                        const double* __restrict__ scale_p, unsigned long long* __restrict__ A_fx) {
     extern __shared__ unsigned long long kld_smem[];
     unsigned long long* tab = kld_smem;                    // [K][J][J], two's complement
+    float* ls = (float*)(tab + K * J * J);                 // [K][J]
     const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const double scale = *scale_p;                         // device-side: the host never reads the data (no sync)
     for (int i = tid; i < K * J * J; i += SPX_KLD_THREADS) tab[i] = 0ull;
+    for (int i = tid; i < K * J; i += SPX_KLD_THREADS) ls[i] = lse[(size_t)b * K * J + i];
     __syncthreads();
     const float* v = vals + (size_t)b * J * HW;
     const int32_t* lab = labels + (size_t)b * HW;
-    const float* ls = lse + (size_t)b * K * J;
     const SpxKldWalk w = spx_kld_walk(HW, W, lane, wave);
     float acc[JT][JT];
 #pragma unroll
@@ -226,9 +243,11 @@ __global__ __launch_bounds__(SPX_KLD_THREADS) void spx_kld_pairs_kernel(const fl
         const int c0 = __builtin_amdgcn_readfirstlane(c);
         const bool uniform = __builtin_amdgcn_ballot_w64(c != c0) == 0;
         float l[JT], p[JT];          // JT = J rounded up to a multiple of 4: static indices, padded slots contribute 0
+        spx_kld_load_planes(l, v, J, HW, step < w.nvalid ? px : 0);
+        const float* lsc = ls + (ok ? c : 0) * J;
 #pragma unroll
         for (int j = 0; j < JT; ++j) {
-            l[j] = (ok && j < J) ? v[(size_t)j * HW + px] - ls[c * J + j] : 0.0f;
+            l[j] = (ok && j < J) ? l[j] - lsc[min(j, J - 1)] : 0.0f;
             p[j] = (ok && j < J) ? __expf(l[j]) : 0.0f;
         }
         if (uniform) {
@@ -304,9 +323,11 @@ __global__ __launch_bounds__(SPX_KLD_THREADS) void spx_kld_backward_kernel(const
         const int c = lab[px];
         const bool ok = c >= 0 && c < K;
         float l[JT], p[JT];
+        spx_kld_load_planes(l, v, J, HW, px);
+        const float* slc = sL + (ok ? c : 0) * J;
 #pragma unroll
         for (int j = 0; j < JT; ++j) {
-            l[j] = (ok && j < J) ? v[(size_t)j * HW + px] - sL[c * J + j] : 0.0f;
+            l[j] = (ok && j < J) ? l[j] - slc[min(j, J - 1)] : 0.0f;
             p[j] = (ok && j < J) ? __expf(l[j]) : 0.0f;
         }
 #pragma unroll
@@ -352,9 +373,9 @@ hipError_t spx_launch_kld(int pass, const float* vals, const int32_t* labels, in
     if (pass == 0)
         hipLaunchKernelGGL(spx_kld_max_kernel, grid, blk, (size_t)(K * J + K) * 4, s, vals, labels, J, HW, W, K, (unsigned int*)out, (unsigned int*)t0);
     else if (pass == 1)
-        hipLaunchKernelGGL(spx_kld_sumexp_kernel, grid, blk, (size_t)K * J * 8, s, vals, labels, J, HW, W, K, (const unsigned int*)t0, (unsigned long long*)out);
+        hipLaunchKernelGGL(spx_kld_sumexp_kernel, grid, blk, (size_t)K * J * 12, s, vals, labels, J, HW, W, K, (const unsigned int*)t0, (unsigned long long*)out);
     else if (pass == 2) {
-        const size_t lds = (size_t)K * J * J * 8;
+        const size_t lds = (size_t)K * J * J * 8 + (size_t)K * J * 4;
         unsigned long long* o = (unsigned long long*)out;
         if (J <= 4) hipLaunchKernelGGL(spx_kld_pairs_kernel<4>, grid, blk, lds, s, vals, labels, J, HW, W, K, t0, scale, o);
         else if (J <= 8) hipLaunchKernelGGL(spx_kld_pairs_kernel<8>, grid, blk, lds, s, vals, labels, J, HW, W, K, t0, scale, o);
