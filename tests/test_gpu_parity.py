@@ -824,3 +824,49 @@ def test_kld_kernels_ragged_grids(H, W):
     A_w, _, _ = L._KLDSegmentGram.apply(base, lab, K, W)
     A_0, _, _ = L._KLDSegmentGram.apply(base, lab, K, 0)
     assert (A_w - A_0).abs().max().item() <= 1e-5 * (1.0 + A_0.abs().max().item())
+
+
+@pytest.mark.parametrize("B,P,K,H,W,void", [(1, 3, 2, 1, 4, 0), (2, 8, 4, 2, 6, None), (3, 21, 7, 10, 36, 3), (1, 190, 19, 64, 260, 0), (2, 9, 3, 130, 64, None)])
+def test_push_argmin_vector_path_edges(B, P, K, H, W, void):
+    """H*W % 4 == 0 (the 4-pixel x 8-prototype kernel): fewer prototypes than a block, pixel ranges that end inside a
+    workgroup's span, no void class, a void class in the middle, exact ties - bit-exact against the oracle."""
+    from scaleprotoseg_amd.functional import push_masked_argmin
+
+    dev = _dev()
+    g = torch.Generator().manual_seed(B * 1000 + P)
+    dist = torch.floor(torch.rand(B, P, H, W, generator=g) * 64) / 8          # many exact ties
+    nlab = K if void is None else K + 1
+    target = torch.randint(0, nlab, (B, H, W), generator=g)
+    ident = torch.zeros(P, K)
+    ident[torch.arange(P), torch.arange(P) % K] = 1
+    if K > 2:
+        ident[:, K - 1] = 0                                                   # a class no prototype belongs to
+    ref_idx, ref_val = O.push_masked_argmin(dist, target, ident, K, void_class=void)
+    idx, val = push_masked_argmin(dist.to(dev), target.to(dev), ident, void_class=void)
+    np.testing.assert_array_equal(idx.cpu().numpy(), ref_idx.numpy())
+    np.testing.assert_array_equal(val.cpu().numpy(), ref_val.numpy())
+
+
+def test_push_argmin_full_size_against_torch():
+    """North-star map size (190 x 1024 x 2048): the kernel against torch's masked min on the GPU (same fp32 arithmetic)."""
+    from scaleprotoseg_amd.functional import push_masked_argmin
+
+    dev = _dev()
+    P, K, H, W = 190, 19, 1024, 2048
+    gen = torch.Generator(device=dev).manual_seed(3)
+    dist = torch.rand(1, P, H, W, device=dev, generator=gen) * 40
+    target = torch.randint(0, K + 1, (1, H, W), device=dev, generator=gen)
+    ident = O.default_class_identity(P, K, 1).to(dev)
+    idx, val = push_masked_argmin(dist, target, ident, void_class=0)
+    cls = ident.argmax(dim=1)                                                 # one class per prototype here
+    for p0 in range(0, P, 38):
+        sl = slice(p0, p0 + 38)
+        mask = (target.reshape(1, 1, -1) - 1 == cls[sl].view(1, -1, 1)).float()
+        masked = dist[:, sl].reshape(1, 38, -1) + 1e10 * (1 - mask)
+        ref = masked.min(dim=-1)
+        assert torch.equal(val[:, sl], ref.values)
+        # torch's GPU min does not promise the first index among exact ties: check the value at ours and minimality
+        got = torch.gather(masked, 2, idx[:, sl].unsqueeze(-1)).squeeze(-1)
+        assert torch.equal(got, ref.values)
+        first = (masked == ref.values.unsqueeze(-1)).float().argmax(dim=-1)
+        assert torch.equal(idx[:, sl], first)
