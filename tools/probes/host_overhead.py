@@ -36,5 +36,5 @@ for tag, cfg in (("Cityscapes train crops x10", (10, 4, 64, 228, 19, 65, 65)), (
     pr.disable()
     torch.cuda.synchronize()
     s = io.StringIO()
-    pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(22)
+    pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(28)
     print("\n".join(l[:150] for l in s.getvalue().splitlines()[4:40]))
