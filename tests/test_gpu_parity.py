@@ -617,7 +617,9 @@ def test_random_configurations(seed):
     tag = f"B{B} S{S} Cs{Cs} P{per_scale} K{K} {H}x{W} {x_dtype}"
     _grad_close(x.grad, dx_ref, "dX " + tag, tol=4e-3 if x_dtype == torch.float32 else 8e-3)
     _grad_close(pv.grad, dp_ref, "dPrototypes " + tag)
-    _grad_close(w.grad, dw_ref, "dLastLayer " + tag, tol=8e-3)
+    # d_W = dLogits^T . a with the activations as ONE bf16 operand: 8e-3 holds for the suite's seeds; the extended run
+    # (tests/fuzz_extended.py, 600 cases) peaks at 9.1e-3 on a 2-prototype-per-class bank
+    _grad_close(w.grad, dw_ref, "dLastLayer " + tag, tol=1.2e-2)
 
 
 @pytest.mark.parametrize("seed", list(range(12)))
@@ -664,7 +666,7 @@ def test_random_gather_and_tail(seed):
         _assert_fwd(logits, None, None, l_ref.detach(), None, None)
         ((logits * g_logits.reshape(-1, K).to(dev)).sum() + (cd * g_cls.permute(0, 2, 1).contiguous().to(dev)).sum()).backward()
         torch.cuda.synchronize()
-        _grad_close(w.grad, w0.grad, "dLastLayer", tol=8e-3)
+        _grad_close(w.grad, w0.grad, "dLastLayer", tol=1.2e-2)      # `a` is ONE bf16 operand; toy grid, see dPrototypes below
     else:
         G = int(rng.integers(2, 4))
         idx = [i for i in O.class_prototype_index(ident) if len(i) > 0]
@@ -692,7 +694,10 @@ def test_random_gather_and_tail(seed):
         torch.cuda.synchronize()
         _grad_close(wgd.grad, wg0.grad, "dLastLayerGroup", tol=2e-3)
     _grad_close(x.grad, c0.grad, "dX", tol=dx_tol)
-    _grad_close(pv.grad, p0.grad, "dPrototypes")
+    # dPrototypes = -2 sum_px G (x - p) with G ONE bf16 operand (half-ulp 2^-9 per term): on these grids of a few
+    # hundred pixels the signed terms cancel and the error relative to max|dP| reaches 4.8e-3 (seen in a 600-case run of
+    # tests/fuzz_extended.py; the realistic shapes of BWD_SHAPES stay inside 3e-3)
+    _grad_close(pv.grad, p0.grad, "dPrototypes", tol=6e-3)
 
 
 
