@@ -4,8 +4,9 @@ class-gathered form.
 The reference's KLDLoss reads, for a pixel of class c, only the distance columns of class c's prototypes
 (loss.py:89-107).  ``ClassDistances`` carries exactly those entries ([B, J, H*W] slot planes, produced by the fused kernels
 with ``forward_from_conv_features(..., target_labels=...)``), so the fp32 [B, P, H, W] map and its gradient never
-cross HBM.  ``KLDLoss`` accepts either form and returns the same value; it is plain torch (device-agnostic host
-logic around the kernels' output), differentiable through ``ClassDistances.values``.
+cross HBM.  ``KLDLoss`` accepts either form and returns the same value; on fp32 GPU tensors the pixel loops run in the
+HIP kernels of csrc/spx_kld.hip (differentiable through ``ClassDistances.values``); the vectorised torch form of the
+same algebra is opt-in (``torch_formulation=True``), never a silent fallback.
 """
 from __future__ import annotations
 
@@ -14,6 +15,8 @@ from typing import Dict, Tuple, Union
 
 import torch
 from torch import nn
+
+from ._lib import SpxError
 
 
 @dataclass
@@ -165,11 +168,16 @@ class KLDLoss(nn.Module):
     ``ClassDistances``.  One pass of segment reductions instead of the reference's (image, class, scale, pair)
     Python loops with host syncs."""
 
-    def __init__(self, prototype_class_identity: torch.Tensor, num_scales: int, scale_num_prototypes: Dict[int, Tuple[int, int]]) -> None:
+    def __init__(self, prototype_class_identity: torch.Tensor, num_scales: int, scale_num_prototypes: Dict[int, Tuple[int, int]],
+                 *, torch_formulation: bool = False) -> None:
+        """``torch_formulation`` (keyword-only, not in the reference): allow the vectorised torch form of the loss for
+        inputs the HIP kernels do not take (not on the GPU, not fp32, J > 16 or K*J*J beyond the LDS table).  Off by
+        default: like the rest of the package the loss then REFUSES such inputs instead of silently leaving the GPU path."""
         super().__init__()
         self.prototype_class_identity = prototype_class_identity
         self.num_scales = num_scales
         self.scale_num_prototypes = scale_num_prototypes
+        self.torch_formulation = torch_formulation
 
     def _pair_mask(self, table: torch.Tensor) -> torch.Tensor:
         """[K, J, J] bool: slots j < k of class c are prototypes of the same scale (loss.py:99-104, :118-121).
@@ -222,6 +230,12 @@ class KLDLoss(nn.Module):
             # this path reads a value back to the host (capturable in a HIP graph)
             A, _, counts = _KLDSegmentGram.apply(planes, lab, K, width)
             return self._loss_from_gram(A.reshape(nseg, J, J), counts.reshape(nseg), table, K, nseg)
+        if not self.torch_formulation:
+            raise SpxError(
+                f"KLD loss: input {tuple(vals.shape)} {vals.dtype} on {vals.device} (K={K}, J={J}) is outside the HIP kernels' "
+                "domain (fp32 on the GPU, J <= 16, K*J*J*8 + K*J*8 <= 60 KiB); pass torch_formulation=True to the "
+                "constructor to allow the torch form - there is no silent fallback"
+            )
         if not bool(ok.any()):
             return torch.tensor(0.0)
         # (image, class) segment of every pixel; pixels without a class go to a dummy segment that is dropped below
@@ -292,11 +306,13 @@ class KLDLossGroup(KLDLoss):
     pair of a class is compared, loss.py:527-536), so the segment kernels are shared; ``list_group_activation`` may
     also be the concatenated [M, n_projections * num_groups] tensor the grouping head produces."""
 
-    def __init__(self, prototype_class_identity: torch.Tensor, group_class_identity: torch.Tensor, num_groups: int) -> None:
+    def __init__(self, prototype_class_identity: torch.Tensor, group_class_identity: torch.Tensor, num_groups: int,
+                 *, torch_formulation: bool = False) -> None:
         nn.Module.__init__(self)
         self.prototype_class_identity = prototype_class_identity
         self.group_class_identity = group_class_identity
         self.num_groups = num_groups
+        self.torch_formulation = torch_formulation
         self._tables = None
 
     def _class_tables(self):

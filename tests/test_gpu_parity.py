@@ -761,8 +761,10 @@ def test_kld_kernels_large_random():
         v1 = base.clone().requires_grad_(True)
         l1 = loss_fn(spx.ClassDistances(v1, (t.reshape(1, -1) - 1).int(), table, (H, W)), t)
         l1.backward()
-        v2 = base.double().clone().requires_grad_(True)                      # fp64 -> the torch path
-        l2 = loss_fn(spx.ClassDistances(v2, (t.reshape(1, -1) - 1).int(), table, (H, W)), t)
+        v2 = base.double().clone().requires_grad_(True)                      # fp64 -> the (opt-in) torch form
+        with pytest.raises(spx.SpxError):
+            loss_fn(spx.ClassDistances(v2, (t.reshape(1, -1) - 1).int(), table, (H, W)), t)      # never a silent fallback
+        l2 = spx.KLDLoss(ident, S, {0: (0, P)}, torch_formulation=True)(spx.ClassDistances(v2, (t.reshape(1, -1) - 1).int(), table, (H, W)), t)
         l2.backward()
         torch.cuda.synchronize()
         assert abs(l1.item() - l2.item()) <= 1e-5 * max(1.0, abs(l2.item())), (l1.item(), l2.item())
@@ -815,7 +817,7 @@ def test_kld_kernels_ragged_grids(H, W):
     loss_fn = spx.KLDLoss(ident, S, {0: (0, P)})
     lab = (t.reshape(2, -1) - 1).int()
     v2 = base.double().clone().requires_grad_(True)
-    l2 = loss_fn(spx.ClassDistances(v2, lab, table, (H, W)), t)
+    l2 = spx.KLDLoss(ident, S, {0: (0, P)}, torch_formulation=True)(spx.ClassDistances(v2, lab, table, (H, W)), t)
     l2.backward()
     for grid in ((H, W), (1, H * W)):               # column strips / one row (= the linear order)
         v1 = base.clone().requires_grad_(True)

@@ -152,7 +152,7 @@ def test_kld_loss_module_matches_reference(golden, tag):
     S = int(g[f"{tag}_S"])
     ranges = {s: tuple(int(v) for v in g[f"{tag}_ranges"][s]) for s in range(S)}
     d = torch.from_numpy(g[f"{tag}_dist"]).requires_grad_(True)
-    loss = KLDLoss(ident, S, ranges)(d, t)
+    loss = KLDLoss(ident, S, ranges, torch_formulation=True)(d, t)
     loss.backward()
     assert abs(loss.item() - float(g[f"{tag}_loss"])) <= 1e-6
     scale = np.abs(g[f"{tag}_grad"]).max()
@@ -162,7 +162,7 @@ def test_kld_loss_module_matches_reference(golden, tag):
     lab0 = t.reshape(t.shape[0], -1) - 1
     cv = gather_class_distances(torch.from_numpy(g[f"{tag}_dist"]), lab0, table)
     assert torch.equal(cv, O.gather_class_distances(torch.from_numpy(g[f"{tag}_dist"]), lab0, ident))
-    lg = KLDLoss(ident, S, ranges)(ClassDistances(cv.permute(0, 2, 1).contiguous(), lab0, table, tuple(t.shape[1:])), t)
+    lg = KLDLoss(ident, S, ranges, torch_formulation=True)(ClassDistances(cv.permute(0, 2, 1).contiguous(), lab0, table, tuple(t.shape[1:])), t)
     assert abs(lg.item() - float(g[f"{tag}_loss"])) <= 1e-6
 
 
@@ -171,7 +171,7 @@ def test_kld_loss_no_terms():
     from oracle import ppnet_oracle as O
 
     ident = O.default_class_identity(8, 4, 1)
-    assert KLDLoss(ident, 1, {0: (0, 8)})(torch.rand(1, 8, 3, 3), torch.zeros(1, 3, 3, dtype=torch.long)).item() == 0.0
+    assert KLDLoss(ident, 1, {0: (0, 8)}, torch_formulation=True)(torch.rand(1, 8, 3, 3), torch.zeros(1, 3, 3, dtype=torch.long)).item() == 0.0
 
 
 def test_reference_state_dict_after_push_dedup(tmp_path, golden):
@@ -232,7 +232,7 @@ def test_kld_loss_group_module_matches_reference(golden):
     n = int(g["grp_n"])
     acts = [torch.from_numpy(g[f"grp_act{i}"]).requires_grad_(True) for i in range(n)]
     t = torch.from_numpy(g["grp_target"])
-    m = KLDLossGroup(torch.from_numpy(g["grp_ident"]), torch.from_numpy(g["grp_gci"]), int(g["grp_G"]))
+    m = KLDLossGroup(torch.from_numpy(g["grp_ident"]), torch.from_numpy(g["grp_gci"]), int(g["grp_G"]), torch_formulation=True)
     loss = m(acts, t)
     loss.backward()
     assert abs(loss.item() - float(g["grp_loss"])) <= 1e-6
@@ -242,3 +242,19 @@ def test_kld_loss_group_module_matches_reference(golden):
     cat = torch.cat([a.detach() for a in acts], dim=1)
     assert abs(m(cat, t).item() - loss.item()) <= 1e-7
     assert m(acts, torch.zeros_like(t)).item() == 0.0                      # void only: no term (loss.py:541-542)
+
+
+def test_kld_loss_refuses_inputs_outside_the_kernels():
+    """Without the explicit opt-in the loss modules do not leave the GPU path: a CPU tensor is an error, not a fallback."""
+    from oracle import ppnet_oracle as O
+    from scaleprotoseg_amd import SpxError
+    from scaleprotoseg_amd.loss import KLDLoss, KLDLossGroup
+
+    ident = O.default_class_identity(8, 4, 1)
+    with pytest.raises(SpxError):
+        KLDLoss(ident, 1, {0: (0, 8)})(torch.rand(1, 8, 3, 3), torch.ones(1, 3, 3, dtype=torch.long))
+    gci = torch.zeros(8, 4)
+    for k in range(4):
+        gci[2 * k:2 * k + 2, k] = 1
+    with pytest.raises(SpxError):
+        KLDLossGroup(ident, gci, 2)([torch.rand(9, 2) for _ in range(4)], torch.ones(1, 3, 3, dtype=torch.long))
