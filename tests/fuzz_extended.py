@@ -1,6 +1,7 @@
 """Extended randomised parity run (not collected by pytest): the bodies of test_random_configurations and
 test_random_gather_and_tail over many more seeds than the suite carries.  Usage (GPU box):
     python tests/fuzz_extended.py FIRST LAST [LOGFILE]
+    python tests/fuzz_extended.py kld|push FIRST LAST [LOGFILE]
 Prints one line per failing seed and a summary; progress goes to LOGFILE every 10 seeds."""
 import os
 import sys
@@ -12,7 +13,93 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import test_gpu_parity as T  # noqa: E402
 
 
+def kld_case(seed):
+    """KLDLoss kernels (all slot-count instances, both walks, ragged grids, void / absent classes, tiny segments) against
+    the fp64 torch form of the same loss."""
+    import numpy as np
+    import torch
+    import scaleprotoseg_amd as spx
+
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(9000 + seed)
+    K = int(rng.integers(1, 24))
+    S = int(rng.choice([1, 2, 4]))
+    r = int(rng.integers(1, 5))                     # prototypes per (class, scale): J = S * r <= 16
+    P = K * S * r
+    B = int(rng.integers(1, 4))
+    H, W = int(rng.integers(1, 120)), int(rng.integers(1, 400))
+    ident = T.O.default_class_identity(P, K, S)
+    ranges = T.O.default_scale_ranges(P, S)
+    lay = T._layout(P, K, S, 16, ranges)
+    keys, J, table = spx.class_gather_table(lay, ident, dev)
+    gen = torch.Generator(device=dev).manual_seed(seed)
+    ph, pw = int(rng.choice([1, 3, 16, 40])), int(rng.choice([1, 5, 64, 100]))
+    t = torch.randint(0, K + 1, (B, -(-H // ph), -(-W // pw)), device=dev, generator=gen)
+    t = t.repeat_interleave(ph, 1).repeat_interleave(pw, 2)[:, :H, :W].contiguous()
+    if K > 2:
+        t[t == 2] = 0                               # class 1 absent
+    base = torch.rand(B, J, H * W, device=dev, generator=gen) * float(rng.choice([1.0, 30.0, 200.0]))
+    lab = (t.reshape(B, -1) - 1).int()
+    grid = (H, W) if seed % 3 else (1, H * W)
+    v1 = base.clone().requires_grad_(True)
+    l1 = spx.KLDLoss(ident, S, ranges)(spx.ClassDistances(v1, lab, table, grid), t)
+    l1.backward()
+    v2 = base.double().clone().requires_grad_(True)
+    l2 = spx.KLDLoss(ident, S, ranges, torch_formulation=True)(spx.ClassDistances(v2, lab, table, (H, W)), t)
+    if v2.grad is None and l2.requires_grad:
+        l2.backward()
+    torch.cuda.synchronize()
+    tag = f"B{B} K{K} S{S} r{r} J{J} {H}x{W} patch {ph}x{pw} grid {grid}"
+    assert abs(l1.item() - l2.item()) <= 2e-5 * max(1.0, abs(l2.item())), (tag, l1.item(), l2.item())
+    if v2.grad is not None:
+        s = v2.grad.abs().max().item()
+        e = (v1.grad.double() - v2.grad).abs().max().item()
+        assert e <= 2e-4 * s + 1e-12, (tag, e, s)
+
+
+def push_case(seed):
+    """Push argmin (vector and scalar kernels) on random shapes, label ranges, void classes and tie-heavy maps: bit-exact."""
+    import numpy as np
+    import torch
+    from scaleprotoseg_amd.functional import push_masked_argmin
+
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(7000 + seed)
+    B, P, K = int(rng.integers(1, 4)), int(rng.integers(1, 70)), int(rng.integers(1, 25))
+    H, W = int(rng.integers(1, 90)), int(rng.integers(1, 200))
+    if seed % 2:
+        W = 4 * max(1, W // 4)                      # the 4-pixel x 8-prototype kernel
+    void = None if seed % 3 == 0 else int(rng.integers(0, K + 1))
+    g = torch.Generator().manual_seed(seed)
+    q = float(rng.choice([1.0, 8.0, 1024.0]))
+    dist = torch.floor(torch.rand(B, P, H, W, generator=g) * 64 * q) / q
+    target = torch.randint(0, K if void is None else K + 1, (B, H, W), generator=g)
+    ident = (torch.rand(P, K, generator=g) < 1.5 / K).float()      # 0, 1 or several classes per prototype
+    ref_idx, ref_val = T.O.push_masked_argmin(dist, target, ident, K, void_class=void)
+    idx, val = push_masked_argmin(dist.to(dev), target.to(dev), ident, void_class=void)
+    tag = f"B{B} P{P} K{K} {H}x{W} void {void}"
+    assert torch.equal(idx.cpu(), ref_idx), tag
+    assert torch.equal(val.cpu(), ref_val), tag
+
+
 def main():
+    if sys.argv[1] in ("kld", "push"):
+        case = kld_case if sys.argv[1] == "kld" else push_case
+        first, last = int(sys.argv[2]), int(sys.argv[3])
+        log = open(sys.argv[4], "a") if len(sys.argv) > 4 else sys.stdout
+        fails = []
+        for seed in range(first, last):
+            try:
+                case(seed)
+            except Exception as e:  # noqa: BLE001
+                fails.append(seed)
+                print(f"FAIL {case.__name__}({seed}): {type(e).__name__}: {str(e)[:300]}", file=log, flush=True)
+                if not isinstance(e, AssertionError):
+                    traceback.print_exc(file=log)
+            if seed % 20 == 0:
+                print(f"kld seed {seed} done, {len(fails)} failures so far", file=log, flush=True)
+        print(f"{sys.argv[1]} fuzz {first}..{last}: {len(fails)} failures {fails}")
+        return 1 if fails else 0
     first, last = int(sys.argv[1]), int(sys.argv[2])
     log = open(sys.argv[3], "a") if len(sys.argv) > 3 else sys.stdout
     fails = []
