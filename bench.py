@@ -42,7 +42,7 @@ def algorithmic_bytes_per_px(C, P, K):
     return fwd, bwd
 
 
-def cpu_baseline(C, P, S, K, sample_hw, reps=3):
+def cpu_baseline(C, P, S, K, sample_hw, reps=6):
     """The oracle (CPU restatement of the reference op sequence) timed on this host's cores."""
     from oracle import ppnet_oracle as O
 
