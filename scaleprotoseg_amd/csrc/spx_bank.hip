@@ -250,14 +250,25 @@ __global__ __launch_bounds__(SPX_BK_THREADS, 2) void spx_bank_bwd_kernel(const S
             const int fo0 = spx_blob_slot(ra, tpp & 1, ts2) * 16 + 8 * (tpp >> 1);
             const int fo1 = spx_blob_slot(ra + 4, tpp & 1, ts2) * 16 + 8 * (tpp >> 1);
             const int fb = ((wsel * NPB + wave) * 2 + ts2) * 1024;
-            const bf16x4 a0 = __builtin_bit_cast(bf16x4, lds_tr_read(As + fb + fo0));
-            const bf16x4 a1 = __builtin_bit_cast(bf16x4, lds_tr_read(As + fb + fo1));
-            const bf16x8 af = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+            // the activation blob is fp16 (the transposed read only moves 16-bit elements): a = hi + lo exactly in two
+            // bf16, so d_W = (hi + lo) . (dl_hi + dl_lo) carries ~2^-12 of a's rounding instead of bf16's 2^-9
+            const f16x4 a0 = __builtin_bit_cast(f16x4, lds_tr_read(As + fb + fo0));
+            const f16x4 a1 = __builtin_bit_cast(f16x4, lds_tr_read(As + fb + fo1));
+            bf16x8 af, af2;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float v = (float)(j < 4 ? a0[j & 3] : a1[j & 3]);
+                __bf16 hi, lo;
+                split_bf16(v, hi, lo);
+                af[j] = hi;
+                af2[j] = lo;
+            }
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb) {
                 const bf16x8 lf = *(const bf16x8*)(Ls + (cb * 32 + r) * SPX_BK_ROW + koff);
                 const bf16x8 lf2 = *(const bf16x8*)(Ls2 + (cb * 32 + r) * SPX_BK_ROW + koff);
                 accw[cb] = mfma_bf16(af, lf, accw[cb]);
+                accw[cb] = mfma_bf16(af2, lf, accw[cb]);
                 accw[cb] = mfma_bf16(af, lf2, accw[cb]);
             }
         };

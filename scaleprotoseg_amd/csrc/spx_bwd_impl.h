@@ -356,13 +356,13 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
         // gout = its packed G fragments (k-steps 0 / 1)
         auto block = [&](int pb, auto slot_c, float (&ddc)[16], float (&ddnext)[16], bf16x8 (&gout)[2]) {
             constexpr int SLOT = decltype(slot_c)::value;
-            bf16x8 anew[2];
+            f16x8 anew[2];     // the activation blob is fp16 (a / ln 2 <= 13.3; 11-bit mantissa): the bank side splits it into bf16 hi + lo
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     gout[s2][j] = (__bf16)0.0f;
-                    anew[s2][j] = (__bf16)0.0f;
+                    anew[s2][j] = (_Float16)0.0f;
                 }
             if (pb < nv) {
                 if (have_dd && pb + 1 < nv) load_ddist(pb + 1, ddnext);
@@ -451,7 +451,7 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
                     // the row sum uses the SAME rounded G as the P^T.G product: dX = 2 sum_p G_p (x - p) then carries
                     // G's rounding relative to |x - p|, not to |p| (matters where a pixel sits on a prototype)
                     rs += (float)gb;
-                    anew[reg >> 3][reg & 7] = (__bf16)av[reg];
+                    anew[reg >> 3][reg & 7] = (_Float16)av[reg];
                 }
             }
             // fragment dump for kernel 2 (wholly padded blocks are written as zeros: kernel 2 reads them)

@@ -82,7 +82,27 @@ def push_case(seed):
     assert torch.equal(val.cpu(), ref_val), tag
 
 
+def grad_stats(first, last):
+    """Peak err / max|ref| per gradient over the randomised configurations (no assertion): what the tolerances are set from."""
+    peaks = {}
+
+    def record(got, ref, what, tol=3e-3):
+        got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
+        ratio = (got - ref).abs().max().item() / (ref.abs().max().item() + 1e-30)
+        key = what.split()[0]
+        peaks[key] = max(peaks.get(key, 0.0), ratio)
+
+    T._grad_close = record
+    for seed in range(first, last):
+        for fn in (T.test_random_configurations, T.test_random_gather_and_tail):
+            fn(seed)
+    print("peak err / max|ref|:", {k: f"{v:.2e}" for k, v in sorted(peaks.items())})
+    return 0
+
+
 def main():
+    if sys.argv[1] == "gradstats":
+        return grad_stats(int(sys.argv[2]), int(sys.argv[3]))
     if sys.argv[1] in ("kld", "push"):
         case = kld_case if sys.argv[1] == "kld" else push_case
         first, last = int(sys.argv[2]), int(sys.argv[3])

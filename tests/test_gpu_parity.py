@@ -150,7 +150,7 @@ def test_backward_matches_oracle(shape, x_dtype):
     assert x.grad.dtype == x_dtype and x.grad.shape == x.shape
     _grad_close(x.grad, dx_ref, "dX", tol=4e-3 if x_dtype == torch.float32 else 8e-3)
     _grad_close(pv.grad, dp_ref, "dPrototypes")
-    _grad_close(w.grad, dw_ref, "dLastLayer", tol=8e-3)
+    _grad_close(w.grad, dw_ref, "dLastLayer", tol=2.5e-3)
 
 
 @pytest.mark.parametrize("name", ["proto_ms_city", "proto_s1_wide"])
@@ -176,7 +176,7 @@ def test_backward_matches_golden(golden, name):
     loss.backward()
     _grad_close(x.grad, torch.from_numpy(g["d_conv"]), "dX")
     _grad_close(pv.grad, torch.from_numpy(g["d_prototypes"]), "dPrototypes")
-    _grad_close(w.grad, torch.from_numpy(g["d_last_layer"]), "dLastLayer", tol=8e-3)
+    _grad_close(w.grad, torch.from_numpy(g["d_last_layer"]), "dLastLayer", tol=2.5e-3)
 
 
 def test_backward_partial_inputs():
@@ -196,7 +196,7 @@ def test_backward_partial_inputs():
     logits, dist, _ = proto_head_forward(x, bank.to(dev), w, _layout(P, K, S, Cs, ranges))
     (logits * g_logits.reshape(-1, K).to(dev)).sum().backward()
     _grad_close(x.grad, dx_ref, "dX (logits only)")
-    _grad_close(w.grad, dw_ref, "dW (logits only)", tol=8e-3)
+    _grad_close(w.grad, dw_ref, "dW (logits only)", tol=2.5e-3)
 
     g_dist = torch.randn(B, P, H, W, generator=g) * 1e-3
     _, _, _, dx_ref, dp_ref, _ = O.fwd_bwd_reference(conv, bank, ranges, S, Wl, torch.zeros(B, H, W, K), g_dist)
@@ -360,7 +360,7 @@ def test_class_gathered_forward_backward(shape, x_dtype):
     torch.cuda.synchronize()
     _grad_close(x.grad, c0.grad, "dX", tol=4e-3 if x_dtype == torch.float32 else 8e-3)
     _grad_close(pv.grad, p0.grad, "dPrototypes")
-    _grad_close(w.grad, w0.grad, "dLastLayer", tol=8e-3)
+    _grad_close(w.grad, w0.grad, "dLastLayer", tol=2.5e-3)
 
 
 def test_kld_through_the_module(golden):
@@ -536,7 +536,7 @@ def test_fused_group_tail(shape, x_dtype):
     mask = torch.zeros(U, P, dtype=torch.bool)
     for k, i in enumerate(idx):
         mask[k * G:(k + 1) * G, i] = True
-    _grad_close(wdd.grad.cpu() * mask, dwd_ref, "dGroupProjection", tol=8e-3)
+    _grad_close(wdd.grad.cpu() * mask, dwd_ref, "dGroupProjection", tol=2.5e-3)
 
 
 @pytest.mark.parametrize("case", [(1, 228, 17, 33, 129, 257, False), (2, 19, 9, 11, 70, 90, True), (1, 5, 4, 5, 4, 5, False),
@@ -616,10 +616,12 @@ def test_random_configurations(seed):
     torch.cuda.synchronize()
     tag = f"B{B} S{S} Cs{Cs} P{per_scale} K{K} {H}x{W} {x_dtype}"
     _grad_close(x.grad, dx_ref, "dX " + tag, tol=4e-3 if x_dtype == torch.float32 else 8e-3)
-    _grad_close(pv.grad, dp_ref, "dPrototypes " + tag)
-    # d_W = dLogits^T . a with the activations as ONE bf16 operand: 8e-3 holds for the suite's seeds; the extended run
-    # (tests/fuzz_extended.py, 600 cases) peaks at 9.1e-3 on a 2-prototype-per-class bank
-    _grad_close(w.grad, dw_ref, "dLastLayer " + tag, tol=1.2e-2)
+    # G is ONE bf16 operand of dPrototypes = -2 sum_px G (x - p): 3e-3 holds on the fixed shapes; with one prototype per
+    # scale the extended run (tests/fuzz_extended.py) reaches 4.4e-3
+    _grad_close(pv.grad, dp_ref, "dPrototypes " + tag, tol=5e-3)
+    # d_W = dLogits^T . a: the activations cross HBM as fp16 and enter the MFMA as bf16 hi + lo, dLogits as bf16 hi + lo;
+    # peak over 400 further random configurations (tests/fuzz_extended.py gradstats): 1.1e-3
+    _grad_close(w.grad, dw_ref, "dLastLayer " + tag, tol=2.5e-3)
 
 
 @pytest.mark.parametrize("seed", list(range(12)))
@@ -666,7 +668,7 @@ def test_random_gather_and_tail(seed):
         _assert_fwd(logits, None, None, l_ref.detach(), None, None)
         ((logits * g_logits.reshape(-1, K).to(dev)).sum() + (cd * g_cls.permute(0, 2, 1).contiguous().to(dev)).sum()).backward()
         torch.cuda.synchronize()
-        _grad_close(w.grad, w0.grad, "dLastLayer", tol=1.2e-2)      # `a` is ONE bf16 operand; toy grid, see dPrototypes below
+        _grad_close(w.grad, w0.grad, "dLastLayer", tol=2.5e-3)
     else:
         G = int(rng.integers(2, 4))
         idx = [i for i in O.class_prototype_index(ident) if len(i) > 0]
