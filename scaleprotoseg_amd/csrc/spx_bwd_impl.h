@@ -428,7 +428,7 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
 #pragma unroll
                     for (int reg = 0; reg < 16; ++reg) {
                         rpv[reg] = 1.0f;
-                        av[reg] = -1.44269504089f * fmaxf(dr[reg], 0.0f);
+                        av[reg] = fmaxf(-1.44269504089f * fmaxf(dr[reg], 0.0f), -65504.0f);   // the blob is fp16: saturate, never inf
                     }
                 }
                 float gv[16];
