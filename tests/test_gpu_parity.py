@@ -879,3 +879,152 @@ def test_push_argmin_full_size_against_torch():
         assert torch.equal(got, ref.values)
         first = (masked == ref.values.unsqueeze(-1)).float().argmax(dim=-1)
         assert torch.equal(idx[:, sl], first)
+
+
+class _Guarded:
+    """A device buffer with guard bands on both sides: kernels get a pointer into the middle, the bands must stay intact."""
+    GUARD = 64 * 1024          # bytes each side
+
+    def __init__(self, nbytes, dev):
+        self.n = int(nbytes)
+        self.buf = torch.full((self.n + 2 * self.GUARD,), 0xA5, dtype=torch.uint8, device=dev)
+
+    @property
+    def ptr(self):
+        return self.buf.data_ptr() + self.GUARD
+
+    def body(self, dtype):
+        return self.buf[self.GUARD:self.GUARD + self.n].view(dtype)
+
+    def intact(self):
+        g = self.GUARD
+        return bool((self.buf[:g] == 0xA5).all()) and bool((self.buf[g + self.n:] == 0xA5).all())
+
+
+@pytest.mark.parametrize("seed", list(range(16)))
+def test_no_write_outside_the_output_buffers(seed):
+    """Every output of the forward / pixel-side / bank-side backward / push through the C ABI, placed between guard
+    bands, on random ragged shapes (partial tiles, odd H*W, 16-channel tails, padded prototype and class blocks):
+    the kernels predicate with out-of-range buffer offsets, so nothing may land outside [ptr, ptr + size)."""
+    import ctypes as C_
+    from scaleprotoseg_amd import _lib
+    from scaleprotoseg_amd.functional import _Packs, BankLayout
+
+    dev = _dev()
+    lib = _lib.load()
+    rng = np.random.default_rng(3000 + seed)
+    B, S, Cs, per_scale, K, H, W = _random_case(rng)
+    P, HW, C = sum(per_scale), H * W, S * Cs
+    ranges, lo = [], 0
+    for n in per_scale:
+        ranges.append((lo, lo + n))
+        lo += n
+    lay = BankLayout(P, K, S, Cs, tuple(ranges))
+    plan = lay.plan()
+    pp = C_.byref(plan)
+    g = torch.Generator(device=dev).manual_seed(seed)
+    xf32 = seed % 2 == 0
+    x = torch.rand(B, C, HW, device=dev, generator=g)
+    x = x if xf32 else x.bfloat16()
+    esz = 4 if xf32 else 2
+    bank = torch.rand(P, Cs, device=dev, generator=g)
+    head = torch.randn(K, P, device=dev, generator=g) * 0.1
+    packs = _Packs(plan, bank, head, True)
+    s = _lib.stream_ptr()
+    dist, act, logits = _Guarded(B * P * HW * 4, dev), _Guarded(B * HW * P * 4, dev), _Guarded(B * HW * K * 4, dev)
+    _lib.check(lib.spx_dist_fwd(pp, _lib.ptr(x), 1 if xf32 else 0, B, HW, _lib.ptr(packs.bank), _lib.ptr(packs.p2), _lib.ptr(packs.head),
+                                dist.ptr, act.ptr, logits.ptr, 1e-4, 0, s))
+    scr = lib.spx_bwd_scratch_bytes(pp, B, HW)
+    dx, gs, as_ = _Guarded(B * C * HW * esz, dev), _Guarded(scr, dev), _Guarded(scr, dev)
+    gd = torch.randn(B, P, HW, device=dev, generator=g) * 1e-3
+    ga = torch.randn(B * HW, P, device=dev, generator=g) * 1e-3
+    gl = torch.randn(B * HW, K, device=dev, generator=g) * 1e-3
+    _lib.check(lib.spx_dist_bwd(pp, _lib.ptr(x), 1 if xf32 else 0, B, HW, _lib.ptr(packs.bank), _lib.ptr(packs.bankT), _lib.ptr(packs.p2),
+                                _lib.ptr(packs.headT), _lib.ptr(gd), _lib.ptr(ga), _lib.ptr(gl), dx.ptr, gs.ptr, as_.ptr, 1e-4, 0, s))
+    ws = _Guarded(lib.spx_bank_bwd_workspace_bytes(pp, B, HW), dev)
+    d_bank, d_head = _Guarded(P * Cs * 4, dev), _Guarded(K * P * 4, dev)
+    _lib.check(lib.spx_bank_bwd(pp, _lib.ptr(x), 1 if xf32 else 0, B, HW, _lib.ptr(bank), gs.ptr, as_.ptr, _lib.ptr(gl), d_bank.ptr,
+                                d_head.ptr, ws.ptr, s))
+    idx, val, scratch = _Guarded(B * P * 8, dev), _Guarded(B * P * 4, dev), _Guarded(B * P * 8, dev)
+    labels = torch.randint(0, K + 1, (B, HW), device=dev, generator=g, dtype=torch.int32)
+    ident = torch.zeros(P, K, device=dev)
+    ident[torch.arange(P), torch.arange(P) % K] = 1
+    _lib.check(lib.spx_push_argmin(dist.ptr, _lib.ptr(labels), _lib.ptr(ident), B, P, K, HW, 0, 1e10, idx.ptr, val.ptr, scratch.ptr, s))
+    torch.cuda.synchronize()
+    tag = f"B{B} S{S} Cs{Cs} P{per_scale} K{K} {H}x{W} {'f32' if xf32 else 'bf16'}"
+    for name, gb in (("distances", dist), ("activations", act), ("logits", logits), ("dX", dx), ("G blob", gs), ("a blob", as_),
+                     ("bank workspace", ws), ("dBank", d_bank), ("dHead", d_head), ("push idx", idx), ("push val", val),
+                     ("push scratch", scratch)):
+        assert gb.intact(), f"{name}: write outside the buffer ({tag})"
+    # and the buffers themselves were fully produced (no 0xA5 pattern left in the dense outputs)
+    for name, gb in (("distances", dist), ("logits", logits), ("dBank", d_bank), ("dHead", d_head)):
+        assert not bool((gb.body(torch.int32) == -1515870811).any()), f"{name}: unwritten words ({tag})"     # 0xA5A5A5A5
+
+
+@pytest.mark.parametrize("seed", list(range(10)))
+def test_no_write_outside_the_output_buffers_extended_ops(seed):
+    """Guard bands around the outputs of the class-gathered forward / backward, the KLD passes and the fused
+    evaluation map, on random ragged shapes."""
+    import ctypes as C_
+    from scaleprotoseg_amd import _lib
+    from scaleprotoseg_amd.functional import _Packs, BankLayout, class_gather_table
+
+    dev = _dev()
+    lib = _lib.load()
+    rng = np.random.default_rng(4000 + seed)
+    S = int(rng.choice([1, 2, 4]))
+    Cs = int(rng.choice([16, 32, 48, 64]))
+    K = int(rng.choice([2, 3, 5, 19, 21]))
+    r = int(rng.integers(1, 4))
+    P = K * S * r
+    B, H, W = int(rng.integers(1, 3)), int(rng.integers(1, 40)), int(rng.integers(1, 70))
+    HW, C = H * W, S * Cs
+    ranges = O.default_scale_ranges(P, S)
+    lay = BankLayout(P, K, S, Cs, tuple(ranges[s] for s in range(S)))
+    plan = lay.plan()
+    pp = C_.byref(plan)
+    ident = O.default_class_identity(P, K, S)
+    keys, J, table = class_gather_table(lay, ident, dev)
+    g = torch.Generator(device=dev).manual_seed(seed)
+    x = torch.rand(B, C, HW, device=dev, generator=g).bfloat16()
+    bank = torch.rand(P, Cs, device=dev, generator=g)
+    head = torch.randn(K, P, device=dev, generator=g) * 0.1
+    packs = _Packs(plan, bank, head, True)
+    labels = torch.randint(-1, K, (B, HW), device=dev, generator=g, dtype=torch.int32)
+    s = _lib.stream_ptr()
+    cd, logits = _Guarded(B * J * HW * 4, dev), _Guarded(B * HW * K * 4, dev)
+    cd.body(torch.float32).zero_()
+    _lib.check(lib.spx_dist_fwd_cls(pp, _lib.ptr(x), 0, B, HW, _lib.ptr(packs.bank), _lib.ptr(packs.p2), _lib.ptr(packs.head),
+                                    _lib.ptr(labels), _lib.ptr(keys), J, cd.ptr, None, logits.ptr, 1e-4, 0, s))
+    scr = lib.spx_bwd_scratch_bytes(pp, B, HW)
+    dx, gs, as_ = _Guarded(B * C * HW * 2, dev), _Guarded(scr, dev), _Guarded(scr, dev)
+    gcd = torch.randn(B, J, HW, device=dev, generator=g) * 1e-3
+    gl = torch.randn(B * HW, K, device=dev, generator=g) * 1e-3
+    _lib.check(lib.spx_dist_bwd_cls(pp, _lib.ptr(x), 0, B, HW, _lib.ptr(packs.bank), _lib.ptr(packs.bankT), _lib.ptr(packs.p2),
+                                    _lib.ptr(packs.headT), _lib.ptr(labels), _lib.ptr(keys), J, _lib.ptr(gcd), None, _lib.ptr(gl),
+                                    dx.ptr, gs.ptr, as_.ptr, 1e-4, 0, s))
+    # KLD passes on the gathered planes
+    kk, cnt, ssum = _Guarded(B * K * J * 4, dev), _Guarded(B * K * 4, dev), _Guarded(B * K * J * 8, dev)
+    lse, afx, grad = _Guarded(B * K * J * 4, dev), _Guarded(B * K * J * J * 8, dev), _Guarded(B * J * HW * 4, dev)
+    for z in (kk, cnt, ssum, afx):
+        z.body(torch.uint8).zero_()
+    Wk = W if seed % 2 else 0
+    _lib.check(lib.spx_kld_segment_max(cd.ptr, _lib.ptr(labels), B, J, HW, Wk, K, kk.ptr, cnt.ptr, s))
+    _lib.check(lib.spx_kld_segment_sumexp(cd.ptr, _lib.ptr(labels), B, J, HW, Wk, K, kk.ptr, ssum.ptr, s))
+    _lib.check(lib.spx_kld_segment_lse(kk.ptr, ssum.ptr, B * K * J, lse.ptr, s))
+    scale = torch.tensor([2.0 ** 30], dtype=torch.float64, device=dev)
+    _lib.check(lib.spx_kld_pair_sums(cd.ptr, _lib.ptr(labels), B, J, HW, Wk, K, lse.ptr, _lib.ptr(scale), afx.ptr, s))
+    A = torch.zeros(B, K, J, J, device=dev)
+    Cf = torch.rand(B, K, J, J, device=dev, generator=g)
+    _lib.check(lib.spx_kld_backward(cd.ptr, _lib.ptr(labels), B, J, HW, K, lse.ptr, _lib.ptr(A), _lib.ptr(Cf), grad.ptr, s))
+    # evaluation map: upsample the small map by a non-integer factor
+    Ho, Wo = int(rng.integers(H, 5 * H + 3)), int(rng.integers(W, 5 * W + 3))
+    src = torch.rand(B, P, H, W, device=dev, generator=g)
+    eidx, eval_ = _Guarded(B * Ho * Wo * 8, dev), _Guarded(B * Ho * Wo * 4, dev)
+    _lib.check(lib.spx_upsample_argext(_lib.ptr(src), B, P, H, W, Ho, Wo, 0, eidx.ptr, eval_.ptr, s))
+    torch.cuda.synchronize()
+    tag = f"B{B} S{S} Cs{Cs} P{P} K{K} J{J} {H}x{W} -> {Ho}x{Wo}"
+    for name, gb in (("class distances", cd), ("logits", logits), ("dX", dx), ("G blob", gs), ("a blob", as_), ("kld keys", kk),
+                     ("kld counts", cnt), ("kld sums", ssum), ("kld lse", lse), ("kld pair sums", afx), ("kld grad", grad),
+                     ("eval idx", eidx), ("eval val", eval_)):
+        assert gb.intact(), f"{name}: write outside the buffer ({tag})"
