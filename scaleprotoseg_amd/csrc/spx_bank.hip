@@ -33,7 +33,7 @@ size_t spx_bank_bwd_ws_floats(const spx_plan& pl, int nsplit) {
 }
 template <int NPB, int NCB>
 __host__ __device__ constexpr int spx_bk_lds_bytes() {
-    return 2 * (2 * NPB * 2 * 1024) + 256 * SPX_BK_ROW + 2 * NCB * 32 * SPX_BK_ROW;   // dLogits^T as (hi, lo) images
+    return 3 * (2 * NPB * 2 * 1024) + 256 * SPX_BK_ROW + 2 * NCB * 32 * SPX_BK_ROW;   // G, a as (hi, lo), X, dLogits^T as (hi, lo)
 }
 
 // DO_P / DO_W: which of the two products this instance carries.  One launch does both for small heads; for the
@@ -67,8 +67,9 @@ __global__ __launch_bounds__(SPX_BK_THREADS, 2) void spx_bank_bwd_kernel(const S
     constexpr int FBYTES = NFRAG * 1024;
 
     char* Gs = smem;                                  // G fragments, verbatim
-    char* As = Gs + FBYTES;                           // a fragments, verbatim
-    char* Xs = As + FBYTES;                           // [256][144 B]  X rows (rows >= Cs are zero)
+    char* As = Gs + FBYTES;                           // a fragments: bf16 high part of the fp16 blob (same lane order)
+    char* As2 = As + FBYTES;                          // ... and the bf16 residual (a = hi + lo exactly)
+    char* Xs = As2 + FBYTES;                          // [256][144 B]  X rows (rows >= Cs are zero)
     char* Ls = Xs + 256 * SPX_BK_ROW;                 // [NCB*32][144 B] dLogits^T, bf16 high part
     char* Ls2 = Ls + NCB * 32 * SPX_BK_ROW;           // ... and the bf16 residual: dLogits enters d_W as hi + lo (~2^-17)
 
@@ -163,7 +164,22 @@ __global__ __launch_bounds__(SPX_BK_THREADS, 2) void spx_bank_bwd_kernel(const S
             const int off = (i * SPX_BK_THREADS + tid) * 16;
             if (off < FBYTES) {
                 *(u32x4*)(Gs + off) = gr[i];
-                *(u32x4*)(As + off) = ar[i];
+                if (DO_W) {
+                    // the activation blob is fp16: split every element into bf16 hi + lo HERE, with the whole workgroup
+                    // and in the blob's own lane order (the split is elementwise), so the waves of the head product
+                    // only read fragments
+                    const f16x8 hv = __builtin_bit_cast(f16x8, ar[i]);
+                    bf16x8 ahi, alo;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        __bf16 hi, lo;
+                        split_bf16((float)hv[j], hi, lo);
+                        ahi[j] = hi;
+                        alo[j] = lo;
+                    }
+                    *(u32x4*)(As + off) = __builtin_bit_cast(u32x4, ahi);
+                    *(u32x4*)(As2 + off) = __builtin_bit_cast(u32x4, alo);
+                }
             }
         }
 #pragma unroll
@@ -250,19 +266,14 @@ __global__ __launch_bounds__(SPX_BK_THREADS, 2) void spx_bank_bwd_kernel(const S
             const int fo0 = spx_blob_slot(ra, tpp & 1, ts2) * 16 + 8 * (tpp >> 1);
             const int fo1 = spx_blob_slot(ra + 4, tpp & 1, ts2) * 16 + 8 * (tpp >> 1);
             const int fb = ((wsel * NPB + wave) * 2 + ts2) * 1024;
-            // the activation blob is fp16 (the transposed read only moves 16-bit elements): a = hi + lo exactly in two
-            // bf16, so d_W = (hi + lo) . (dl_hi + dl_lo) carries ~2^-12 of a's rounding instead of bf16's 2^-9
-            const f16x4 a0 = __builtin_bit_cast(f16x4, lds_tr_read(As + fb + fo0));
-            const f16x4 a1 = __builtin_bit_cast(f16x4, lds_tr_read(As + fb + fo1));
-            bf16x8 af, af2;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float v = (float)(j < 4 ? a0[j & 3] : a1[j & 3]);
-                __bf16 hi, lo;
-                split_bf16(v, hi, lo);
-                af[j] = hi;
-                af2[j] = lo;
-            }
+            // a = hi + lo (split at commit time): d_W = (hi + lo) . (dl_hi + dl_lo) carries ~2^-12 of a's fp16 rounding
+            // instead of bf16's 2^-9
+            const bf16x4 a0 = __builtin_bit_cast(bf16x4, lds_tr_read(As + fb + fo0));
+            const bf16x4 a1 = __builtin_bit_cast(bf16x4, lds_tr_read(As + fb + fo1));
+            const bf16x4 b0 = __builtin_bit_cast(bf16x4, lds_tr_read(As2 + fb + fo0));
+            const bf16x4 b1 = __builtin_bit_cast(bf16x4, lds_tr_read(As2 + fb + fo1));
+            const bf16x8 af = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+            const bf16x8 af2 = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb) {
                 const bf16x8 lf = *(const bf16x8*)(Ls + (cb * 32 + r) * SPX_BK_ROW + koff);
