@@ -179,16 +179,37 @@ class KLDLoss(nn.Module):
         self.scale_num_prototypes = scale_num_prototypes
         self.torch_formulation = torch_formulation
 
+    def _slot_table(self) -> torch.Tensor:
+        """class_slot_table of the loss's identity, built once per identity OBJECT and in-place version (a strong
+        reference is kept, so neither an id nor a device address can be recycled under the cache)."""
+        ident = self.prototype_class_identity
+        c = getattr(self, "_slot_table_cache", None)
+        if c is None or c[0] is not ident or c[1] != ident._version:
+            c = (ident, ident._version, class_slot_table(ident))
+            self._slot_table_cache = c
+        return c[2]
+
     def _pair_mask(self, table: torch.Tensor) -> torch.Tensor:
         """[K, J, J] bool: slots j < k of class c are prototypes of the same scale (loss.py:99-104, :118-121).
-        Cached per (table, scale table): it is host-side work with a device read-back, not something to redo per step."""
-        key = (table.data_ptr(), tuple(table.shape), str(table.device), tuple(sorted((int(s), tuple(r)) for s, r in self.scale_num_prototypes.items())))
+        Cached per (table object + its in-place version, scale table): it is host-side work with a device read-back,
+        not something to redo per step.  The cache holds the table itself, so the key cannot alias a recycled tensor."""
+        scales = tuple(sorted((int(s), tuple(r)) for s, r in self.scale_num_prototypes.items()))
         cached = getattr(self, "_pair_mask_cache", None)
-        if cached is not None and cached[0] == key:
-            return cached[1]
+        if cached is not None and cached[0] is table and cached[1] == (table._version, scales):
+            return cached[2]
         mask = self._pair_mask_build(table).to(table.device)
-        self._pair_mask_cache = (key, mask)
+        self._pair_mask_cache = (table, (table._version, scales), mask)
         return mask
+
+    def _table_on(self, table: torch.Tensor, dev) -> torch.Tensor:
+        """``table`` on ``dev`` (the same object every step, so the pair-mask cache keyed on it holds)."""
+        if table.device == dev:
+            return table
+        c = getattr(self, "_table_dev_cache", None)
+        if c is None or c[0] is not table or c[1] != (table._version, str(dev)):
+            c = (table, (table._version, str(dev)), table.to(dev))
+            self._table_dev_cache = c
+        return c[2]
 
     def _pair_mask_build(self, table: torch.Tensor) -> torch.Tensor:
         K, J = table.shape
@@ -207,7 +228,7 @@ class KLDLoss(nn.Module):
             table = prototype_distances.table
             vals = prototype_distances.values.permute(0, 2, 1)          # [B, H*W, J] view
         else:
-            table = class_slot_table(self.prototype_class_identity)
+            table = self._slot_table()
             vals = gather_class_distances(prototype_distances, labels0, table)
         planes = prototype_distances.values if isinstance(prototype_distances, ClassDistances) else None
         width = prototype_distances.grid[-1] if isinstance(prototype_distances, ClassDistances) else prototype_distances.shape[-1]
@@ -217,7 +238,7 @@ class KLDLoss(nn.Module):
         """Loss from the class-gathered values ``vals`` [B, H*W, J] (``planes``: the same as [B, J, H*W], if the caller
         already holds that layout; ``width``: W of the pixel grid if known, a traversal hint for the kernels)."""
         dev = vals.device
-        table = table.to(dev)
+        table = self._table_on(table, dev)
         K, J = table.shape
         B = vals.shape[0]
         lab = labels0.to(dev)
@@ -333,10 +354,10 @@ class KLDLossGroup(KLDLoss):
 
     def _pair_mask(self, table: torch.Tensor) -> torch.Tensor:
         cached = getattr(self, "_pair_mask_cache", None)
-        if cached is None or cached[0] != str(table.device):
-            cached = (str(table.device), self._pair_mask_build(table).to(table.device))
+        if cached is None or cached[0] is not table or cached[1] != table._version:
+            cached = (table, table._version, self._pair_mask_build(table).to(table.device))
             self._pair_mask_cache = cached
-        return cached[1]
+        return cached[2]
 
     def forward(self, list_group_activation, target_labels: torch.Tensor) -> torch.Tensor:
         G = self.num_groups

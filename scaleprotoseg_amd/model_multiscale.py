@@ -61,6 +61,15 @@ def _build_add_on(kind: str, in_ch: int, proto_ch: int, bottleneck_stride: Optio
 class _PrototypeBankMixin:
     """State and helpers shared by the prototype-phase and group-phase modules."""
 
+    _tables_version = 0
+
+    def __setattr__(self, name, value):
+        # prototype_class_identity / scale_num_prototypes are plain attributes that callers re-assign
+        # (finetune_wandb_group.py:77-78, prune_prototypes): every derived cache is keyed on this counter
+        if name in ("prototype_class_identity", "scale_num_prototypes"):
+            object.__setattr__(self, "_tables_version", self._tables_version + 1)
+        super().__setattr__(name, value)
+
     def _init_bank(self, prototype_shape, num_classes: int, num_scales: int):
         self.epsilon = 1e-4  # model_multiscale.py:106
         self.num_scales = num_scales
@@ -104,14 +113,15 @@ class _PrototypeBankMixin:
     def _class_gather(self, target_labels: torch.Tensor, layout: BankLayout, device) -> ClassGather:
         """Kernel-side description of 'only my class's prototypes' for labels in the reference's convention
         (0 = void, 1..K = class; module_multiscale.py:234-242, loss.py:73).  The (class, slot) table is cached
-        until prototype_class_identity is re-assigned (prune_prototypes) or the scale table changes."""
+        until prototype_class_identity is re-assigned (prune_prototypes, attribute assignment), edited in place
+        (tensor version counter) or the scale table changes."""
         ident = self.prototype_class_identity
-        tag = (id(ident), tuple(ident.shape), layout.scale_ranges, str(device))
+        tag = (self._tables_version, ident._version, layout.scale_ranges, str(device))
         cache = getattr(self, "_gather_cache", None)
-        if cache is None or cache[0] != tag:
-            cache = (tag, class_gather_table(layout, ident, device))
+        if cache is None or cache[0] is not ident or cache[1] != tag:
+            cache = (ident, tag, class_gather_table(layout, ident, device))      # holds ident: its id cannot be recycled
             self._gather_cache = cache
-        keys, width, table = cache[1]
+        keys, width, table = cache[2]
         B = target_labels.shape[0]
         labels0 = (target_labels.reshape(B, -1).to(device=device, dtype=torch.int32) - 1).contiguous()
         return ClassGather(labels=labels0, keys=keys, width=width, table=table)
@@ -121,6 +131,23 @@ class _PrototypeBankMixin:
             raise SpxError("scale_head aggregation has no fused kernel (every reference config sets scale_head_type=None)")
         if self.prototype_vectors.shape[2] != 1 or self.prototype_vectors.shape[3] != 1:
             raise SpxError("only 1x1 prototypes are supported (all reference configs)")
+
+    def _prune_bank(self, prototypes_to_prune) -> List[int]:
+        """The bank half of ``prune_prototypes`` (model_multiscale.py:400-423, :428-432): shrinks ``prototype_vectors``,
+        ``ones`` and ``prototype_class_identity`` to the kept rows and re-packs ``scale_num_prototypes``.  Returns the
+        kept indices (ascending).  The parameters are re-created, as upstream (optimizers holding the old ones go stale)."""
+        drop = set(int(i) for i in prototypes_to_prune)
+        keep = sorted(set(range(self.num_prototypes)) - drop)
+        prev_hi = 0
+        for s in range(self.num_scales):
+            lo, hi = self.scale_num_prototypes[s]
+            n = len(set(range(lo, hi)) - drop)
+            self.scale_num_prototypes[s] = (prev_hi, prev_hi + n)
+            prev_hi += n
+        self.prototype_vectors = nn.Parameter(self.prototype_vectors.data[keep, ...], requires_grad=True)
+        self.ones = nn.Parameter(self.ones.data[keep, ...], requires_grad=False)
+        self.prototype_class_identity = self.prototype_class_identity[keep, :]      # bumps _tables_version
+        return keep
 
     # -- reference methods on the distance path ---------------------------------------------------
     def conv_features(self, x):
@@ -241,20 +268,10 @@ class PPNetMultiScale(_PrototypeBankMixin, nn.Module):
 
     def prune_prototypes(self, prototypes_to_prune: List[int]):
         """Drop prototype rows and re-pack the scale table (model_multiscale.py:400-432)."""
-        drop = set(int(i) for i in prototypes_to_prune)
-        keep = sorted(set(range(self.num_prototypes)) - drop)
-        prev_hi = 0
-        for s in range(self.num_scales):
-            lo, hi = self.scale_num_prototypes[s]
-            n = len(set(range(lo, hi)) - drop)
-            self.scale_num_prototypes[s] = (prev_hi, prev_hi + n)
-            prev_hi += n
-        self.prototype_vectors = nn.Parameter(self.prototype_vectors.data[keep, ...], requires_grad=True)
+        keep = self._prune_bank(prototypes_to_prune)
         self.last_layer.in_features = self.num_prototypes
         self.last_layer.out_features = self.num_classes
         self.last_layer.weight.data = self.last_layer.weight.data[:, keep]
-        self.ones = nn.Parameter(self.ones.data[keep, ...], requires_grad=False)
-        self.prototype_class_identity = self.prototype_class_identity[keep, :]
 
     def set_last_layer_incorrect_connection(self, incorrect_strength: float):
         """+1 own class / incorrect_strength elsewhere (model_multiscale.py:449-464)."""

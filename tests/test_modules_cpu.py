@@ -210,6 +210,68 @@ def test_reference_state_dict_after_push_dedup(tmp_path, golden):
     assert dst2.scale_num_prototypes == {s: tuple(int(v) for v in g["prune_after_ranges"][s]) for s in range(S)}
 
 
+def test_pruned_prototype_checkpoint_loads_into_the_group_module(tmp_path, golden):
+    """finetune_wandb_group.py:74-80 hand-over after a push: a de-duplicated prototype-phase state_dict +
+    unique_prototypes.json loads into the group-phase module; projection shapes and group_class_identity follow the
+    pruned class table."""
+    import json
+    from scaleprotoseg_amd.checkpoint import export_state, import_state, load_reference_state_dict
+    from scaleprotoseg_amd.model_multiscale_group import PPNetMultiScale as GroupNet
+
+    g = golden("misc")
+    P, S, K = int(g["prune_P"]), int(g["prune_S"]), int(g["prune_K"])
+    drop = [int(i) for i in g["prune_drop"]]
+    src = _proto(P, 8, S, K)
+    with torch.no_grad():
+        src.prototype_vectors.copy_(torch.from_numpy(g["prune_before_protos"]))
+    src.prune_prototypes(drop)
+    keep = sorted(set(range(P)) - set(drop))
+    path = tmp_path / "unique_prototypes.json"
+    path.write_text(json.dumps(keep))
+
+    def fresh():
+        return GroupNet(_Backbone(8 * S), 64, (P, 8, 1, 1), [], K, add_on_layers_type="deeplab_simple",
+                        patch_classification=True, num_scales=S, num_groups=3)
+
+    dst = fresh()
+    res = load_reference_state_dict(dst, src.state_dict(), unique_prototypes=str(path))
+    assert list(res.unexpected_keys) == ["last_layer.weight"]
+    np.testing.assert_array_equal(dst.prototype_vectors.detach().numpy(), g["prune_after_protos"])
+    np.testing.assert_array_equal(dst.prototype_class_identity.numpy(), g["prune_after_identity"])
+    assert [tuple(dst.scale_num_prototypes[s]) for s in range(S)] == [tuple(r) for r in g["prune_after_ranges"]]
+    ident = torch.from_numpy(g["prune_after_identity"])
+    present = [k for k in range(K) if ident[:, k].sum() > 0]
+    assert [tuple(gp.weight.shape) for gp in dst.group_projection] == [(3, int(ident[:, k].sum())) for k in present]
+    assert tuple(dst.group_class_identity.shape) == (3 * len(present), K)
+    assert tuple(dst.last_layer_group.weight.shape) == (K, 3 * len(present))
+    allowed = torch.cat([ident[:, k].bool().unsqueeze(0).expand(3, -1) for k in present])
+    assert not ((dst._dense_group_matrix() != 0) & ~allowed).any()     # dense head: weights only on own-class columns
+    dst2 = fresh()
+    import_state(dst2, export_state(src))
+    np.testing.assert_array_equal(dst2.prototype_class_identity.numpy(), g["prune_after_identity"])
+    assert [tuple(gp.weight.shape) for gp in dst2.group_projection] == [tuple(gp.weight.shape) for gp in dst.group_projection]
+
+
+def test_table_caches_follow_in_place_edits_and_reassignment():
+    """The (class, slot) gather table and the dense grouping index are keyed on the identity OBJECT, its in-place
+    version and the module's table counter: an in-place edit or a re-assignment invalidates them."""
+    from scaleprotoseg_amd.model_multiscale_group import PPNetMultiScale as GroupNet
+
+    net = GroupNet(_Backbone(32), 64, (12, 8, 1, 1), [], 3, add_on_layers_type="deeplab_simple",
+                   patch_classification=True, num_scales=4, num_groups=2)
+    r0, c0, n0 = net._group_index("cpu")
+    assert net._group_index("cpu")[0] is r0                      # cached
+    v = net._tables_version
+    net.prototype_class_identity = net.prototype_class_identity.clone()
+    assert net._tables_version == v + 1
+    assert net._group_index("cpu")[0] is not r0                  # re-assignment: rebuilt
+    r1 = net._group_index("cpu")[0]
+    net.prototype_class_identity[0, 0] = 0                       # in-place edit: tensor version moves
+    net.prototype_class_identity[0, 1] = 1
+    r2, c2, _ = net._group_index("cpu")
+    assert r2 is not r1 and not torch.equal(c2, c0)
+
+
 def test_cross_entropy_matches_reference(golden):
     from scaleprotoseg_amd.loss import PixelWiseCrossEntropyLoss
 
