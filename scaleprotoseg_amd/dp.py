@@ -18,6 +18,29 @@ import torch
 import torch.distributed as dist
 
 
+def _all_reduce_sum(t: torch.Tensor, group=None) -> None:
+    """In-place sum all-reduce.  RCCL ("nccl") reduces device tensors directly; under the gloo rehearsal backend a
+    device tensor is staged through the host (gloo's device-tensor support depends on the build)."""
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        h = t.detach().cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+
+
+def _all_gather(t: torch.Tensor, group=None) -> List[torch.Tensor]:
+    world = dist.get_world_size(group)
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        h = t.detach().cpu()
+        out = [torch.empty_like(h) for _ in range(world)]
+        dist.all_gather(out, h, group=group)
+        return [o.to(t.device) for o in out]
+    out = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(out, t, group=group)
+    return out
+
+
 def shard_range(n_items: int, rank: int, world_size: int) -> range:
     """Contiguous, balanced shard of ``range(n_items)`` for ``rank``."""
     base, rem = divmod(n_items, world_size)
@@ -59,7 +82,7 @@ class FlatGradBucket:
         """Sum (or mean) the bucket over the ranks with one collective and write the grads back."""
         self.gather()
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+            _all_reduce_sum(self.flat, group)
             if average:
                 self.flat.div_(dist.get_world_size(group))
         self.scatter()
@@ -91,9 +114,7 @@ def reduce_push_candidates(
     # pack to one int64 triple per prototype so a single all_gather moves everything (values via bit cast)
     vbits = local_values.to(torch.float32).contiguous().view(torch.int32).to(torch.int64)
     payload = torch.stack([vbits, gimg, local_flat_idx.to(torch.int64)], dim=0).contiguous()
-    gathered = [torch.empty_like(payload) for _ in range(world)]
-    dist.all_gather(gathered, payload, group=group)
-    allp = torch.stack(gathered, dim=0)                      # [world, 3, P]
+    allp = torch.stack(_all_gather(payload, group), dim=0)   # [world, 3, P]
     vals = allp[:, 0].to(torch.int32).view(torch.float32)    # [world, P]
     imgs = allp[:, 1]
     flats = allp[:, 2]
@@ -112,5 +133,45 @@ def gather_push_patches(local_patches: torch.Tensor, owner_mask: torch.Tensor, g
     all-reduce assembles the full bank (exact: every row has exactly one non-zero contributor)."""
     out = torch.where(owner_mask[:, None], local_patches, torch.zeros_like(local_patches)).contiguous()
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(out, op=dist.ReduceOp.SUM, group=group)
+        _all_reduce_sum(out, group)
     return out
+
+
+class DataParallelStep:
+    """Minimal data-parallel optimizer step for the prototype path: every rank runs forward + backward
+    on its own images, the parameter gradients are averaged with ONE all-reduce of a flat bucket after the ``iter_size``
+    accumulation window, then every rank applies the same optimizer step and - in the group phase - the same simplex
+    re-projection of the group projections (segmentation/model/module_multiscale_group_train.py:323-338:
+    ``manual_backward(loss / iter_size)``, ``optimizer.step()``, ``projection_simplex_sort`` per projection).
+    Kernels, all-reduce order and the update are deterministic, so replicas stay bit-identical.
+
+    Gradient semantics: the mean over ranks of per-rank gradients, i.e. the gradient of the mean of the per-rank losses
+    (equal to the single-process loss over the union batch when each rank's loss is a mean over equally many terms)."""
+
+    def __init__(self, net: torch.nn.Module, optimizer: torch.optim.Optimizer, iter_size: int = 1, group=None):
+        self.net = net
+        self.optimizer = optimizer
+        self.iter_size = int(iter_size)
+        self.group = group
+        self.iter_steps = 0
+        params = [p for g in optimizer.param_groups for p in g["params"]]
+        self.bucket = FlatGradBucket(params)
+
+    def backward(self, loss: torch.Tensor) -> bool:
+        """Accumulate ``loss / iter_size``; at the end of the window all-reduce, step and re-project.  Returns True when
+        the optimizer stepped."""
+        (loss / self.iter_size).backward()
+        self.iter_steps += 1
+        if self.iter_steps < self.iter_size:
+            return False
+        self.iter_steps = 0
+        self.bucket.all_reduce(group=self.group, average=True)
+        self.optimizer.step()
+        projections = getattr(self.net, "group_projection", None)
+        if projections is not None:
+            from .utils import projection_simplex_sort
+
+            for gp in projections:
+                gp.weight.data = projection_simplex_sort(gp.weight.data)
+        self.optimizer.zero_grad(set_to_none=True)
+        return True

@@ -73,26 +73,17 @@ def min_across_dataset(
     return argmin_over_images(tot), list_idx
 
 
-@torch.no_grad()
-def global_min(
-    proto_min_dist: torch.Tensor,
-    list_min_patch: Sequence[torch.Tensor],
-    dataset,
-    ppnet,
-    device: Optional[str] = None,
-    image_offset: int = 0,
-) -> List[np.ndarray]:
-    """Feature vector [Cs,1,1] of every prototype's winning latent pixel (push_multiscale_optimization.py:140-190).
-
-    The reference re-runs the backbone once per prototype; here each winning image is encoded once
-     and the P vectors are gathered on the GPU."""
-    device = device or str(ppnet.prototype_vectors.device)
+def _winning_patches(best: Sequence[int], list_min_patch, dataset, ppnet, device, image_offset: int = 0,
+                     only: Optional[Sequence[bool]] = None) -> torch.Tensor:
+    """[P, Cs] feature vectors of the winning latent pixels (rows outside ``only`` stay zero).  Each winning image is
+    encoded once, the reference re-runs the backbone once per prototype."""
     P, S = ppnet.num_prototypes, ppnet.num_scales
     per_scale = P // S
-    best = proto_min_dist.tolist()
     conv_cache: Dict[int, torch.Tensor] = {}
-    out = []
+    out = None
     for p in range(P):
+        if only is not None and not bool(only[p]):
+            continue
         s = p // per_scale
         i = int(best[p])
         if i not in conv_cache:
@@ -104,8 +95,28 @@ def global_min(
         cv = conv.view(S, C // S, H, W)
         flat = int(list_min_patch[i][:, p].item())
         r, c = flat // W, flat % W
-        out.append(cv[s, :, r : r + 1, c : c + 1].detach().float().cpu().numpy())
+        if out is None:
+            out = torch.zeros((P, C // S), dtype=torch.float32, device=conv.device)
+        out[p] = cv[s, :, r, c].detach().float()
+    if out is None:
+        cs = int(ppnet.prototype_shape[1])
+        out = torch.zeros((P, cs), dtype=torch.float32, device=device)
     return out
+
+
+@torch.no_grad()
+def global_min(
+    proto_min_dist: torch.Tensor,
+    list_min_patch: Sequence[torch.Tensor],
+    dataset,
+    ppnet,
+    device: Optional[str] = None,
+    image_offset: int = 0,
+) -> List[np.ndarray]:
+    """Feature vector [Cs,1,1] of every prototype's winning latent pixel (push_multiscale_optimization.py:140-190)."""
+    device = device or str(ppnet.prototype_vectors.device)
+    rows = _winning_patches(proto_min_dist.tolist(), list_min_patch, dataset, ppnet, device, image_offset).cpu().numpy()
+    return [rows[p].reshape(-1, 1, 1) for p in range(rows.shape[0])]
 
 
 def commit_push(ppnet, patches: Sequence[np.ndarray], root_dir: Optional[os.PathLike] = None, log: Callable = print):
@@ -126,15 +137,34 @@ def commit_push(ppnet, patches: Sequence[np.ndarray], root_dir: Optional[os.Path
     return dup
 
 
+def _dp_world(group) -> Tuple[int, int]:
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(group), dist.get_world_size(group)
+    return 0, 1
+
+
 def push_prototypes_multiscale(
     dataset,
     prototype_network_parallel,
     root_dir_for_saving_prototypes: Optional[os.PathLike] = None,
     log: Callable = print,
     device: Optional[str] = None,
+    group=None,
     **_ignored,
 ):
-    """Numerical part of push_multiscale_optimization.py:193-338 (plot/file-dump arguments are accepted and ignored)."""
+    """Numerical part of push_multiscale_optimization.py:193-338 (plot/file-dump arguments are accepted and ignored).
+
+    Data-parallel form (SURVEY.md 8e "Push"; new capability, the reference is single-process): when
+    ``torch.distributed`` is initialised with more than one rank, every rank scans a contiguous shard of the image list
+    (``dp.shard_range``), the per-prototype winners are combined with one all-gather and a lexicographic minimum on
+    (value, global image index) - the reference's lowest-image tie-break (:137) - the winning feature vectors are
+    assembled with one sum all-reduce (each row has exactly one contributor), and EVERY rank commits the same bank,
+    de-dup and pruning; rank 0 alone writes ``unique_prototypes.json``.  Returns (best image per prototype [P] as GLOBAL
+    image indices, the local shard's per-image flat indices, dropped duplicates)."""
+    from . import dp
+
     net = prototype_network_parallel
     if hasattr(net, "module"):
         net = net.module
@@ -142,8 +172,36 @@ def push_prototypes_multiscale(
     log("\tpush")
     start = time.time()
     num_classes = net.num_classes
-    best, tot_idx = min_across_dataset(dataset, net, num_classes, void_class=0, device=device)
-    patches = global_min(best, tot_idx, dataset, net, device=device)
-    dup = commit_push(net, patches, root_dir_for_saving_prototypes, log=log)
+    device = device or str(net.prototype_vectors.device)
+    rank, world = _dp_world(group)
+    if world == 1:
+        best, tot_idx = min_across_dataset(dataset, net, num_classes, void_class=0, device=device)
+        patches = global_min(best, tot_idx, dataset, net, device=device)
+        dup = commit_push(net, patches, root_dir_for_saving_prototypes, log=log)
+        log("\tpush time: \t{0}".format(time.time() - start))
+        return best, tot_idx, dup
+
+    P = net.num_prototypes
+    rng = dp.shard_range(len(dataset), rank, world)
+    dev = torch.device(device)
+    ar = torch.arange(P, device=dev)
+    if len(rng) > 0:
+        best_local, tot_idx = min_across_dataset(dataset, net, num_classes, void_class=0, device=device, image_range=rng)
+        tot_val = min_across_dataset.last_values                       # [n_local, P]
+        local_val = tot_val[best_local, ar]
+        local_flat = torch.cat(list(tot_idx), dim=0)[best_local, ar]
+    else:                                                              # more ranks than images: this rank never wins
+        best_local = torch.zeros(P, dtype=torch.int64, device=dev)
+        tot_idx = []
+        local_val = torch.full((P,), float("inf"), dtype=torch.float32, device=dev)
+        local_flat = torch.zeros(P, dtype=torch.int64, device=dev)
+    gimg, _, gflat = dp.reduce_push_candidates(best_local, local_val, local_flat, rng.start, group=group)
+    owner = (gimg >= rng.start) & (gimg < rng.stop)
+    with torch.no_grad():
+        local = _winning_patches((gimg - rng.start).tolist(), tot_idx, dataset, net, device, image_offset=rng.start,
+                                 only=owner.tolist())
+    full = dp.gather_push_patches(local, owner, group=group)           # [P, Cs], identical on every rank
+    patches = full.cpu().numpy().reshape(tuple(net.prototype_shape))
+    dup = commit_push(net, patches, root_dir_for_saving_prototypes if rank == 0 else None, log=log)
     log("\tpush time: \t{0}".format(time.time() - start))
-    return best, tot_idx, dup
+    return gimg, tot_idx, dup

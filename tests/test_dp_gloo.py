@@ -115,3 +115,147 @@ def test_shard_range_covers_everything():
             assert got == list(range(n))
             sizes = [len(shard_range(n, r, w)) for r in range(w)]
             assert max(sizes) - min(sizes) <= 1
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the data-parallel push DRIVER and the data-parallel optimizer step (composition logic; the kernels are replaced by
+# the CPU oracle here - the same drivers run on the real kernels in tests/test_gpu_dp.py)
+# ---------------------------------------------------------------------------------------------------------------
+class _Backbone(torch.nn.Module):
+    def __init__(self, ch):
+        super().__init__()
+        self.base = torch.nn.Sequential(torch.nn.Conv2d(3, ch, 1), torch.nn.Conv2d(ch, ch, 1))
+        self.pool = torch.nn.AvgPool2d(4)
+
+    def __repr__(self):
+        return "MSC(standin)"
+
+    def forward(self, x):
+        return self.base(self.pool(x))
+
+
+class _PushData:
+    convert_targets = None
+
+    def __init__(self, n, K, absent, seed):
+        g = torch.Generator().manual_seed(seed)
+        self.items = []
+        for _ in range(n):
+            img = torch.randn(3, 24, 32, generator=g)
+            t = torch.randint(0, K + 1, (3, 4), generator=g).repeat_interleave(8, 0).repeat_interleave(8, 1)
+            t[t == absent + 1] = 0
+            self.items.append((img, t.numpy()))
+
+    def __len__(self):
+        return len(self.items)
+
+    def __getitem__(self, i):
+        return self.items[i]
+
+
+def _push_setup():
+    import scaleprotoseg_amd as spx
+
+    S, Cs, K, per = 2, 16, 3, 2
+    P = S * K * per
+    torch.manual_seed(11)
+    net = spx.PPNetMultiScale(_Backbone(S * Cs), 64, (P, Cs, 1, 1), [], K, add_on_layers_type="deeplab_simple",
+                              patch_classification=True, num_scales=S)
+    with torch.no_grad():
+        net.prototype_vectors[1].copy_(net.prototype_vectors[0])      # forced duplicate
+    return net, _PushData(7, K, absent=2, seed=12), S, K
+
+
+def _patch_kernels_with_oracle(S):
+    """compute_distances / argmin_over_images on the CPU oracle (tests may use it; the product path never does)."""
+    from oracle import ppnet_oracle as O
+    from scaleprotoseg_amd import push as push_mod
+
+    def compute_distances(ppnet, dataset, img, target, num_classes, max_dist=1e10, device=None, void_class=None):
+        conv = ppnet.conv_features(img.unsqueeze(0))
+        ranges = {s: tuple(ppnet.scale_num_prototypes[s]) for s in range(S)}
+        d = O.scale_l2_convolution(conv, ppnet.prototype_vectors.detach(), ranges, S)
+        lab = O.resize_label(target, (d.shape[3], d.shape[2])).unsqueeze(0)
+        return O.push_masked_argmin(d, lab, ppnet.prototype_class_identity, num_classes, max_dist, void_class)
+
+    push_mod.compute_distances = compute_distances
+    push_mod.argmin_over_images = lambda v: v.argmin(dim=0)
+
+
+def _dp_push_case(rank, world):
+    from scaleprotoseg_amd.push import push_prototypes_multiscale
+
+    net, data, S, K = _push_setup()
+    _patch_kernels_with_oracle(S)
+    best, _, dup = push_prototypes_multiscale(data, net, log=lambda *_: None, device="cpu")
+    return (net.prototype_vectors.detach().clone(), best.clone(), list(dup),
+            {s: tuple(net.scale_num_prototypes[s]) for s in range(S)}, net.last_layer.weight.detach().clone())
+
+
+def test_data_parallel_push_driver_equals_single_process(tmp_path):
+    from scaleprotoseg_amd.push import push_prototypes_multiscale
+
+    res = _run(_dp_push_case, tmp_path)
+    net, data, S, K = _push_setup()
+    _patch_kernels_with_oracle(S)
+    best, _, dup = push_prototypes_multiscale(data, net, log=lambda *_: None, device="cpu")    # world = 1 here
+    assert 1 in dup and len(dup) >= 2                    # forced duplicate + the absent class's prototypes per scale
+    for bank, gbest, gdup, ranges, wl in res:
+        assert torch.equal(bank, net.prototype_vectors.detach())        # bit-identical bank on every rank
+        assert torch.equal(gbest, best) and gdup == list(dup)
+        assert ranges == {s: tuple(net.scale_num_prototypes[s]) for s in range(S)}
+        assert torch.equal(wl, net.last_layer.weight.detach())
+
+
+class _TinyGroupModel(torch.nn.Module):
+    """Parameters with the group phase's names and shapes; the 'loss' is a smooth function of them and of rank-local data."""
+
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(3)
+        self.prototype_vectors = torch.nn.Parameter(torch.rand(12, 8, 1, 1))
+        self.group_projection = torch.nn.ModuleList([torch.nn.Linear(4, 3, bias=False) for _ in range(3)])
+        self.last_layer_group = torch.nn.Linear(9, 3, bias=False)
+
+    def loss(self, x):
+        act = torch.exp(-torch.cdist(x, self.prototype_vectors.flatten(1)))
+        groups = [torch.exp(gp(act[:, 4 * i:4 * i + 4])) for i, gp in enumerate(self.group_projection)]
+        return (self.last_layer_group(torch.cat(groups, 1)) ** 2).mean()
+
+
+def _dp_step_case(rank, world):
+    from scaleprotoseg_amd.dp import DataParallelStep
+
+    m = _TinyGroupModel()
+    opt = torch.optim.Adam(m.parameters(), lr=1e-2)
+    stepper = DataParallelStep(m, opt, iter_size=2)
+    g = torch.Generator().manual_seed(50 + rank)
+    stepped = []
+    for it in range(6):                                   # 3 optimizer steps of 2 accumulation micro-steps
+        stepped.append(stepper.backward(m.loss(torch.rand(5, 8, generator=g))))
+    return [p.detach().clone() for p in m.parameters()], stepped
+
+
+def test_data_parallel_step_keeps_replicas_bit_identical(tmp_path):
+    from scaleprotoseg_amd.utils import projection_simplex_sort
+
+    res = _run(_dp_step_case, tmp_path)
+    (p0, s0), (p1, s1) = res
+    assert s0 == s1 == [False, True] * 3
+    assert all(torch.equal(a, b) for a, b in zip(p0, p1))               # replicas bit-identical after 3 steps
+    # single-process restatement: the gradient of the mean of the per-rank losses, same Adam, same re-projection
+    m = _TinyGroupModel()
+    opt = torch.optim.Adam(m.parameters(), lr=1e-2)
+    gens = [torch.Generator().manual_seed(50 + r) for r in range(2)]
+    for it in range(3):
+        opt.zero_grad(set_to_none=True)
+        micro = [[torch.rand(5, 8, generator=g) for g in gens] for _ in range(2)]
+        loss = sum(m.loss(x) for pair in micro for x in pair) / 4.0
+        loss.backward()
+        opt.step()
+        for gp in m.group_projection:
+            gp.weight.data = projection_simplex_sort(gp.weight.data)
+    for a, b in zip(p0, m.parameters()):
+        assert torch.allclose(a, b.detach(), rtol=1e-5, atol=1e-7)
+    for gp_w in p0[1:4]:
+        assert (gp_w >= 0).all() and torch.allclose(gp_w.sum(1), torch.ones(3), atol=1e-5)    # rows on the simplex
