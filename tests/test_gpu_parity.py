@@ -1028,3 +1028,91 @@ def test_no_write_outside_the_output_buffers_extended_ops(seed):
                      ("kld counts", cnt), ("kld sums", ssum), ("kld lse", lse), ("kld pair sums", afx), ("kld grad", grad),
                      ("eval idx", eidx), ("eval val", eval_)):
         assert gb.intact(), f"{name}: write outside the buffer ({tag})"
+
+
+def _graph_problem(dev):
+    from scaleprotoseg_amd.functional import BankLayout
+
+    B, S, Cs, P, K, H, W = 2, 4, 64, 228, 19, 33, 33
+    g = torch.Generator().manual_seed(31)
+    x = torch.sigmoid(torch.randn(B, S * Cs, H, W, generator=g)).to(dev, torch.bfloat16).requires_grad_(True)
+    bank = torch.rand(P, Cs, 1, 1, generator=g).to(dev).requires_grad_(True)
+    head = (torch.randn(K, P, generator=g) * 0.1).to(dev).requires_grad_(True)
+    per = P // S
+    lay = BankLayout(P, K, S, Cs, tuple((s * per, (s + 1) * per) for s in range(S)))
+    gl = (torch.randn(B * H * W, K, generator=g) * 1e-3).to(dev)
+    gd = (torch.randn(B, P, H, W, generator=g) * 1e-3).to(dev)
+    return x, bank, head, lay, gl, gd
+
+
+def test_hip_graph_capture_replay():
+    """The whole step (packs, forward, K1, K2, K3, .grad accumulation) captured into a HIP graph replays bit-identically,
+    also after the static inputs were refilled in place.  Round 1's capture_end segfault (gpurun_out/seg.log) was the
+    legacy default stream being pulled into the capture by AccumulateGrad nodes of a still-alive eager graph - stock
+    torch ops alone reproduce it (tools/probes/capture_repro.py); capture_step captures on one side stream and refuses
+    to start with such a graph alive."""
+    from scaleprotoseg_amd.functional import proto_head_forward
+    from scaleprotoseg_amd.graphs import capture_step
+
+    dev = _dev()
+    x, bank, head, lay, gl, gd = _graph_problem(dev)
+    leaves = (x, bank, head)
+
+    def step():
+        for t in leaves:
+            t.grad = None
+        logits, d, _ = proto_head_forward(x, bank, head, lay)
+        torch.autograd.backward([logits, d], [gl, gd])
+        return logits.detach(), d.detach()
+
+    def eager():
+        lo, di = step()
+        res = [lo.clone(), di.clone()] + [t.grad.clone() for t in leaves]
+        for t in leaves:
+            t.grad = None
+        return res
+
+    ref = eager()
+    # nothing of the eager graph is kept alive: step() returns detached tensors and eager() drops the grads
+    graph, (lo, di) = capture_step(step, warmup=2)
+    for t in leaves:
+        t.grad.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    got = [lo, di] + [t.grad for t in leaves]
+    assert all(torch.equal(a, b) for a, b in zip(got, ref))
+    # new data in the static buffers: replay == eager on the new data
+    with torch.no_grad():
+        x.copy_(torch.sigmoid(torch.randn_like(x, dtype=torch.float32)).to(x.dtype))
+        bank.mul_(0.5)
+    graph.replay()
+    torch.cuda.synchronize()
+    got = [t.clone() for t in [lo, di] + [t.grad for t in leaves]]
+    del graph
+    ref2 = eager()
+    assert all(torch.equal(a, b) for a, b in zip(got, ref2))
+
+
+def test_capture_step_refuses_a_stale_default_stream_graph():
+    """With an eager graph (default stream) alive, capture_step raises before any capture begins instead of letting
+    hipStreamEndCapture crash the process."""
+    from scaleprotoseg_amd import SpxError
+    from scaleprotoseg_amd.functional import proto_head_forward
+    from scaleprotoseg_amd.graphs import capture_step
+
+    dev = _dev()
+    x, bank, head, lay, gl, gd = _graph_problem(dev)
+
+    def step():
+        for t in (x, bank, head):
+            t.grad = None
+        logits, d, _ = proto_head_forward(x, bank, head, lay)
+        torch.autograd.backward([logits, d], [gl, gd])
+
+    keep = proto_head_forward(x, bank, head, lay)        # eager graph on the default stream, kept alive
+    with pytest.raises(SpxError, match="still alive"):
+        capture_step(step, warmup=1)
+    del keep
+    graph, _ = capture_step(step, warmup=1)              # and with the graph gone the same step captures
+    graph.replay()
+    torch.cuda.synchronize()
