@@ -31,9 +31,13 @@ int spx_bank_bwd_nsplit(const spx_plan& pl, int B, int HW) {
 size_t spx_bank_bwd_ws_floats(const spx_plan& pl, int nsplit) {
     return (size_t)nsplit * pl.npanels * pl.npb * 32 * spx_bk_wstride(pl);
 }
-template <int NPB, int NCB>
+// LDS carve: [G hi | G lo | X] (d_bank instances) then [a hi | a lo | dLogits^T hi | dLogits^T lo] (d_W instances)
+template <int NPB, int NCB, bool DO_P, bool DO_W>
 __host__ __device__ constexpr int spx_bk_lds_bytes() {
-    return 3 * (2 * NPB * 2 * 1024) + 256 * SPX_BK_ROW + 2 * NCB * 32 * SPX_BK_ROW;   // G, a as (hi, lo), X, dLogits^T as (hi, lo)
+    constexpr int fb = 2 * NPB * 2 * 1024;
+    constexpr int red = (2 * 3 * 2 * 1024 + 2 * 3 * 64) * 4;          // the k-step-split reduction re-uses the staging area
+    constexpr int n = (DO_P ? 2 * fb + 256 * SPX_BK_ROW : 0) + (DO_W ? 2 * fb + 2 * NCB * 32 * SPX_BK_ROW : 0);
+    return n > red ? n : red;
 }
 
 // DO_P / DO_W: which of the two products this instance carries.  One launch does both for small heads; for the
@@ -66,11 +70,14 @@ __global__ __launch_bounds__(SPX_BK_THREADS, 2) void spx_bank_bwd_kernel(const S
     constexpr int NFRAG = 2 * NPB * 2;                // fragments per chunk and image: 2 kernel-1 waves x NPB x 2 k-steps
     constexpr int FBYTES = NFRAG * 1024;
 
-    char* Gs = smem;                                  // G fragments, verbatim
-    char* As = Gs + FBYTES;                           // a fragments: bf16 high part of the fp16 blob (same lane order)
+    // both blobs are fp16 (G scaled per (lane, block), see kernel 1); each is split into an exact bf16 hi + lo pair
+    // while it is committed to LDS, in the blob's own lane order (the split is elementwise)
+    char* Gs = smem;                                  // G fragments: bf16 high part of scale * fp16
+    char* Gs2 = Gs + (DO_P ? FBYTES : 0);             // ... and the bf16 residual (G = hi + lo exactly)
+    char* Xs = Gs2 + (DO_P ? FBYTES : 0);             // [256][144 B]  X rows (rows >= Cs are zero)
+    char* As = Xs + (DO_P ? 256 * SPX_BK_ROW : 0);    // a fragments: bf16 high part of the fp16 blob
     char* As2 = As + FBYTES;                          // ... and the bf16 residual (a = hi + lo exactly)
-    char* Xs = As2 + FBYTES;                          // [256][144 B]  X rows (rows >= Cs are zero)
-    char* Ls = Xs + 256 * SPX_BK_ROW;                 // [NCB*32][144 B] dLogits^T, bf16 high part
+    char* Ls = As2 + FBYTES;                          // [NCB*32][144 B] dLogits^T, bf16 high part
     char* Ls2 = Ls + NCB * 32 * SPX_BK_ROW;           // ... and the bf16 residual: dLogits enters d_W as hi + lo (~2^-17)
 
     // wave roles
@@ -104,6 +111,18 @@ __global__ __launch_bounds__(SPX_BK_THREADS, 2) void spx_bank_bwd_kernel(const S
     constexpr int FP = (FBYTES / 16 + SPX_BK_THREADS - 1) / SPX_BK_THREADS;   // 16-B pieces per thread per image
     constexpr int XPT = 256 * 8 / SPX_BK_THREADS;                               // X pieces (8 px) per thread = 4
     u32x4 gr[FP], ar[FP], xr[XPT][XF32 ? 2 : 1];
+    float gsc[FP];                                    // inverse scale of each staged G piece (one lane of one block)
+    // piece -> (fragment, lane) of the blob: the inverse of spx_blob_slot.  Fixed per thread for the whole launch.
+    uint32_t gsc_off[FP];
+#pragma unroll
+    for (int i = 0; i < FP; ++i) {
+        const int off = (i * SPX_BK_THREADS + tid) * 16;
+        const int frag = off >> 10, slot = (off >> 4) & 63, s2 = frag & 1;
+        const int t = (slot - 8 * s2) & 63;
+        const int rr = (t >> 3) * 4 + (t & 3), hh = (t & 7) >> 2;
+        gsc_off[i] = off < FBYTES ? (uint32_t)(((frag >> 1) * 64 + rr + 32 * hh) * 4) : SPX_OOB;
+    }
+    const size_t blob_total = (size_t)pl.npanels * ntiles * 4 * NPB * 2 * 1024;
     constexpr int LPT = (SPX_BK_PX * 32 * NCB + SPX_BK_THREADS - 1) / SPX_BK_THREADS;   // dLogits elements per thread (upper bound)
     float lr_[LPT];
     const int piece = tid & 7, prow = tid >> 3;      // X staging: piece of 8 px, row (0..63) within a pass of 64 rows
@@ -116,10 +135,12 @@ __global__ __launch_bounds__(SPX_BK_THREADS, 2) void spx_bank_bwd_kernel(const S
         const size_t blob0 = ((((size_t)q * ntiles + tile_g) * 4 + 2 * (ci & 1)) * NPB * 2) * 1024;
         const spx_rsrc grs = make_rsrc_pred(a.g_in ? (const char*)a.g_in + blob0 : nullptr);
         const spx_rsrc ars = make_rsrc_pred(a.a_in ? (const char*)a.a_in + blob0 : nullptr);
+        const spx_rsrc gss = make_rsrc_pred(a.g_in ? (const char*)a.g_in + blob_total + blob0 / 8 : nullptr);
 #pragma unroll
         for (int i = 0; i < FP; ++i) {
             const uint32_t off = (uint32_t)((i * SPX_BK_THREADS + tid) * 16);
             gr[i] = buf_load_b128_p<SPX_AUX_BLOB_LD>(grs, (want_p && off < (uint32_t)FBYTES) ? off : SPX_OOB, 0);
+            gsc[i] = buf_load_f32(gss, want_p ? gsc_off[i] : SPX_OOB, 0);
             ar[i] = buf_load_b128_p<SPX_AUX_BLOB_LD>(ars, (want_w && off < (uint32_t)FBYTES) ? off : SPX_OOB, 0);
         }
         const int px = ci * SPX_BK_PX + piece * 8;
@@ -163,7 +184,19 @@ __global__ __launch_bounds__(SPX_BK_THREADS, 2) void spx_bank_bwd_kernel(const S
         for (int i = 0; i < FP; ++i) {
             const int off = (i * SPX_BK_THREADS + tid) * 16;
             if (off < FBYTES) {
-                *(u32x4*)(Gs + off) = gr[i];
+                if (DO_P) {
+                    const f16x8 hv = __builtin_bit_cast(f16x8, gr[i]);
+                    bf16x8 ghi, glo;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        __bf16 hi, lo;
+                        split_bf16((float)hv[j] * gsc[i], hi, lo);      // 11-bit mantissa: hi + lo is exact
+                        ghi[j] = hi;
+                        glo[j] = lo;
+                    }
+                    *(u32x4*)(Gs + off) = __builtin_bit_cast(u32x4, ghi);
+                    *(u32x4*)(Gs2 + off) = __builtin_bit_cast(u32x4, glo);
+                }
                 if (DO_W) {
                     // the activation blob is fp16: split every element into bf16 hi + lo HERE, with the whole workgroup
                     // and in the blob's own lane order (the split is elementwise), so the waves of the head product
@@ -196,12 +229,12 @@ __global__ __launch_bounds__(SPX_BK_THREADS, 2) void spx_bank_bwd_kernel(const S
             } else {
                 v = xr[i][0];
             }
-            *(u32x4*)(Xs + (prow + 64 * i) * SPX_BK_ROW + piece * 16) = v;
+            if (DO_P) *(u32x4*)(Xs + (prow + 64 * i) * SPX_BK_ROW + piece * 16) = v;
         }
 #pragma unroll
         for (int i = 0; i < LPT; ++i) {
             const int e = i * SPX_BK_THREADS + tid;
-            if (e < SPX_BK_PX * K) {
+            if (DO_W && e < SPX_BK_PX * K) {
                 const int p = e / K, cls = e - p * K;
                 __bf16 hi, lo;
                 split_bf16(lr_[i], hi, lo);
@@ -212,7 +245,7 @@ __global__ __launch_bounds__(SPX_BK_THREADS, 2) void spx_bank_bwd_kernel(const S
     };
 
     // padded class rows of the dLogits^T image stay zero for the whole kernel
-    for (int e = tid; e < NCB * 32 * SPX_BK_PX; e += SPX_BK_THREADS) {
+    for (int e = tid; DO_W && e < NCB * 32 * SPX_BK_PX; e += SPX_BK_THREADS) {
         const int cls = e / SPX_BK_PX, p = e - cls * SPX_BK_PX;
         if (cls >= K) {
             *(uint16_t*)(Ls + cls * SPX_BK_ROW + p * 2) = 0;
@@ -247,15 +280,21 @@ __global__ __launch_bounds__(SPX_BK_THREADS, 2) void spx_bank_bwd_kernel(const S
                 const int fb = ((wsel * NPB + pb0 + i) * 2 + ts2) * 1024;
                 const bf16x4 g0 = __builtin_bit_cast(bf16x4, lds_tr_read(Gs + fb + fo0));
                 const bf16x4 g1 = __builtin_bit_cast(bf16x4, lds_tr_read(Gs + fb + fo1));
+                const bf16x4 l0 = __builtin_bit_cast(bf16x4, lds_tr_read(Gs2 + fb + fo0));
+                const bf16x4 l1 = __builtin_bit_cast(bf16x4, lds_tr_read(Gs2 + fb + fo1));
                 const bf16x8 gf = __builtin_shufflevector(g0, g1, 0, 1, 2, 3, 4, 5, 6, 7);
+                const bf16x8 gf2 = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
                 if (cs_role) {   // colsum(G): every lane holds 8 px of its prototype row; lanes r, r+32 cover the k-step
                     float s8 = 0.0f;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) s8 += (float)gf[j];
+                    for (int j = 0; j < 8; ++j) s8 += (float)gf[j] + (float)gf2[j];
                     csum[i] += s8;
                 }
 #pragma unroll
-                for (int t = 0; t < 2; ++t) accp[i][t] = mfma_bf16(gf, xb[t], accp[i][t]);
+                for (int t = 0; t < 2; ++t) {
+                    accp[i][t] = mfma_bf16(gf, xb[t], accp[i][t]);
+                    accp[i][t] = mfma_bf16(gf2, xb[t], accp[i][t]);
+                }
             }
         };
         // d_W part of one pixel k-step (waves 0 .. NPB-1: prototype block `wave`, every class block)
@@ -427,7 +466,8 @@ __global__ __launch_bounds__(SPX_RED_ELEMS * SPX_RED_PARTS) void spx_bank_reduce
 
 template <int NPB, int NCB, bool DO_P, bool DO_W, bool KSPLIT>
 static hipError_t launch_bank_k(const SpxBankBwdArgs& a, int x_dtype, dim3 grid, hipStream_t s) {
-    constexpr size_t lds = (size_t)spx_bk_lds_bytes<NPB, NCB>();
+    constexpr size_t lds = (size_t)spx_bk_lds_bytes<NPB, NCB, DO_P, DO_W>();
+    static_assert(lds <= SPX_LDS_LIMIT, "bank kernel LDS");
     if (x_dtype == 1) {
         if (a.vec_ok) hipLaunchKernelGGL((spx_bank_bwd_kernel<NPB, NCB, true, true, DO_P, DO_W, KSPLIT>), grid, dim3(SPX_BK_THREADS), lds, s, a);
         else hipLaunchKernelGGL((spx_bank_bwd_kernel<NPB, NCB, true, false, DO_P, DO_W, KSPLIT>), grid, dim3(SPX_BK_THREADS), lds, s, a);

@@ -296,6 +296,9 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
         const size_t blob0 = (((size_t)panel * ntiles + tile_g) * 4) * NPB * 2 * 1024;   // bytes
         const spx_rsrc gr = make_rsrc(a.g_out ? (const char*)a.g_out + blob0 : nullptr);
         const spx_rsrc ar = make_rsrc(a.a_out ? (const char*)a.a_out + blob0 : nullptr);
+        // inverse scales of the G blob: one float per (lane, block) behind the blobs, [panel][tile][wave][block][lane]
+        const size_t blob_total = (size_t)pl.npanels * ntiles * 4 * NPB * 2 * 1024;
+        const spx_rsrc gsr = make_rsrc(a.g_out ? (const char*)a.g_out + blob_total + blob0 / 8 : nullptr);
 
         // ---- phase 1: G, a — a ROLLED loop over the panel's 32-prototype blocks.  The block being processed is
         // always acc[0]; acc is rotated after each block and the packed G fragments enter a register queue, so
@@ -354,15 +357,22 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
 
         // one prototype block, read from accumulator slot SLOT (static); ddc = its dDist, ddnext = prefetch target;
         // gout = its packed G fragments (k-steps 0 / 1)
-        auto block = [&](int pb, auto slot_c, float (&ddc)[16], float (&ddnext)[16], bf16x8 (&gout)[2]) {
+        auto block = [&](int pb, auto slot_c, float (&ddc)[16], float (&ddnext)[16], bf16x8 (&gout)[2], bf16x8 (&glo)[2]) {
             constexpr int SLOT = decltype(slot_c)::value;
             f16x8 anew[2];     // the activation blob is fp16 (a / ln 2 <= 13.3; 11-bit mantissa): the bank side splits it into bf16 hi + lo
+            // the G blob is fp16 too, scaled per (lane, block) by a power of two so that the lane's largest |G| of the
+            // block sits just under 2^15 (a gradient has no fixed range: bf16's exponent with fp16's mantissa); the
+            // inverse scale goes to a side array and the bank side rebuilds G = fp16 * scale as an exact bf16 hi + lo pair
+            f16x8 gblob[2];
+            float gscale_up = 1.0f;
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     gout[s2][j] = (__bf16)0.0f;
+                    glo[s2][j] = (__bf16)0.0f;
                     anew[s2][j] = (_Float16)0.0f;
+                    gblob[s2][j] = (_Float16)0.0f;
                 }
             if (pb < nv) {
                 if (have_dd && pb + 1 < nv) load_ddist(pb + 1, ddnext);
@@ -443,14 +453,26 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
                         av[reg] = valid ? av[reg] : 0.0f;
                     }
                 }
+                float gmax = 0.0f;
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) gmax = fmaxf(gmax, __builtin_fabsf(gv[reg]));
+                // gmax = m * 2^ex, m in [0.5, 1): scaled by 2^(15 - ex) the block's values stay below 2^15 (fp16 max 65504)
+                int ex = __builtin_amdgcn_frexp_expf(gmax);
+                ex = ex < -100 ? -100 : (ex > 100 ? 100 : ex);
+                const float gscale_dn = __builtin_amdgcn_ldexpf(1.0f, 15 - ex);
+                gscale_up = __builtin_amdgcn_ldexpf(1.0f, ex - 15);
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) {
-                    // register reg = 8 s2 + j of the tile -> element j of k-step s2 of the B fragment
-                    const __bf16 gb = (__bf16)gv[reg];
+                    // register reg = 8 s2 + j of the tile -> element j of k-step s2 of the B fragment.  G enters
+                    // dX = 2 (rs x - P^T G) as a bf16 hi + lo pair (~2^-17 relative)
+                    __bf16 gb, gl;
+                    split_bf16(gv[reg], gb, gl);
                     gout[reg >> 3][reg & 7] = gb;
+                    glo[reg >> 3][reg & 7] = gl;
                     // the row sum uses the SAME rounded G as the P^T.G product: dX = 2 sum_p G_p (x - p) then carries
                     // G's rounding relative to |x - p|, not to |p| (matters where a pixel sits on a prototype)
-                    rs += (float)gb;
+                    rs += (float)gb + (float)gl;
+                    gblob[reg >> 3][reg & 7] = (_Float16)(gv[reg] * gscale_dn);
                     anew[reg >> 3][reg & 7] = (_Float16)av[reg];
                 }
             }
@@ -459,18 +481,20 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
             for (int s2 = 0; s2 < 2; ++s2) {
                 const uint32_t so = (uint32_t)(((wave * NPB + pb) * 2 + s2) * 1024);
                 const uint32_t vo = spx_blob_slot(r, h, s2) * 16u;
-                if (a.g_out) buf_store_b128_p<SPX_AUX_BLOB_ST>(__builtin_bit_cast(u32x4, gout[s2]), gr, vo, so);
+                if (a.g_out) buf_store_b128_p<SPX_AUX_BLOB_ST>(__builtin_bit_cast(u32x4, gblob[s2]), gr, vo, so);
                 if (a.a_out) buf_store_b128_p<SPX_AUX_BLOB_ST>(__builtin_bit_cast(u32x4, anew[s2]), ar, vo, so);
             }
+            if (a.g_out) buf_store_f32(gscale_up, gsr, (uint32_t)lane * 4u, (uint32_t)((wave * NPB + pb) * 256));
         };
-        auto put_g = [&](f32x16& dst, const bf16x8 (&g)[2]) {
+        auto put_g = [&](f32x16& dst, const bf16x8 (&g)[2], const bf16x8 (&gl)[2]) {
             const u32x4 g0 = __builtin_bit_cast(u32x4, g[0]), g1 = __builtin_bit_cast(u32x4, g[1]);
+            const u32x4 l0 = __builtin_bit_cast(u32x4, gl[0]), l1 = __builtin_bit_cast(u32x4, gl[1]);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 dst[i] = __uint_as_float(g0[i]);
                 dst[4 + i] = __uint_as_float(g1[i]);
-                dst[8 + i] = 0.0f;
-                dst[12 + i] = 0.0f;
+                dst[8 + i] = __uint_as_float(l0[i]);
+                dst[12 + i] = __uint_as_float(l1[i]);
             }
         };
         // ROLLED loop, two blocks per iteration from the static slots 0 and 1 (static dDist buffers too), then one
@@ -478,18 +502,18 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
         // slots.  NPB / 2 iterations, so the rotation ends aligned: acc[i] = block i's G fragments.
 #pragma unroll 1
         for (int pb = 0; pb < NPB; pb += 2) {
-            bf16x8 gA[2], gB[2];
-            block(pb, std::integral_constant<int, 0>{}, ddA, ddB, gA);
-            block(pb + 1, std::integral_constant<int, 1>{}, ddB, ddA, gB);
+            bf16x8 gA[2], gB[2], lA[2], lB[2];
+            block(pb, std::integral_constant<int, 0>{}, ddA, ddB, gA, lA);
+            block(pb + 1, std::integral_constant<int, 1>{}, ddB, ddA, gB, lB);
 #pragma unroll
             for (int i = 0; i + 2 < NPB; ++i) acc[i] = acc[i + 2];
-            put_g(acc[NPB - 2], gA);
-            put_g(acc[NPB - 1], gB);
+            put_g(acc[NPB - 2], gA, lA);
+            put_g(acc[NPB - 1], gB, lB);
         }
 #ifdef SPX_DIAG_STAMPS
         dg_t2 = __builtin_amdgcn_s_memtime();
 #endif
-        auto g_frag = [&](int pb, int s2) -> bf16x8 {
+        auto g_frag = [&](int pb, int s2) -> bf16x8 {       // s2 = 0, 1: bf16 high parts of k-steps 0, 1; 2, 3: the residuals
             u32x4 w;
 #pragma unroll
             for (int i = 0; i < 4; ++i) w[i] = __float_as_uint(acc[pb][4 * s2 + i]);
@@ -604,8 +628,11 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
             for (int pb = 0; pb < NPB; ++pb) {
                 if (pb < nv) {
 #pragma unroll
-                    for (int s2 = 0; s2 < 2; ++s2)
-                        accx = mfma_bf16(*(const bf16x8*)(cur + (pb * 2 + s2) * 1024), g_frag(pb, s2), accx);
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        const bf16x8 pt = *(const bf16x8*)(cur + (pb * 2 + s2) * 1024);
+                        accx = mfma_bf16(pt, g_frag(pb, s2), accx);
+                        accx = mfma_bf16(pt, g_frag(pb, 2 + s2), accx);
+                    }
                 }
             }
             char* T = (chb & 1) ? tt1 : tt0;

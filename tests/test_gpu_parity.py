@@ -4,11 +4,10 @@ Stated tolerances (inputs are bf16-representable fp32, SURVEY.md 8d "identical i
   distances   |d - d_ref| <= 1e-4 * (1 + d_ref)
   activations |a - a_ref| <= 2e-4 * (1 + |a_ref|)
   logits      |l - l_ref| <= 1e-4 * max(1, max|l_ref|)      (1e-4 relative, north star)
-  gradients   max|g - g_ref| <= 4e-3 * max|g_ref| for dX with fp32 X (G enters dX = 2(rs x - P^T G) as ONE bf16
-              operand: unit roundoff 2^-8 = 3.9e-3, reached when a scale has one or two prototypes and nothing
-              averages), 3e-3 for dPrototypes (a sum over all pixels), 8e-3 for dX in bf16 and
-              for dLastLayer (G, the activations and dLogits enter the pixel-sum MFMAs as bf16: unbiased
-              2^-9 operand rounding, which does not average out on the random-sign test gradients)
+  gradients   max|g - g_ref| <= 1e-3 * max|g_ref| for dX (fp32 features), dPrototypes, dLastLayer, dGroupProjection and
+              dLastLayerGroup everywhere (G enters dX = 2(rs x - P^T G) as a bf16 hi + lo pair and crosses to the
+              parameter kernel as per-lane-scaled fp16 rebuilt as an exact hi + lo pair; activations likewise; dLogits
+              as split bf16); 3e-3 for dX RETURNED in bf16 (bf16 features): the output rounding alone is 2^-9
   push        indices bit-exact, values bit-exact given the same distance map
 """
 import numpy as np
@@ -108,7 +107,20 @@ def test_forward_matches_golden(golden, name):
                 torch.from_numpy(g["activations"]))
 
 
-def _grad_close(got, ref, what, tol=3e-3):
+GRAD_TOL = 1e-3        # gradients rel 1e-3 (max-normalised)
+BF16_DX_TOL = 4e-3     # dX returned in bf16 (bf16 features): ONE output rounding is half a bf16 ulp = 2^-8 of the element
+
+
+def _dx_tol(x_dtype, ranges=None):
+    """fp32 features: 1e-3.  bf16 features: dX is returned in bf16 and a scale with more than 192 prototypes (several
+    panels) accumulates its partial dX through that bf16 buffer - one 2^-8 rounding per panel of the scale."""
+    if x_dtype == torch.float32:
+        return GRAD_TOL
+    panels = 1 if ranges is None else max(-(-(hi - lo) // 192) for lo, hi in (ranges.values() if isinstance(ranges, dict) else ranges))
+    return BF16_DX_TOL * max(1, panels)
+
+
+def _grad_close(got, ref, what, tol=GRAD_TOL):
     got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
     scale = ref.abs().max().item() + 1e-30
     err = (got - ref).abs().max().item()
@@ -148,9 +160,9 @@ def test_backward_matches_oracle(shape, x_dtype):
     loss.backward()
     torch.cuda.synchronize()
     assert x.grad.dtype == x_dtype and x.grad.shape == x.shape
-    _grad_close(x.grad, dx_ref, "dX", tol=4e-3 if x_dtype == torch.float32 else 8e-3)
+    _grad_close(x.grad, dx_ref, "dX", tol=_dx_tol(x_dtype, ranges))
     _grad_close(pv.grad, dp_ref, "dPrototypes")
-    _grad_close(w.grad, dw_ref, "dLastLayer", tol=2.5e-3)
+    _grad_close(w.grad, dw_ref, "dLastLayer")
 
 
 @pytest.mark.parametrize("name", ["proto_ms_city", "proto_s1_wide"])
@@ -176,7 +188,7 @@ def test_backward_matches_golden(golden, name):
     loss.backward()
     _grad_close(x.grad, torch.from_numpy(g["d_conv"]), "dX")
     _grad_close(pv.grad, torch.from_numpy(g["d_prototypes"]), "dPrototypes")
-    _grad_close(w.grad, torch.from_numpy(g["d_last_layer"]), "dLastLayer", tol=2.5e-3)
+    _grad_close(w.grad, torch.from_numpy(g["d_last_layer"]), "dLastLayer")
 
 
 def test_backward_partial_inputs():
@@ -196,7 +208,7 @@ def test_backward_partial_inputs():
     logits, dist, _ = proto_head_forward(x, bank.to(dev), w, _layout(P, K, S, Cs, ranges))
     (logits * g_logits.reshape(-1, K).to(dev)).sum().backward()
     _grad_close(x.grad, dx_ref, "dX (logits only)")
-    _grad_close(w.grad, dw_ref, "dW (logits only)", tol=2.5e-3)
+    _grad_close(w.grad, dw_ref, "dW (logits only)")
 
     g_dist = torch.randn(B, P, H, W, generator=g) * 1e-3
     _, _, _, dx_ref, dp_ref, _ = O.fwd_bwd_reference(conv, bank, ranges, S, Wl, torch.zeros(B, H, W, K), g_dist)
@@ -358,9 +370,9 @@ def test_class_gathered_forward_backward(shape, x_dtype):
     _assert_fwd(logits, None, None, l_ref.detach(), None, None)
     ((logits * g_logits.reshape(-1, K).to(dev)).sum() + (cd * g_cls.permute(0, 2, 1).contiguous().to(dev)).sum()).backward()
     torch.cuda.synchronize()
-    _grad_close(x.grad, c0.grad, "dX", tol=4e-3 if x_dtype == torch.float32 else 8e-3)
+    _grad_close(x.grad, c0.grad, "dX", tol=_dx_tol(x_dtype, ranges))
     _grad_close(pv.grad, p0.grad, "dPrototypes")
-    _grad_close(w.grad, w0.grad, "dLastLayer", tol=2.5e-3)
+    _grad_close(w.grad, w0.grad, "dLastLayer")
 
 
 def test_kld_through_the_module(golden):
@@ -403,8 +415,8 @@ def test_kld_through_the_module(golden):
     k_ref = O.kld_loss(d_ref, target, ident, S, ranges)
     k_ref.backward()
     assert abs(kld.item() - k_ref.item()) <= 1e-4 * max(1.0, abs(k_ref.item())), (kld.item(), k_ref.item())
-    _grad_close(x.grad, c0.grad, "dX via KLD", tol=5e-3)
-    _grad_close(net.prototype_vectors.grad, p0.grad, "dPrototypes via KLD", tol=5e-3)
+    _grad_close(x.grad, c0.grad, "dX via KLD")
+    _grad_close(net.prototype_vectors.grad, p0.grad, "dPrototypes via KLD")
     # same module, same loss class, full-map input: identical value
     logits2, dist2 = net.forward_from_conv_features(conv.to(dev))
     k2 = spx.KLDLoss(net.prototype_class_identity, S, net.scale_num_prototypes)(dist2, target.to(dev))
@@ -446,8 +458,8 @@ def test_north_star_size_properties():
     assert torch.equal(d_b, d_s.repeat(1, 1, H // h, W // w))
     assert torch.equal(l_b.view(H, W, K), l_s.view(h, w, K).repeat(H // h, W // w, 1))
     assert torch.equal(dx_b, dx_s.repeat(1, 1, H // h, W // w))
-    _grad_close(dp_b, reps * dp_s, "dPrototypes (full size)", tol=2e-3)
-    _grad_close(dw_b, reps * dw_s, "dLastLayer (full size)", tol=2e-3)
+    _grad_close(dp_b, reps * dp_s, "dPrototypes (full size)")
+    _grad_close(dw_b, reps * dw_s, "dLastLayer (full size)")
 
 
 def test_argument_errors():
@@ -527,16 +539,16 @@ def test_fused_group_tail(shape, x_dtype):
     assert ((gact.cpu() - ug).abs() <= 2e-4 * (1 + ug.abs())).all(), "group activations"
     ((logits * g_logits.reshape(-1, K).to(dev)).sum() + (dist * g_dist.to(dev)).sum()).backward()
     torch.cuda.synchronize()
-    _grad_close(x.grad, c0.grad, "dX", tol=4e-3 if x_dtype == torch.float32 else 8e-3)
+    _grad_close(x.grad, c0.grad, "dX", tol=_dx_tol(x_dtype, ranges))
     _grad_close(pv.grad, p0.grad, "dPrototypes")
-    _grad_close(wgd.grad, wg0.grad, "dLastLayerGroup", tol=2e-3)
+    _grad_close(wgd.grad, wg0.grad, "dLastLayerGroup")
     dwd_ref = torch.zeros(U, P)
     for k, i in enumerate(idx):
         dwd_ref[k * G:(k + 1) * G, i] = gw0[k].grad
     mask = torch.zeros(U, P, dtype=torch.bool)
     for k, i in enumerate(idx):
         mask[k * G:(k + 1) * G, i] = True
-    _grad_close(wdd.grad.cpu() * mask, dwd_ref, "dGroupProjection", tol=2.5e-3)
+    _grad_close(wdd.grad.cpu() * mask, dwd_ref, "dGroupProjection")
 
 
 @pytest.mark.parametrize("case", [(1, 228, 17, 33, 129, 257, False), (2, 19, 9, 11, 70, 90, True), (1, 5, 4, 5, 4, 5, False),
@@ -615,13 +627,13 @@ def test_random_configurations(seed):
     ((logits * g_logits.reshape(-1, K).to(dev)).sum() + (dist * g_dist.to(dev)).sum() + (act * g_act.to(dev)).sum()).backward()
     torch.cuda.synchronize()
     tag = f"B{B} S{S} Cs{Cs} P{per_scale} K{K} {H}x{W} {x_dtype}"
-    _grad_close(x.grad, dx_ref, "dX " + tag, tol=4e-3 if x_dtype == torch.float32 else 8e-3)
+    _grad_close(x.grad, dx_ref, "dX " + tag, tol=_dx_tol(x_dtype, ranges))
     # G is ONE bf16 operand of dPrototypes = -2 sum_px G (x - p): 3e-3 holds on the fixed shapes; with one prototype per
     # scale the extended run (tests/fuzz_extended.py) reaches 4.4e-3
-    _grad_close(pv.grad, dp_ref, "dPrototypes " + tag, tol=5e-3)
+    _grad_close(pv.grad, dp_ref, "dPrototypes " + tag)
     # d_W = dLogits^T . a: the activations cross HBM as fp16 and enter the MFMA as bf16 hi + lo, dLogits as bf16 hi + lo;
     # peak over 400 further random configurations (tests/fuzz_extended.py gradstats): 1.1e-3
-    _grad_close(w.grad, dw_ref, "dLastLayer " + tag, tol=2.5e-3)
+    _grad_close(w.grad, dw_ref, "dLastLayer " + tag)
 
 
 @pytest.mark.parametrize("seed", list(range(12)))
@@ -650,7 +662,7 @@ def test_random_gather_and_tail(seed):
     # tiny banks (P as small as 4): dX is a sum of a handful of signed terms G_p (x - p), each carrying G's bf16
     # rounding (2^-8); with cancellation between them the error relative to max|dX| can pass the 4e-3 of the
     # realistic shapes, so these toy cases get 6e-3
-    dx_tol = 6e-3 if x_dtype == torch.float32 else 8e-3
+    dx_tol = _dx_tol(x_dtype, ranges)
     if seed % 2 == 0:
         target = _labels(B, H, W, K, seed=seed)
         lab0 = target.reshape(B, -1) - 1
@@ -668,7 +680,7 @@ def test_random_gather_and_tail(seed):
         _assert_fwd(logits, None, None, l_ref.detach(), None, None)
         ((logits * g_logits.reshape(-1, K).to(dev)).sum() + (cd * g_cls.permute(0, 2, 1).contiguous().to(dev)).sum()).backward()
         torch.cuda.synchronize()
-        _grad_close(w.grad, w0.grad, "dLastLayer", tol=2.5e-3)
+        _grad_close(w.grad, w0.grad, "dLastLayer")
     else:
         G = int(rng.integers(2, 4))
         idx = [i for i in O.class_prototype_index(ident) if len(i) > 0]
@@ -694,12 +706,9 @@ def test_random_gather_and_tail(seed):
         assert err <= 1e-4 * max(1.0, rl.abs().max().item()), f"group logits err {err}"
         (logits * g_logits.reshape(-1, K).to(dev)).sum().backward()
         torch.cuda.synchronize()
-        _grad_close(wgd.grad, wg0.grad, "dLastLayerGroup", tol=2e-3)
+        _grad_close(wgd.grad, wg0.grad, "dLastLayerGroup")
     _grad_close(x.grad, c0.grad, "dX", tol=dx_tol)
-    # dPrototypes = -2 sum_px G (x - p) with G ONE bf16 operand (half-ulp 2^-9 per term): on these grids of a few
-    # hundred pixels the signed terms cancel and the error relative to max|dP| reaches 4.8e-3 (seen in a 600-case run of
-    # tests/fuzz_extended.py; the realistic shapes of BWD_SHAPES stay inside 3e-3)
-    _grad_close(pv.grad, p0.grad, "dPrototypes", tol=6e-3)
+    _grad_close(pv.grad, p0.grad, "dPrototypes")
 
 
 
