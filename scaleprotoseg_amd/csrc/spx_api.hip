@@ -229,6 +229,10 @@ static int dist_bwd_impl(const spx_plan* pl, const void* x, int32_t x_dtype, int
     if (dx && !packed_bankT) return fail("spx_dist_bwd: dx requested without packed bank^T");
     if (d_logits && !packed_headT) return fail("spx_dist_bwd: d_logits given without packed head^T");
     if ((long long)pl->num_prototypes * HW >= (1LL << 29)) return fail("spx_dist_bwd: P*HW too large for 32-bit offsets");
+    const long long tiles = (long long)B * ((HW + SPX_TILE_PX - 1) / SPX_TILE_PX);
+    if (tiles > 0x7fffffffLL) return fail("spx_dist_bwd: too many pixel tiles");
+    if ((long long)pl->num_scales * pl->channels_per_scale * HW * (x_dtype ? 4 : 2) >= (1LL << 32)) return fail("spx_dist_bwd: one image of features exceeds 4 GiB");
+    if (g_out && pl->channels_per_scale > 256) return fail("spx_dist_bwd: G scratch requested but spx_bank_bwd supports channels_per_scale <= 256 (got %d)", pl->channels_per_scale);
     SpxBwdArgs a;
     a.plan = *pl;
     a.x = x;

@@ -161,6 +161,38 @@ def _pixel_outer(a: torch.Tensor, b: torch.Tensor, chunk: int = 4096) -> torch.T
     return out
 
 
+# Limits of the head product fused into the distance kernels (class blocks of 32 rows: 1, 2 or 5 per instance)
+MAX_FUSED_HEAD_ROWS = 160
+MAX_FUSED_TAIL_CLASSES = 32
+
+
+class _WideLinearFn(torch.autograd.Function):
+    """y = a . w^T for heads wider than the fused kernels carry (more than 160 rows: scaleproto_coco.gin's 182 classes,
+    the dense grouping heads of group_scaleproto_ade.gin / _coco.gin with 450 / 546 rows, or a grouping tail over more
+    than 32 classes).  The [pixel][P] activations come out of the distance kernel once; this product is a PLAIN library
+    GEMM (rocBLAS through torch.mm) - the one case the hardware rules reserve for a library.  Backward: d_a = g . w, and
+    d_w = g^T . a as a chunked tall-skinny product (the plain form is a single-workgroup-shaped GEMM)."""
+
+    @staticmethod
+    def forward(ctx, a, w):
+        ctx.save_for_backward(a, w)
+        return a @ w.t()
+
+    @staticmethod
+    def backward(ctx, g):
+        a, w = ctx.saved_tensors
+        g = g.contiguous()
+        da = g @ w if ctx.needs_input_grad[0] else None
+        dw = _pixel_outer(g, a).to(w.dtype) if ctx.needs_input_grad[1] else None
+        return da, dw
+
+
+def wide_linear(a: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+    if not a.is_cuda:
+        raise SpxError("scaleprotoseg_amd runs on an AMD GPU only; there is no CPU fallback")
+    return _WideLinearFn.apply(a, w)
+
+
 class _Packs:
     """Device buffers holding the MFMA-ordered operands of one forward."""
 
@@ -204,6 +236,10 @@ class _ProtoHeadFn(torch.autograd.Function):
             raise SpxError(f"head matrix must be [{K}, {P}], got {tuple(head2d.shape)}")
         plan = layout.plan()
         need_bwd = any(t is not None and t.requires_grad for t in (x, bank, head, tail))
+        if need_bwd and bank.requires_grad and layout.channels_per_scale > 256:
+            # the parameter-side backward tiles at most 8 channel blocks: say so BEFORE a full forward has run
+            raise SpxError(f"prototype gradients need channels_per_scale <= 256, got {layout.channels_per_scale} "
+                           "(freeze the bank or run the forward under torch.no_grad())")
         tail2d = tail.detach().contiguous().float() if tail is not None else None
         if tail2d is not None:
             if head2d is None or gather is not None:

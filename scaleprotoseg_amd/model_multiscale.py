@@ -15,7 +15,8 @@ from typing import Any, Dict, List, Optional, Tuple, Union
 import torch
 import torch.nn as nn
 
-from .functional import BankLayout, ClassGather, SpxError, class_gather_table, proto_head_forward
+from .functional import (MAX_FUSED_HEAD_ROWS, BankLayout, ClassGather, SpxError, class_gather_table, proto_head_forward,
+                         wide_linear)
 from .loss import ClassDistances
 
 
@@ -246,17 +247,20 @@ class PPNetMultiScale(_PrototypeBankMixin, nn.Module):
             raise SpxError("callable prototype_activation_function has no fused kernel")
         B, _, H, W = conv_features.shape
         want_dist = return_distances or not return_activations
-        layout = self._layout(self.num_classes)
+        wide = self.num_classes > MAX_FUSED_HEAD_ROWS          # e.g. scaleproto_coco.gin: 182 classes
+        layout = self._layout(1 if wide else self.num_classes)
         gather = None
         if target_labels is not None and want_dist:
             if tuple(target_labels.shape) != (B, H, W):
                 raise SpxError(f"target_labels must be [{B}, {H}, {W}] (latent grid), got {tuple(target_labels.shape)}")
             gather = self._class_gather(target_labels, layout, conv_features.device)
         logits, dist, act = proto_head_forward(
-            conv_features, self.prototype_vectors, self.last_layer.weight, layout,
-            want_distances=want_dist and gather is None, want_activations=return_activations, epsilon=self.epsilon,
-            activation=self.prototype_activation_function, class_gather=gather,
+            conv_features, self.prototype_vectors, None if wide else self.last_layer.weight, layout,
+            want_distances=want_dist and gather is None, want_activations=return_activations or wide,
+            epsilon=self.epsilon, activation=self.prototype_activation_function, class_gather=gather,
         )
+        if wide:      # the kernel hands out the activations once; the 182-row head is a plain library GEMM on them
+            logits = wide_linear(act, self.last_layer.weight)
         if gather is not None:
             dist = ClassDistances(values=dist, labels=gather.labels, table=gather.table, grid=(H, W))
         logits = logits.reshape(B, H, W, -1)

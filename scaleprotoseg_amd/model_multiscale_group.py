@@ -17,9 +17,8 @@ from typing import Any, List, Optional, Tuple
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
-from .functional import SpxError, proto_head_forward
+from .functional import MAX_FUSED_HEAD_ROWS, MAX_FUSED_TAIL_CLASSES, SpxError, proto_head_forward, wide_linear
 from .model_multiscale import _PrototypeBankMixin, _build_add_on, _first_add_on_channels
 from .utils import projection_simplex_sort
 
@@ -147,21 +146,28 @@ class PPNetMultiScale(_PrototypeBankMixin, nn.Module):
         wd = self._dense_group_matrix()
         want_dist = return_distances or not return_activations
         wg = self.last_layer_group.weight
-        if wg.shape[0] <= 32:
+        rows, k2 = int(wd.shape[0]), int(wg.shape[0])
+        kw = dict(want_distances=want_dist, epsilon=self.epsilon, activation=self.prototype_activation_function)
+        if rows <= MAX_FUSED_HEAD_ROWS and k2 <= MAX_FUSED_TAIL_CLASSES:
             # whole grouping head in the kernel: units = act . Wd^T, exp, last_layer_group (:303-308)
             logits, dist, act, _ = proto_head_forward(
-                conv_features, self.prototype_vectors, wd, self._layout(wd.shape[0]),
-                want_distances=want_dist, want_activations=return_activations, epsilon=self.epsilon,
-                activation=self.prototype_activation_function, group_tail=wg,
+                conv_features, self.prototype_vectors, wd, self._layout(rows), want_activations=return_activations,
+                group_tail=wg, **kw,
             )
-            logits = logits.reshape(B, H, W, -1)
-        else:   # more than 32 classes: the tail runs as two torch GPU ops
-            gpre, dist, act = proto_head_forward(
-                conv_features, self.prototype_vectors, wd, self._layout(wd.shape[0]),
-                want_distances=want_dist, want_activations=return_activations, epsilon=self.epsilon,
-                activation=self.prototype_activation_function,
+        elif rows <= MAX_FUSED_HEAD_ROWS:
+            # up to 160 units but more than 32 classes: the unit product stays in the kernel, the tail is a library GEMM
+            units, dist, act = proto_head_forward(
+                conv_features, self.prototype_vectors, wd, self._layout(rows), want_activations=return_activations, **kw,
             )
-            logits = F.linear(torch.exp(gpre), wg).reshape(B, H, W, -1)
+            logits = wide_linear(torch.exp(units), wg)
+        else:
+            # group_scaleproto_ade.gin (150 classes x 3 groups = 450 units) / _coco.gin (546): the kernel hands out the
+            # [pixel][P] activations once, both products are plain library GEMMs on them
+            _, dist, act = proto_head_forward(
+                conv_features, self.prototype_vectors, None, self._layout(1), want_activations=True, **kw,
+            )
+            logits = wide_linear(torch.exp(wide_linear(act, wd)), wg)
+        logits = logits.reshape(B, H, W, -1)
         if return_activations and not return_distances:
             return logits, act
         if return_activations and return_distances:

@@ -490,3 +490,100 @@ def test_push_prototypes_multiscale_end_to_end(tmp_path):
                                              net.last_layer.weight.detach().cpu())
     _close_fwd(dist, rd, "distances")
     _close_fwd(logits, rl, "logits")
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# heads wider than the fused kernels carry (group_scaleproto_ade.gin: 150 classes x 3 groups = 450 units over a
+# 1800-prototype bank in 4 scales; scaleproto_coco.gin: 182 classes): distances / activations from the kernel, the head
+# as library GEMMs on the activations (functional.wide_linear)
+# ------------------------------------------------------------------------------------------------------------------
+def test_ade_group_phase_wide_head_forward_backward():
+    from scaleprotoseg_amd.model_multiscale_group import PPNetMultiScale as GroupNet
+
+    dev = _dev()
+    S, Cs, K, G, P, B, H, W = 4, 64, 150, 3, 1800, 1, 9, 8
+    gen = torch.Generator().manual_seed(20220227 + 23)
+    conv = O.bf16_representable(torch.sigmoid(torch.randn(B, S * Cs, H, W, generator=gen)))
+    bank = O.bf16_representable(torch.rand(P, Cs, 1, 1, generator=gen))
+    torch.manual_seed(5)
+    net = GroupNet(_Backbone(S * Cs), 64, (P, Cs, 1, 1), [], K, add_on_layers_type="deeplab_simple",
+                   patch_classification=True, num_scales=S, num_groups=G)
+    assert net.last_layer_group.weight.shape == (K, G * K) and len(net.group_projection) == K
+    with torch.no_grad():
+        net.prototype_vectors.copy_(bank)
+        net.last_layer_group.weight.add_(0.02 * torch.randn(K, G * K, generator=gen))
+    net = net.to(dev)
+    ident = net.prototype_class_identity.cpu()
+    gw = [gp.weight.detach().cpu().clone().requires_grad_(True) for gp in net.group_projection]
+    wg = net.last_layer_group.weight.detach().cpu().clone().requires_grad_(True)
+    c0 = conv.clone().requires_grad_(True)
+    p0 = bank.clone().requires_grad_(True)
+    ranges = {s: tuple(net.scale_num_prototypes[s]) for s in range(S)}
+    rl, rd, ra = O.forward_from_conv_features(c0, p0, ranges, S, None, class_identity=ident, group_weights=gw,
+                                              last_layer_group_weight=wg)
+    g_logits = torch.randn(rl.shape, generator=gen) * 1e-3
+    g_dist = torch.randn(rd.shape, generator=gen) * 1e-3
+    ((rl * g_logits).sum() + (rd * g_dist).sum()).backward()
+
+    x = conv.to(dev).requires_grad_(True)
+    logits, dist = net.forward_from_conv_features(x)
+    _close_fwd(dist, rd.detach(), "distances")
+    _close_fwd(logits, rl.detach(), "logits")
+    ((logits * g_logits.to(dev)).sum() + (dist * g_dist.to(dev)).sum()).backward()
+    _grad_close(x.grad, c0.grad, "dX")
+    _grad_close(net.prototype_vectors.grad, p0.grad, "dPrototypes")
+    _grad_close(net.last_layer_group.weight.grad, wg.grad, "dLastLayerGroup")
+    scale = max(w.grad.abs().max().item() for w in gw)
+    for i, gp in enumerate(net.group_projection):
+        err = (gp.weight.grad.cpu() - gw[i].grad).abs().max().item()
+        assert err <= GRAD_TOL * scale, f"d group_projection[{i}]: {err:.3e} vs {scale:.3e}"
+    out = net.forward_from_conv_features(x.detach(), return_activations=True, return_distances=True)
+    assert len(out) == 3
+    _close_fwd(out[2], ra.detach(), "activations")
+
+
+@pytest.mark.parametrize("K,G", [(182, None), (50, 3)])
+def test_wide_class_heads(K, G):
+    """182 classes (scaleproto_coco.gin) on the prototype-phase module; 50 classes x 3 groups = 150 units with a 50-class
+    tail (unit product in the kernel, tail as a library GEMM) on the group-phase module."""
+    import scaleprotoseg_amd as spx
+    from scaleprotoseg_amd.model_multiscale_group import PPNetMultiScale as GroupNet
+
+    dev = _dev()
+    S, Cs, B, H, W = 4, 16, 2, 7, 9
+    P = S * K * 1
+    gen = torch.Generator().manual_seed(20220227 + 29)
+    conv = O.bf16_representable(torch.sigmoid(torch.randn(B, S * Cs, H, W, generator=gen)))
+    bank = O.bf16_representable(torch.rand(P, Cs, 1, 1, generator=gen))
+    torch.manual_seed(6)
+    if G is None:
+        net = spx.PPNetMultiScale(_Backbone(S * Cs), 64, (P, Cs, 1, 1), [], K, add_on_layers_type="deeplab_simple",
+                                  patch_classification=True, num_scales=S)
+    else:
+        net = GroupNet(_Backbone(S * Cs), 64, (P, Cs, 1, 1), [], K, add_on_layers_type="deeplab_simple",
+                       patch_classification=True, num_scales=S, num_groups=G)
+    with torch.no_grad():
+        net.prototype_vectors.copy_(bank)
+    net = net.to(dev)
+    ranges = {s: tuple(net.scale_num_prototypes[s]) for s in range(S)}
+    c0 = conv.clone().requires_grad_(True)
+    p0 = bank.clone().requires_grad_(True)
+    if G is None:
+        w0 = net.last_layer.weight.detach().cpu().clone().requires_grad_(True)
+        rl, rd, _ = O.forward_from_conv_features(c0, p0, ranges, S, w0)
+    else:
+        gw = [gp.weight.detach().cpu().clone() for gp in net.group_projection]
+        w0 = net.last_layer_group.weight.detach().cpu().clone().requires_grad_(True)
+        rl, rd, _ = O.forward_from_conv_features(c0, p0, ranges, S, None, class_identity=net.prototype_class_identity.cpu(),
+                                                 group_weights=gw, last_layer_group_weight=w0)
+    g_logits = torch.randn(rl.shape, generator=gen) * 1e-3
+    (rl * g_logits).sum().backward()
+    x = conv.to(dev).requires_grad_(True)
+    logits, dist = net.forward_from_conv_features(x)
+    _close_fwd(dist, rd.detach(), "distances")
+    _close_fwd(logits, rl.detach(), "logits")
+    (logits * g_logits.to(dev)).sum().backward()
+    _grad_close(x.grad, c0.grad, "dX")
+    _grad_close(net.prototype_vectors.grad, p0.grad, "dPrototypes")
+    head = net.last_layer.weight if G is None else net.last_layer_group.weight
+    _grad_close(head.grad, w0.grad, "dHead")
