@@ -7,8 +7,9 @@ import sys
 
 root = sys.argv[1]
 print(f"# rocprofv3 summary ({root})\n")
-print("Command: `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline` "
-      "(PMC counters: separate `--pmc` passes of the same command)\n")
+import os
+cmd = open(root + "/command.txt").read().strip() if os.path.exists(root + "/command.txt") else "python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline"
+print(f"Command: `rocprofv3 --kernel-trace --stats -- {cmd}` (PMC counters, where present: separate `--pmc` passes of the same command)\n")
 for f in glob.glob(root + "/trace/*/*kernel_stats.csv"):
     print("## Kernel stats (all calls incl. warm-up)\n")
     print("| kernel | calls | avg µs | total ms | % |")
