@@ -715,7 +715,11 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
 
 template <int NPB, int NCB, bool GATHER, bool DACT>
 static hipError_t launch_bwd_gd(const SpxBwdArgs& a, int x_dtype, dim3 grid, hipStream_t s) {
+#ifdef SPX_DIAG_BWD_LDS_EXTRA
+    constexpr size_t lds = (size_t)spx_bwd_lds_bytes<NPB, NCB>() + SPX_DIAG_BWD_LDS_EXTRA;   // experiment: force one workgroup per CU
+#else
     constexpr size_t lds = (size_t)spx_bwd_lds_bytes<NPB, NCB>();
+#endif
     if (x_dtype == 1) {
         if (a.vec_ok) hipLaunchKernelGGL((spx_bwd_kernel<NPB, NCB, true, true, GATHER, DACT>), grid, dim3(256), lds, s, a);
         else hipLaunchKernelGGL((spx_bwd_kernel<NPB, NCB, true, false, GATHER, DACT>), grid, dim3(256), lds, s, a);
