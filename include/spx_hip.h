@@ -35,7 +35,7 @@ extern "C" {
 #endif
 
 #define SPX_MAX_PANELS 64   /* (scale, <=192-prototype block) work units per pixel tile */
-#define SPX_ABI_VERSION 5
+#define SPX_ABI_VERSION 6
 
 /* How the prototype bank is cut into MFMA panels.  Filled by spx_make_plan(). */
 typedef struct spx_plan {
@@ -123,6 +123,51 @@ int spx_dist_bwd_cls(const spx_plan* plan, const void* x, int32_t x_dtype, int32
                      const float* d_class_distances, const float* d_act, const float* d_logits,
                      void* dx, void* g_out, void* a_out,
                      float epsilon, int32_t act_fn, void* stream);
+
+/* Pixel-wise cross entropy on the path's logits (segmentation/model/loss.py:9-48, caller
+ * segmentation/model/module_multiscale.py:239): CE = mean over the non-ignored pixels of
+ * logsumexp_k(logits[px]) - logits[px, label[px]].
+ *   labels    int32 [B*HW]: class 0..K-1 of the pixel (the reference's target - 1); any other value = ignored
+ *   lse       fp32  [B*HW]: per-pixel logsumexp (forward output, backward input)
+ *   pred      int32 [B*HW]: argmax class, lowest index on ties (optional forward output: `correct`, loss.py:43-46)
+ *   partials  fp32  [2 * spx_ce_partials(...)]: (sum of the per-pixel losses, number of non-ignored pixels) pairs, one
+ *             per wave; the caller sums them (fixed shape, fixed order: deterministic) and divides
+ *   logits    the forward's logits (backward input)
+ *   coef      DEVICE scalar: dLoss/dCE / number of non-ignored pixels
+ *   d_logits_out fp32 [B*HW, K]: coef * (softmax - onehot) (0 on ignored pixels), formed by the pixel-side backward for
+ *             spx_bank_bwd's d_logits operand
+ * spx_dist_fwd_ce = spx_dist_fwd / spx_dist_fwd_cls (labels_cls / proto_key NULL = the P-wide map) with the CE
+ * statistics computed on the logits tile while it is still in registers (8 B/px of extra output instead of separate
+ * log_softmax / nll passes over the [B*HW, K] tensor); spx_dist_bwd_ce = spx_dist_bwd / spx_dist_bwd_cls taking
+ * (logits, lse, labels, coef) in place of d_logits.  spx_ce_fwd / spx_ce_bwd are the same arithmetic as stand-alone
+ * kernels over any [M, K] logits (heads the fused kernels do not carry: more than 160 classes, the grouping tail). */
+typedef struct spx_ce {
+    const int32_t* labels;
+    float* lse;
+    int32_t* pred;
+    float* partials;
+    const float* logits;
+    const float* coef;
+    float* d_logits_out;
+} spx_ce;
+size_t spx_ce_partials(int32_t B, int32_t HW);       /* (sum, count) pairs the fused forward writes */
+size_t spx_ce_partials_flat(int64_t M);              /* ... and spx_ce_fwd */
+int spx_dist_fwd_ce(const spx_plan* plan, const void* x, int32_t x_dtype, int32_t B, int32_t HW,
+                    const void* packed_bank, const float* packed_p2, const void* packed_head,
+                    const int32_t* labels_cls, const uint32_t* proto_key, int32_t J, float* class_distances,
+                    float* distances, float* activations, float* logits, const spx_ce* ce,
+                    float epsilon, int32_t act_fn, void* stream);
+int spx_dist_bwd_ce(const spx_plan* plan, const void* x, int32_t x_dtype, int32_t B, int32_t HW,
+                    const void* packed_bank, const void* packed_bankT, const float* packed_p2,
+                    const void* packed_headT,
+                    const int32_t* labels_cls, const uint32_t* proto_key, int32_t J,
+                    const float* d_dist, const float* d_class_distances, const float* d_act, const spx_ce* ce,
+                    void* dx, void* g_out, void* a_out,
+                    float epsilon, int32_t act_fn, void* stream);
+int spx_ce_fwd(const float* logits, const int32_t* labels, int64_t M, int32_t K, float* lse, int32_t* pred,
+               float* partials, void* stream);
+int spx_ce_bwd(const float* logits, const float* lse, const int32_t* labels, const float* coef, int64_t M, int32_t K,
+               float* d_logits, void* stream);
 
 /* Grouping head with its tail fused (segmentation/model/model_multiscale_group.py:283-308, run_last_layer):
  *   units = act . Wd^T   (Wd = the dense [U = G*K', P] form of the per-class group_projection matrices, packed with

@@ -15,6 +15,8 @@ from ._lib import SpxError, load as load_library  # noqa: F401
 from .functional import (  # noqa: F401
     BankLayout,
     ClassGather,
+    FusedCrossEntropy,
+    cross_entropy_from_logits,
     argmin_over_images,
     class_gather_table,
     proto_head_forward,

@@ -15,7 +15,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libspx_hip.so")
 SPX_MAX_PANELS = 64
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class SpxError(RuntimeError):
@@ -38,7 +38,22 @@ class SpxPlan(C.Structure):
     ]
 
 
+class SpxCe(C.Structure):
+    """spx_ce of include/spx_hip.h: the cross-entropy attachment of spx_dist_fwd_ce / spx_dist_bwd_ce."""
+
+    _fields_ = [
+        ("labels", C.c_void_p),
+        ("lse", C.c_void_p),
+        ("pred", C.c_void_p),
+        ("partials", C.c_void_p),
+        ("logits", C.c_void_p),
+        ("coef", C.c_void_p),
+        ("d_logits_out", C.c_void_p),
+    ]
+
+
 _PP = C.POINTER(SpxPlan)
+_PCE = C.POINTER(SpxCe)
 _V = C.c_void_p
 _I = C.c_int32
 _F = C.c_float
@@ -75,6 +90,12 @@ SIGNATURES = {
     "spx_kld_pair_sums": (C.c_int, [_V, _V, _I, _I, _I, _I, _I, _V, _V, _V, _V]),
     "spx_kld_backward": (C.c_int, [_V, _V, _I, _I, _I, _I, _V, _V, _V, _V, _V]),
     "spx_upsample_argext": (C.c_int, [_V, _I, _I, _I, _I, _I, _I, _I, _V, _V, _V]),
+    "spx_ce_partials": (C.c_size_t, [_I, _I]),
+    "spx_ce_partials_flat": (C.c_size_t, [C.c_int64]),
+    "spx_dist_fwd_ce": (C.c_int, [_PP, _V, _I, _I, _I, _V, _V, _V, _V, _V, _I, _V, _V, _V, _V, _PCE, _F, _I, _V]),
+    "spx_dist_bwd_ce": (C.c_int, [_PP, _V, _I, _I, _I, _V, _V, _V, _V, _V, _V, _I, _V, _V, _V, _PCE, _V, _V, _V, _F, _I, _V]),
+    "spx_ce_fwd": (C.c_int, [_V, _V, C.c_int64, _I, _V, _V, _V, _V]),
+    "spx_ce_bwd": (C.c_int, [_V, _V, _V, _V, C.c_int64, _I, _V, _V]),
 }
 
 _lib: Optional[C.CDLL] = None

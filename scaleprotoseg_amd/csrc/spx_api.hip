@@ -145,7 +145,7 @@ static int dist_fwd_impl(const spx_plan* pl, const void* x, int32_t x_dtype, int
                          const void* packed_bank, const float* packed_p2, const void* packed_head, float* distances,
                          const int32_t* labels, const uint32_t* proto_key, int32_t J, float* cls_dist,
                          float* activations, float* logits, float epsilon, int32_t act_fn, void* stream,
-                         SpxTailFwd tail = SpxTailFwd{nullptr, 0, nullptr}) {
+                         SpxTailFwd tail = SpxTailFwd{nullptr, 0, nullptr}, const spx_ce* ce = nullptr) {
     if (check_plan(pl)) return 1;
     if (!x || !packed_bank || !packed_p2) return fail("spx_dist_fwd: NULL operand");
     if (x_dtype != 0 && x_dtype != 1) return fail("spx_dist_fwd: x_dtype %d (0 = bf16, 1 = fp32)", x_dtype);
@@ -176,6 +176,18 @@ static int dist_fwd_impl(const spx_plan* pl, const void* x, int32_t x_dtype, int
     a.gact = tail.gact;
     a.K2 = tail.K2;
     a.dist_vec = distances && ((uintptr_t)distances & 15) == 0 && HW % 4 == 0;
+    a.ce_labels = nullptr;
+    a.ce_lse = nullptr;
+    a.ce_pred = nullptr;
+    a.ce_partials = nullptr;
+    if (ce) {
+        if (!logits) return fail("spx_dist_fwd_ce: the cross entropy needs the logits output");
+        if (!ce->labels || !ce->lse || !ce->partials) return fail("spx_dist_fwd_ce: NULL labels / lse / partials");
+        a.ce_labels = ce->labels;
+        a.ce_lse = ce->lse;
+        a.ce_pred = ce->pred;
+        a.ce_partials = ce->partials;
+    }
     a.eps = epsilon;
     a.act_fn = act_fn;
     a.dbg = g_dbg;
@@ -221,13 +233,15 @@ static int dist_bwd_impl(const spx_plan* pl, const void* x, int32_t x_dtype, int
                          const void* packed_headT, const float* d_dist, const int32_t* labels,
                          const uint32_t* proto_key, int32_t J, const float* d_cls_dist, const float* d_act,
                          const float* d_logits, void* dx, void* g_out, void* a_out, float epsilon, int32_t act_fn,
-                         void* stream, SpxTailBwd tail = SpxTailBwd{nullptr, 0, nullptr, nullptr}) {
+                         void* stream, SpxTailBwd tail = SpxTailBwd{nullptr, 0, nullptr, nullptr}, const spx_ce* ce = nullptr) {
     if (check_plan(pl)) return 1;
     if (!x || !packed_bank || !packed_p2) return fail("spx_dist_bwd: NULL operand");
     if (x_dtype != 0 && x_dtype != 1) return fail("spx_dist_bwd: x_dtype %d", x_dtype);
     if (B < 1 || HW < 1) return fail("spx_dist_bwd: empty input");
     if (dx && !packed_bankT) return fail("spx_dist_bwd: dx requested without packed bank^T");
-    if (d_logits && !packed_headT) return fail("spx_dist_bwd: d_logits given without packed head^T");
+    if ((d_logits || ce) && !packed_headT) return fail("spx_dist_bwd: d_logits given without packed head^T");
+    if (ce && (d_logits || tail.packed_tailT)) return fail("spx_dist_bwd_ce: the fused cross entropy replaces d_logits and has no tail variant");
+    if (ce && (!ce->labels || !ce->lse || !ce->logits || !ce->coef)) return fail("spx_dist_bwd_ce: NULL labels / lse / logits / coef");
     if ((long long)pl->num_prototypes * HW >= (1LL << 29)) return fail("spx_dist_bwd: P*HW too large for 32-bit offsets");
     const long long tiles = (long long)B * ((HW + SPX_TILE_PX - 1) / SPX_TILE_PX);
     if (tiles > 0x7fffffffLL) return fail("spx_dist_bwd: too many pixel tiles");
@@ -251,6 +265,11 @@ static int dist_bwd_impl(const spx_plan* pl, const void* x, int32_t x_dtype, int
     a.gact = tail.gact;
     a.d_units = tail.d_units;
     a.K2 = tail.K2;
+    a.ce_labels = ce ? ce->labels : nullptr;
+    a.ce_logits = ce ? ce->logits : nullptr;
+    a.ce_lse = ce ? ce->lse : nullptr;
+    a.ce_coef = ce ? ce->coef : nullptr;
+    a.ce_dlogits_out = ce ? ce->d_logits_out : nullptr;
     a.dx = dx;
     a.g_out = (uint16_t*)g_out;
     a.a_out = (uint16_t*)a_out;
@@ -295,6 +314,51 @@ int spx_dist_bwd_cls(const spx_plan* pl, const void* x, int32_t x_dtype, int32_t
     return dist_bwd_impl(pl, x, x_dtype, B, HW, packed_bank, packed_bankT, packed_p2, packed_headT, nullptr,
                          d_class_distances ? labels : nullptr, proto_key, J, d_class_distances, d_act, d_logits, dx,
                          g_out, a_out, epsilon, act_fn, stream);
+}
+
+size_t spx_ce_partials(int32_t B, int32_t HW) { return (size_t)B * ((HW + SPX_TILE_PX - 1) / SPX_TILE_PX) * 4; }
+size_t spx_ce_partials_flat(int64_t M) { return (size_t)((M + 255) / 256) * 4; }
+
+int spx_dist_fwd_ce(const spx_plan* pl, const void* x, int32_t x_dtype, int32_t B, int32_t HW, const void* packed_bank,
+                    const float* packed_p2, const void* packed_head, const int32_t* labels_cls, const uint32_t* proto_key,
+                    int32_t J, float* class_distances, float* distances, float* activations, float* logits,
+                    const spx_ce* ce, float epsilon, int32_t act_fn, void* stream) {
+    if (!ce) return fail("spx_dist_fwd_ce: NULL ce");
+    if (labels_cls) {
+        if (check_cls("spx_dist_fwd_ce", labels_cls, proto_key, J, HW)) return 1;
+        if (!class_distances) return fail("spx_dist_fwd_ce: NULL class_distances");
+        if (distances) return fail("spx_dist_fwd_ce: class-gathered and P-wide distances are exclusive");
+    }
+    return dist_fwd_impl(pl, x, x_dtype, B, HW, packed_bank, packed_p2, packed_head, distances, labels_cls, proto_key,
+                         labels_cls ? J : 0, labels_cls ? class_distances : nullptr, activations, logits, epsilon, act_fn,
+                         stream, SpxTailFwd{nullptr, 0, nullptr}, ce);
+}
+
+int spx_dist_bwd_ce(const spx_plan* pl, const void* x, int32_t x_dtype, int32_t B, int32_t HW, const void* packed_bank,
+                    const void* packed_bankT, const float* packed_p2, const void* packed_headT, const int32_t* labels_cls,
+                    const uint32_t* proto_key, int32_t J, const float* d_dist, const float* d_class_distances,
+                    const float* d_act, const spx_ce* ce, void* dx, void* g_out, void* a_out, float epsilon,
+                    int32_t act_fn, void* stream) {
+    if (!ce) return fail("spx_dist_bwd_ce: NULL ce");
+    if (labels_cls && check_cls("spx_dist_bwd_ce", labels_cls, proto_key, J, HW)) return 1;
+    if (labels_cls && d_dist) return fail("spx_dist_bwd_ce: class-gathered and P-wide distance gradients are exclusive");
+    return dist_bwd_impl(pl, x, x_dtype, B, HW, packed_bank, packed_bankT, packed_p2, packed_headT, d_dist,
+                         (labels_cls && d_class_distances) ? labels_cls : nullptr, proto_key, labels_cls ? J : 0,
+                         labels_cls ? d_class_distances : nullptr, d_act, nullptr, dx, g_out, a_out, epsilon, act_fn, stream,
+                         SpxTailBwd{nullptr, 0, nullptr, nullptr}, ce);
+}
+
+int spx_ce_fwd(const float* logits, const int32_t* labels, int64_t M, int32_t K, float* lse, int32_t* pred, float* partials,
+               void* stream) {
+    if (!logits || !labels || !lse || !partials) return fail("spx_ce_fwd: NULL buffer");
+    if (M < 1 || K < 1 || (M + 255) / 256 > 0x7fffffffLL) return fail("spx_ce_fwd: bad sizes (M=%lld K=%d)", (long long)M, K);
+    return hip_status(spx_launch_ce_fwd(logits, labels, M, K, lse, pred, partials, (hipStream_t)stream), "spx_ce_fwd");
+}
+int spx_ce_bwd(const float* logits, const float* lse, const int32_t* labels, const float* coef, int64_t M, int32_t K,
+               float* d_logits, void* stream) {
+    if (!logits || !lse || !labels || !coef || !d_logits) return fail("spx_ce_bwd: NULL buffer");
+    if (M < 1 || K < 1 || (M * K + 255) / 256 > 0x7fffffffLL) return fail("spx_ce_bwd: bad sizes (M=%lld K=%d)", (long long)M, K);
+    return hip_status(spx_launch_ce_bwd(logits, lse, labels, coef, M, K, d_logits, (hipStream_t)stream), "spx_ce_bwd");
 }
 
 size_t spx_bank_bwd_workspace_bytes(const spx_plan* pl, int32_t B, int32_t HW) {

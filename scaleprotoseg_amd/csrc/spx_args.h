@@ -22,6 +22,11 @@ struct SpxFwdArgs {
     const char* packed_tail;   // W_g A-fragments (spx_pack_group_tail); NULL = no tail
     float* gact;               // [B*HW, U] exp(units) (optional)
     int K2;                    // classes of the tail (<= 32)
+    // fused cross entropy (spx_dist_fwd_ce): statistics of the logits tile, see spx_hip.h
+    const int32_t* ce_labels;  // [B, HW]; NULL = off
+    float* ce_lse;             // [B*HW]
+    int32_t* ce_pred;          // [B*HW] or NULL
+    float* ce_partials;        // [tiles * 4 waves][2]
     float eps;
     int act_fn;
     unsigned long long* dbg;   // diagnostic builds only (SPX_DIAG_STAMPS): per-workgroup phase clocks
@@ -45,6 +50,12 @@ struct SpxBwdArgs {
     const float* gact;          // [B*HW, U] exp(units) of the forward
     float* d_units;             // [B*HW, U] written for the parameter kernel
     int K2;
+    // fused cross entropy (spx_dist_bwd_ce): d_logits = coef * (softmax(logits) - onehot(label)) formed in the prologue
+    const int32_t* ce_labels;   // [B, HW]; NULL = off (then d_logits above is used)
+    const float* ce_logits;     // [B*HW, K] the forward's logits
+    const float* ce_lse;        // [B*HW]
+    const float* ce_coef;       // device scalar
+    float* ce_dlogits_out;      // [B*HW, K] written for the parameter kernel (may be NULL)
     void* dx;
     uint16_t* g_out;
     uint16_t* a_out;
@@ -89,6 +100,10 @@ hipError_t spx_launch_push_argmin(const float* dist, const int32_t* labels, cons
 hipError_t spx_launch_argmin_images(const float* values, int N, int P, int64_t* best, hipStream_t s);
 hipError_t spx_launch_upsample_argext(const float* src, int N, int C, int h, int w, int H, int W, int take_max,
                                       int64_t* idx, float* val, hipStream_t s);
+hipError_t spx_launch_ce_fwd(const float* logits, const int32_t* labels, long long M, int K, float* lse, int32_t* pred,
+                             float* partials, hipStream_t s);
+hipError_t spx_launch_ce_bwd(const float* logits, const float* lse, const int32_t* labels, const float* coef, long long M, int K,
+                             float* d_logits, hipStream_t s);
 hipError_t spx_launch_kld_lse(const uint32_t* keys, const uint64_t* ssum_fx, int n, float* lse, hipStream_t s);
 hipError_t spx_launch_kld(int pass, const float* vals, const int32_t* labels, int B, int J, int HW, int W, int K, const float* t0,
                           const float* t1, const float* t2, const double* scale, void* out, hipStream_t s);

@@ -122,6 +122,7 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
     }
     const bool have_dd = GATHER ? a.d_cls_dist != nullptr : a.d_dist != nullptr;
 
+    const bool have_dl = a.d_logits != nullptr || a.ce_labels != nullptr;     // a gradient reaches the logits
     const bool act_is_log = a.act_fn == 0;
     const float act_c1 = act_is_log ? -(1.0f - a.eps) : -1.0f;
     // dLogits of this lane's pixel as split-bf16 B fragments: element j of k-step c <-> class 16c + 8h + j
@@ -230,9 +231,23 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
         }
         if (BLK) block_flush(a.d_units + (size_t)b * a.HW * K, K);
     } else {
-        const spx_rsrc lr = make_rsrc_pred(a.d_logits ? a.d_logits + (size_t)b * a.HW * K : nullptr);
-        const uint32_t voff_l = (a.d_logits && px_ok) ? ((uint32_t)px * (uint32_t)K + (uint32_t)(8 * h)) * 4u : SPX_OOB;
-        if (BLK && a.d_logits) block_fetch(a.d_logits + (size_t)b * a.HW * K, K);
+        // d_logits of the wave's pixels: given ([px][K] fp32), or - fused cross entropy - formed here from the forward's
+        // logits: coef * (softmax - onehot) on the non-ignored pixels (loss.py:9-48 through autograd), written out once
+        // for the parameter kernel
+        const bool ce = a.ce_labels != nullptr;
+        const float* const lsrc = ce ? a.ce_logits : a.d_logits;
+        const spx_rsrc lr = make_rsrc_pred(lsrc ? lsrc + (size_t)b * a.HW * K : nullptr);
+        const uint32_t voff_l = (lsrc && px_ok) ? ((uint32_t)px * (uint32_t)K + (uint32_t)(8 * h)) * 4u : SPX_OOB;
+        float ce_lse = 0.0f, ce_c = 0.0f;
+        int ce_lab = -1;
+        if (ce) {
+            const uint32_t vo1 = px_ok ? (uint32_t)px * 4u : SPX_OOB;
+            ce_lab = (int)__builtin_amdgcn_raw_buffer_load_b32(make_rsrc_pred(a.ce_labels + (size_t)b * a.HW), vo1, 0, 0);
+            ce_lse = buf_load_f32(make_rsrc_pred(a.ce_lse + (size_t)b * a.HW), vo1, 0);
+            ce_c = (px_ok && (uint32_t)ce_lab < (uint32_t)K) ? *a.ce_coef : 0.0f;
+        }
+        const spx_rsrc dor = make_rsrc_pred((ce && a.ce_dlogits_out) ? a.ce_dlogits_out + (size_t)b * a.HW * K : nullptr);
+        if (BLK && lsrc) block_fetch(lsrc + (size_t)b * a.HW * K, K);
 #pragma unroll
         for (int c = 0; c < NCB * 2; ++c) {
 #pragma unroll
@@ -241,8 +256,16 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
                 // pre-scaled by the constant factor of act'(d) (log: -(1-eps) / ((d+1)(d+eps)); linear: -1), so the
                 // element loop multiplies by 1/((d+1)(d+eps)) only
                 float v;
-                if (BLK) v = (a.d_logits && cls < K) ? bsc[r * K + cls] : 0.0f;
+                if (BLK) v = (lsrc && cls < K) ? bsc[r * K + cls] : 0.0f;
                 else v = buf_load_f32(lr, cls < K ? voff_l : SPX_OOB, (uint32_t)((c * 16 + j) * 4));
+                if (ce) {
+                    v = cls < K ? ce_c * (ce_exp(v - ce_lse) - (cls == ce_lab ? 1.0f : 0.0f)) : 0.0f;
+                    if (BLK) {
+                        if (cls < K) bsc[r * K + cls] = v;
+                    } else {
+                        buf_store_f32(v, dor, cls < K ? voff_l : SPX_OOB, (uint32_t)((c * 16 + j) * 4));
+                    }
+                }
                 v *= act_c1;
                 __bf16 hi, lo;
                 split_bf16(v, hi, lo);
@@ -250,6 +273,7 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
                 dllo[c][j] = lo;
             }
         }
+        if (BLK && ce && a.ce_dlogits_out) block_flush(a.ce_dlogits_out + (size_t)b * a.HW * K, K);
     }
     if (BLK) __syncthreads();      // the scratch sits in the main-loop stages: every wave is done with it before they fill
 
@@ -268,7 +292,7 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
     auto consts_issue = [&](int panel) {
 #pragma unroll
         for (int i = 0; i < HPASS; ++i)
-            hreg[i] = buf_load_b128(htp, a.d_logits ? (uint32_t)(i * 4096 + tid * 16) : SPX_OOB, (uint32_t)(panel * head_lds));
+            hreg[i] = buf_load_b128(htp, have_dl ? (uint32_t)(i * 4096 + tid * 16) : SPX_OOB, (uint32_t)(panel * head_lds));
         p2reg = buf_load_f32(p2p, tid < NPB * 32 ? (uint32_t)tid * 4u : SPX_OOB, (uint32_t)(panel * NPB * 32 * 4));
         if (GATHER) keyreg = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(keyr, tid < NPB * 32 ? (uint32_t)tid * 4u : SPX_OOB, (uint32_t)(panel * NPB * 32 * 4), 0);
     };
@@ -380,7 +404,7 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
                 f32x16 ga;        // (dAct + dLogits.W) * c1, c1 = the constant factor of act'(d)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) ga[i] = 0.0f;
-                if (a.d_logits) {
+                if (have_dl) {
 #pragma unroll
                     for (int c = 0; c < ncstep; ++c) {
                         bf16x8 whi, wlo;

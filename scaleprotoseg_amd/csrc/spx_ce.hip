@@ -1,0 +1,66 @@
+// Stand-alone pixel-wise cross entropy over [M, K] logits (segmentation/model/loss.py:9-48): the arithmetic of the
+// fused epilogue (spx_fwd_impl.h) / prologue (spx_bwd_impl.h) for heads those kernels do not carry (more than 160
+// classes, the grouping tail) and for callers that hold logits of their own.
+#include "spx_args.h"
+#include "spx_common.h"
+
+#define SPX_CE_THREADS 256
+
+// one pixel per thread: logsumexp, argmax (lowest index on ties), label's logit; per-wave (loss sum, count) partials
+__global__ __launch_bounds__(SPX_CE_THREADS) void spx_ce_fwd_kernel(const float* __restrict__ logits, const int32_t* __restrict__ labels,
+                                                                  long long M, int K, float* __restrict__ lse_out,
+                                                                  int32_t* __restrict__ pred, float* __restrict__ partials) {
+    const long long m_ = (long long)blockIdx.x * SPX_CE_THREADS + threadIdx.x;
+    const bool in = m_ < M;
+    const float* row = logits + (in ? m_ : 0) * K;
+    const int lab = in ? labels[m_] : -1;
+    const bool valid = in && (unsigned)lab < (unsigned)K;
+    float mx = -3.0e38f;
+    int best = 0x7fffffff;
+    for (int k = 0; k < K; ++k) ce_best(row[k], k, mx, best);
+    float ssum = 0.0f;
+    for (int k = 0; k < K; ++k) ssum += ce_exp(row[k] - mx);
+    const float lse = mx + ce_log(ssum);
+    if (in) {
+        lse_out[m_] = lse;
+        if (pred) pred[m_] = best;
+    }
+    float lossv = valid ? lse - row[lab] : 0.0f, cnt = valid ? 1.0f : 0.0f;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        lossv += __shfl_xor(lossv, off);
+        cnt += __shfl_xor(cnt, off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        float* const pp = partials + ((size_t)blockIdx.x * (SPX_CE_THREADS / 64) + (threadIdx.x >> 6)) * 2;
+        pp[0] = lossv;
+        pp[1] = cnt;
+    }
+}
+
+// d_logits[m, k] = coef * (softmax - onehot) on the non-ignored pixels, 0 elsewhere
+__global__ __launch_bounds__(SPX_CE_THREADS) void spx_ce_bwd_kernel(const float* __restrict__ logits, const float* __restrict__ lse,
+                                                                  const int32_t* __restrict__ labels, const float* __restrict__ coef,
+                                                                  long long M, int K, float* __restrict__ d_logits) {
+    const long long i = (long long)blockIdx.x * SPX_CE_THREADS + threadIdx.x;
+    if (i >= M * K) return;
+    const long long m_ = i / K;
+    const int k = (int)(i - m_ * K);
+    const int lab = labels[m_];
+    const bool valid = (unsigned)lab < (unsigned)K;
+    d_logits[i] = valid ? *coef * (ce_exp(logits[i] - lse[m_]) - (k == lab ? 1.0f : 0.0f)) : 0.0f;
+}
+
+hipError_t spx_launch_ce_fwd(const float* logits, const int32_t* labels, long long M, int K, float* lse, int32_t* pred,
+                             float* partials, hipStream_t s) {
+    const unsigned grid = (unsigned)((M + SPX_CE_THREADS - 1) / SPX_CE_THREADS);
+    hipLaunchKernelGGL(spx_ce_fwd_kernel, dim3(grid), dim3(SPX_CE_THREADS), 0, s, logits, labels, M, K, lse, pred, partials);
+    return hipGetLastError();
+}
+hipError_t spx_launch_ce_bwd(const float* logits, const float* lse, const int32_t* labels, const float* coef, long long M, int K,
+                             float* d_logits, hipStream_t s) {
+    const long long n = M * K;
+    const unsigned grid = (unsigned)((n + SPX_CE_THREADS - 1) / SPX_CE_THREADS);
+    hipLaunchKernelGGL(spx_ce_bwd_kernel, dim3(grid), dim3(SPX_CE_THREADS), 0, s, logits, lse, labels, coef, M, K, d_logits);
+    return hipGetLastError();
+}

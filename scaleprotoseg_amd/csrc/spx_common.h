@@ -155,6 +155,17 @@ __device__ __forceinline__ float act_log_grad(float d, float eps) {
     return -(1.0f - eps) * __builtin_amdgcn_rcpf((d + 1.0f) * (d + eps));
 }
 
+// cross entropy helpers (segmentation/model/loss.py:9-48): running maximum with the LOWEST class index on ties
+// (torch.argmax's contract) and softmax pieces through the raw exp2 / log2 units
+__device__ __forceinline__ void ce_best(float v, int cls, float& m, int& best) {
+    if (v > m || (v == m && cls < best)) {
+        m = v;
+        best = cls;
+    }
+}
+__device__ __forceinline__ float ce_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504089f); }
+__device__ __forceinline__ float ce_log(float x) { return __builtin_amdgcn_logf(x) * 0.69314718056f; }
+
 // monotone float -> uint32 key (total order incl. negatives), for packed (value,index) minima
 __device__ __forceinline__ uint32_t float_key(float v) {
     uint32_t u = __float_as_uint(v);

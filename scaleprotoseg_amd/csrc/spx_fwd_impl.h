@@ -393,6 +393,51 @@ __global__ __launch_bounds__(256 * SPLIT, (NPB == 2 && NCB == 1 ? 3 : SPX_FWD_WA
             if (acc_row(reg, h) < K2) bsc[r * K2 + acc_row(reg, h)] = acc2[reg];
         block_flush(a.logits + (size_t)b * a.HW * K2, K2);
     } else if (want_head && ph == 0) {
+        if (a.ce_labels) {
+            // fused cross entropy: logsumexp, the label's logit and the argmax of this lane's pixel while the logits
+            // tile is in registers (rows = classes, the two lane halves hold different rows of the same pixel)
+            const spx_rsrc clr = make_rsrc_pred(a.ce_labels + (size_t)b * a.HW);
+            const int lab = (int)__builtin_amdgcn_raw_buffer_load_b32(clr, px_ok ? (uint32_t)px * 4u : SPX_OOB, 0, 0);
+            const bool valid = px_ok && (uint32_t)lab < (uint32_t)K;
+            float m = -3.0e38f;
+            int best = 0x7fffffff;
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int cls = cb * 32 + acc_row(reg, h);
+                    if (cls < K) ce_best(accl[cb][reg], cls, m, best);
+                }
+            ce_best(__shfl_xor(m, 32), __shfl_xor(best, 32), m, best);
+            float ssum = 0.0f, picked = 0.0f;
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int cls = cb * 32 + acc_row(reg, h);
+                    if (cls < K) {
+                        ssum += ce_exp(accl[cb][reg] - m);
+                        picked += cls == lab ? accl[cb][reg] : 0.0f;
+                    }
+                }
+            ssum += __shfl_xor(ssum, 32);
+            picked += __shfl_xor(picked, 32);
+            const float lse = m + ce_log(ssum);
+            const uint32_t vo1 = (px_ok && h == 0) ? (uint32_t)px * 4u : SPX_OOB;
+            buf_store_f32(lse, make_rsrc_pred(a.ce_lse + (size_t)b * a.HW), vo1, 0);
+            if (a.ce_pred) buf_store_f32(__int_as_float(best), make_rsrc_pred(a.ce_pred + (size_t)b * a.HW), vo1, 0);
+            float lossv = (valid && h == 0) ? lse - picked : 0.0f, cnt = (valid && h == 0) ? 1.0f : 0.0f;
+#pragma unroll
+            for (int off = 16; off >= 1; off >>= 1) {
+                lossv += __shfl_xor(lossv, off);
+                cnt += __shfl_xor(cnt, off);
+            }
+            if (lane == 0) {
+                float* const pp = a.ce_partials + ((size_t)blockIdx.x * 4 + pg) * 2;
+                pp[0] = lossv;
+                pp[1] = cnt;
+            }
+        }
         if (NCB <= 2) {
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb)

@@ -76,6 +76,57 @@ class BankLayout:
 
 
 @dataclass
+class FusedCrossEntropy:
+    """Cross entropy computed in the logits epilogue: ``loss`` (scalar, differentiable: mean over the non-ignored pixels,
+    segmentation/model/loss.py:9-48), ``pred`` int32 [B*H*W] (argmax class), ``labels`` int32 [B, H*W] it was computed for
+    (class 0..K-1; anything else was ignored)."""
+
+    loss: torch.Tensor
+    pred: torch.Tensor
+    labels: torch.Tensor
+    target: Optional[torch.Tensor] = None      # the caller's label tensor (0 = void, 1..K) the labels were derived from
+
+
+def cross_entropy_from_logits(logits: torch.Tensor, labels0: torch.Tensor) -> FusedCrossEntropy:
+    """The same cross entropy as stand-alone HIP kernels over any [..., K] logits tensor on the GPU (heads the fused
+    kernels do not carry: more than 160 classes, the grouping tail).  ``labels0``: class 0..K-1, anything else ignored."""
+    loss, pred, lab = _CrossEntropyFn.apply(logits, labels0)
+    return FusedCrossEntropy(loss, pred, lab)
+
+
+class _CrossEntropyFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, labels0):
+        lib = _lib.load()
+        if not logits.is_cuda:
+            raise SpxError("scaleprotoseg_amd runs on an AMD GPU only; there is no CPU fallback")
+        K = int(logits.shape[-1])
+        lg = logits.detach().reshape(-1, K).contiguous().float()
+        M = int(lg.shape[0])
+        lab = labels0.to(device=lg.device, dtype=torch.int32).reshape(-1).contiguous()
+        if lab.numel() != M:
+            raise SpxError(f"{lab.numel()} labels for {M} logit rows")
+        lse = torch.empty((M,), dtype=torch.float32, device=lg.device)
+        pred = torch.empty((M,), dtype=torch.int32, device=lg.device)
+        partials = torch.empty((lib.spx_ce_partials_flat(M), 2), dtype=torch.float32, device=lg.device)
+        _lib.check(lib.spx_ce_fwd(_lib.ptr(lg), _lib.ptr(lab), M, K, _lib.ptr(lse), _lib.ptr(pred), _lib.ptr(partials), _lib.stream_ptr()))
+        tot = partials.sum(dim=0)
+        ctx.save_for_backward(lg, lse, lab, tot)
+        ctx.shape = tuple(logits.shape)
+        ctx.mark_non_differentiable(pred, lab)
+        return tot[0] / tot[1], pred, lab
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_pred=None, _g_lab=None):
+        lib = _lib.load()
+        lg, lse, lab, tot = ctx.saved_tensors
+        coef = (g_loss.float() / tot[1]).reshape(1).contiguous()
+        dl = torch.empty_like(lg)
+        _lib.check(lib.spx_ce_bwd(_lib.ptr(lg), _lib.ptr(lse), _lib.ptr(lab), _lib.ptr(coef), lg.shape[0], lg.shape[1], _lib.ptr(dl), _lib.stream_ptr()))
+        return dl.reshape(ctx.shape), None
+
+
+@dataclass
 class ClassGather:
     """Class-gathered distance mode: per pixel, only the distances to its own class's prototypes.
 
@@ -224,8 +275,9 @@ class _Packs:
 
 class _ProtoHeadFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, bank, head, layout, want_dist, want_act, epsilon, act_fn, gather=None, tail=None):
+    def forward(ctx, x, bank, head, layout, want_dist, want_act, epsilon, act_fn, gather=None, tail=None, ce_labels=None):
         lib = _lib.load()
+        ctx.set_materialize_grads(False)      # an output nobody differentiates arrives as None, not as a zero tensor
         B, HW = _check_x(x, layout)
         P, K = layout.num_prototypes, layout.num_classes
         xd = _x_dtype_code(x)
@@ -251,6 +303,18 @@ class _ProtoHeadFn(torch.autograd.Function):
         act = torch.empty((B * HW, P), **f32) if want_act else None
         logits = torch.empty((B * HW, K), **f32) if head is not None else None
         gact = None
+        ce = ce_state = None
+        if ce_labels is not None:
+            if head is None or tail2d is not None:
+                raise SpxError("the fused cross entropy needs the plain class head (no grouping tail)")
+            if tuple(ce_labels.shape) != (B, HW) or ce_labels.dtype != torch.int32 or not ce_labels.is_cuda:
+                raise SpxError(f"ce labels must be int32 [{B}, {HW}] on the GPU (class 0..K-1, anything else = ignored)")
+            ce_labels = ce_labels.contiguous()
+            lse = torch.empty((B * HW,), **f32)
+            pred = torch.empty((B * HW,), dtype=torch.int32, device=x.device)
+            partials = torch.empty((lib.spx_ce_partials(B, HW), 2), **f32)
+            ce = _lib.SpxCe(labels=_lib.ptr(ce_labels), lse=_lib.ptr(lse), pred=_lib.ptr(pred), partials=_lib.ptr(partials))
+            ce_state = (ce_labels, lse, pred, partials)
         if tail2d is not None:
             K2 = int(tail2d.shape[0])
             logits = torch.empty((B * HW, K2), **f32)
@@ -270,7 +334,17 @@ class _ProtoHeadFn(torch.autograd.Function):
             # slots no prototype maps to (and pixels without a class) stay 0
             dist = torch.zeros((B, gather.width, HW), **f32)
             with _timed("spx_dist_fwd"):
-                _lib.check(
+                if ce is not None:
+                    _lib.check(
+                        lib.spx_dist_fwd_ce(
+                            C.byref(plan), _lib.ptr(x), xd, B, HW, _lib.ptr(packs.bank), _lib.ptr(packs.p2),
+                            _lib.ptr(packs.head), _lib.ptr(gather.labels), _lib.ptr(gather.keys), gather.width,
+                            _lib.ptr(dist), None, _lib.ptr(act), _lib.ptr(logits), C.byref(ce), float(epsilon),
+                            ACT_FN[act_fn], _lib.stream_ptr(),
+                        )
+                    )
+                else:
+                  _lib.check(
                     lib.spx_dist_fwd_cls(
                         C.byref(plan), _lib.ptr(x), xd, B, HW, _lib.ptr(packs.bank), _lib.ptr(packs.p2),
                         _lib.ptr(packs.head), _lib.ptr(gather.labels), _lib.ptr(gather.keys), gather.width,
@@ -281,13 +355,22 @@ class _ProtoHeadFn(torch.autograd.Function):
         else:
             dist = torch.empty((B, P) + tuple(x.shape[2:]), **f32) if want_dist else None
             with _timed("spx_dist_fwd"):
-                _lib.check(
-                    lib.spx_dist_fwd(
-                        C.byref(plan), _lib.ptr(x), xd, B, HW, _lib.ptr(packs.bank), _lib.ptr(packs.p2),
-                        _lib.ptr(packs.head), _lib.ptr(dist), _lib.ptr(act), _lib.ptr(logits), float(epsilon),
-                        ACT_FN[act_fn], _lib.stream_ptr(),
+                if ce is not None:
+                    _lib.check(
+                        lib.spx_dist_fwd_ce(
+                            C.byref(plan), _lib.ptr(x), xd, B, HW, _lib.ptr(packs.bank), _lib.ptr(packs.p2),
+                            _lib.ptr(packs.head), None, None, 0, None, _lib.ptr(dist), _lib.ptr(act), _lib.ptr(logits),
+                            C.byref(ce), float(epsilon), ACT_FN[act_fn], _lib.stream_ptr(),
+                        )
                     )
-                )
+                else:
+                    _lib.check(
+                        lib.spx_dist_fwd(
+                            C.byref(plan), _lib.ptr(x), xd, B, HW, _lib.ptr(packs.bank), _lib.ptr(packs.p2),
+                            _lib.ptr(packs.head), _lib.ptr(dist), _lib.ptr(act), _lib.ptr(logits), float(epsilon),
+                            ACT_FN[act_fn], _lib.stream_ptr(),
+                        )
+                    )
         ctx.gather = gather
         ctx.gact = gact
         ctx.tail2d = tail2d
@@ -298,11 +381,19 @@ class _ProtoHeadFn(torch.autograd.Function):
         ctx.bank_shape = tuple(bank.shape)
         outs = tuple(t if t is not None else x.new_empty(0) for t in (logits, dist, act))
         extra = gact if tail2d is not None else x.new_empty(0)     # exp(units): an output for the caller, no gradient path
-        ctx.mark_non_differentiable(*([o for o, h in zip(outs, ctx.have) if not h] + [extra]))
-        return outs + (extra,)
+        ce_loss, ce_pred = x.new_empty(0), x.new_empty(0)
+        ctx.ce_state = ctx.ce_count = None
+        if ce_state is not None:
+            tot = ce_state[3].sum(dim=0)                          # (sum of the pixel losses, non-ignored pixels): fixed order
+            ce_loss = tot[0] / tot[1]                               # 0 / 0 = nan when every pixel is ignored, as torch's mean
+            ce_pred = ce_state[2]
+            ctx.ce_state, ctx.ce_count, ctx.ce_logits = ce_state, tot[1], logits
+        ctx.mark_non_differentiable(*([o for o, h in zip(outs, ctx.have) if not h] + [extra, ce_pred]
+                                      + ([ce_loss] if ce_state is None else [])))
+        return outs + (extra, ce_loss, ce_pred)
 
     @staticmethod
-    def backward(ctx, g_logits, g_dist, g_act, _g_gact=None):
+    def backward(ctx, g_logits, g_dist, g_act, _g_gact=None, g_ce=None, _g_pred=None):
         lib = _lib.load()
         x, bank2d, head2d = ctx.saved_tensors
         layout, plan, packs = ctx.layout, ctx.plan, ctx.packs
@@ -319,11 +410,27 @@ class _ProtoHeadFn(torch.autograd.Function):
         dev = x.device
         xd = _x_dtype_code(x)
         scr = lib.spx_bwd_scratch_bytes(pp, B, HW)
-        need_head = need_head and gl is not None
+        with_ce = ctx.ce_state is not None and g_ce is not None
+        need_head = need_head and (gl is not None or with_ce)
+        s = _lib.stream_ptr()
+        ce = d_logits_ce = None
+        if with_ce:
+            ce_labels, lse, _, _ = ctx.ce_state
+            coef = (g_ce.float() / ctx.ce_count).reshape(1).contiguous()       # on the device: no host read-back
+            if gl is not None:
+                # the logits ALSO carry a gradient of their own: form the cross entropy's part with the stand-alone
+                # kernel, add, and take the ordinary d_logits path
+                dl = torch.empty_like(ctx.ce_logits)
+                _lib.check(lib.spx_ce_bwd(_lib.ptr(ctx.ce_logits), _lib.ptr(lse), _lib.ptr(ce_labels), _lib.ptr(coef),
+                                          B * HW, K, _lib.ptr(dl), s))
+                gl = gl.reshape(dl.shape) + dl
+            else:
+                d_logits_ce = torch.empty_like(ctx.ce_logits) if need_head else None
+                ce = _lib.SpxCe(labels=_lib.ptr(ce_labels), lse=_lib.ptr(lse), logits=_lib.ptr(ctx.ce_logits),
+                                coef=_lib.ptr(coef), d_logits_out=_lib.ptr(d_logits_ce))
         dx = torch.empty_like(x) if need_x else None
         g_scr = torch.empty(scr, dtype=torch.uint8, device=dev) if need_bank else None
         a_scr = torch.empty(scr, dtype=torch.uint8, device=dev) if need_head else None
-        s = _lib.stream_ptr()
         tail2d, d_units, d_tail = ctx.tail2d, None, None
         if tail2d is not None and gl is None:
             raise SpxError("backward through the fused group tail without a logits gradient")
@@ -336,6 +443,17 @@ class _ProtoHeadFn(torch.autograd.Function):
                         _lib.ptr(packs.headT), _lib.ptr(packs.tailT), int(tail2d.shape[0]), _lib.ptr(ctx.gact),
                         _lib.ptr(gd), _lib.ptr(ga), _lib.ptr(gl), _lib.ptr(d_units), _lib.ptr(dx), _lib.ptr(g_scr),
                         _lib.ptr(a_scr), ctx.epsilon, ACT_FN[ctx.act_fn], s,
+                    )
+                )
+            elif ce is not None:
+                g = ctx.gather
+                _lib.check(
+                    lib.spx_dist_bwd_ce(
+                        pp, _lib.ptr(x), xd, B, HW, _lib.ptr(packs.bank), _lib.ptr(packs.bankT), _lib.ptr(packs.p2),
+                        _lib.ptr(packs.headT), _lib.ptr(g.labels) if g is not None else None,
+                        _lib.ptr(g.keys) if g is not None else None, g.width if g is not None else 0,
+                        _lib.ptr(gd) if g is None else None, _lib.ptr(gd) if g is not None else None, _lib.ptr(ga),
+                        C.byref(ce), _lib.ptr(dx), _lib.ptr(g_scr), _lib.ptr(a_scr), ctx.epsilon, ACT_FN[ctx.act_fn], s,
                     )
                 )
             elif ctx.gather is not None:
@@ -360,6 +478,8 @@ class _ProtoHeadFn(torch.autograd.Function):
             if ctx.needs_input_grad[9]:
                 d_tail = _pixel_outer(gl, ctx.gact)   # d W_g [K2, U]: one small product over the pixels
             gl = d_units                              # the parameter kernel's d_logits operand
+        if ce is not None:
+            gl = d_logits_ce                          # formed by the pixel kernel's prologue
         d_bank = d_head = None
         if need_bank or need_head:
             ws = torch.empty(lib.spx_bank_bwd_workspace_bytes(pp, B, HW) // 4, dtype=torch.float32, device=dev)
@@ -380,7 +500,7 @@ class _ProtoHeadFn(torch.autograd.Function):
             d_head = torch.zeros_like(head2d)
         if tail2d is not None and ctx.needs_input_grad[9] and d_tail is None:
             d_tail = torch.zeros_like(tail2d)
-        return dx, d_bank, d_head, None, None, None, None, None, None, d_tail
+        return dx, d_bank, d_head, None, None, None, None, None, None, d_tail, None
 
 
 def proto_head_forward(
@@ -395,6 +515,7 @@ def proto_head_forward(
     activation: str = "log",
     class_gather: Optional[ClassGather] = None,
     group_tail: Optional[torch.Tensor] = None,
+    ce_labels: Optional[torch.Tensor] = None,
 ):
     """(logits [B*H*W, K] | None, distances [B,P,H,W] | None, activations [B*H*W, P] | None).
 
@@ -404,10 +525,15 @@ def proto_head_forward(
         raise SpxError(f"activation {activation!r} has no fused kernel (use 'log' or 'linear')")
     if not x.is_cuda:
         raise SpxError("scaleprotoseg_amd runs on an AMD GPU only; there is no CPU fallback")
-    logits, dist, act, gact = _ProtoHeadFn.apply(
+    logits, dist, act, gact, ce_loss, ce_pred = _ProtoHeadFn.apply(
         x, bank, head, layout, want_distances or class_gather is not None, want_activations, epsilon, activation,
-        class_gather, group_tail,
+        class_gather, group_tail, ce_labels,
     )
+    if ce_labels is not None:
+        # fused cross entropy: a 4th entry (loss, argmax prediction per pixel); the loss is
+        # differentiable through the same backward as the logits
+        return (logits, dist if (want_distances or class_gather is not None) else None,
+                act if want_activations else None, FusedCrossEntropy(ce_loss, ce_pred, ce_labels))
     if group_tail is not None:
         # fused grouping head (model_multiscale_group.py:283-308): logits = exp(act . head^T) . group_tail^T;
         # the 4th entry is exp(act . head^T) [B*H*W, U] (cat of compute_group's list), not differentiable here

@@ -72,22 +72,46 @@ def _pixel_outer(a: torch.Tensor, b: torch.Tensor, chunk: int = 4096) -> torch.T
 class PixelWiseCrossEntropyLoss(nn.Module):
     """Drop-in for segmentation/model/loss.py:9-48: cross entropy over the [..., K] logits with labels shifted by one
     (1..K -> 0..K-1; the training modules pass ``ignore_index=-1`` so that void = 0 is skipped,
-    module_multiscale.py:162-164), optionally with the per-pixel correctness of the non-ignored pixels."""
+    module_multiscale.py:162-164), optionally with the per-pixel correctness of the non-ignored pixels.
 
-    def __init__(self, ignore_index: int = 255, return_correct: bool = False) -> None:
+    On GPU tensors the loss runs in HIP: if the logits come from ``forward_from_conv_features(..., ce_target=target)``
+    the value was already computed in the logits epilogue (``logits.spx_ce``, SURVEY.md 8f-1) and is returned as is;
+    otherwise the stand-alone kernels of csrc/spx_ce.hip run.  Labels outside 0..K-1 other than ``ignore_index`` make
+    torch raise; here they are ignored.  ``torch_formulation`` (keyword-only, not in the reference) allows the stock
+    torch form for tensors that are not on the GPU - off by default: no silent fallback."""
+
+    def __init__(self, ignore_index: int = 255, return_correct: bool = False, *, torch_formulation: bool = False) -> None:
         super().__init__()
         self.loss = nn.CrossEntropyLoss(ignore_index=ignore_index)
         self.return_correct = return_correct
         self.ignore_index = ignore_index
+        self.torch_formulation = torch_formulation
 
     def forward(self, predicted_logits: torch.Tensor, target_labels: torch.Tensor):
-        predicted_logits = predicted_logits.reshape(-1, predicted_logits.size(-1))
-        target_labels = target_labels.reshape(-1) - 1                                  # loss.py:32
+        fused = getattr(predicted_logits, "spx_ce", None)
+        K = predicted_logits.size(-1)
+        if predicted_logits.is_cuda:
+            from .functional import cross_entropy_from_logits
+
+            labels0 = target_labels.reshape(-1).to(predicted_logits.device) - 1                  # loss.py:32
+            ignores_a_class = self.ignore_index is not None and 0 <= self.ignore_index < K
+            if fused is None or fused.target is not target_labels or ignores_a_class:
+                lab = labels0 if not ignores_a_class else torch.where(labels0 == self.ignore_index, torch.full_like(labels0, -1), labels0)
+                fused = cross_entropy_from_logits(predicted_logits, lab)
+            if not self.return_correct:
+                return fused.loss
+            correct = fused.pred.reshape(-1).to(labels0.dtype) == labels0
+            mask = (labels0 != self.ignore_index).nonzero().squeeze()                             # loss.py:43-46
+            return fused.loss, correct[mask]
+        if not self.torch_formulation:
+            raise SpxError(f"cross entropy: logits on {predicted_logits.device}; the loss runs on the GPU "
+                           "(pass torch_formulation=True to allow the stock torch form - there is no silent fallback)")
+        predicted_logits = predicted_logits.reshape(-1, K)
+        target_labels = target_labels.reshape(-1) - 1
         loss = self.loss(predicted_logits, target_labels)
         if not self.return_correct:
             return loss
-        predicted_labels = torch.argmax(predicted_logits, dim=-1)
-        correct = predicted_labels == target_labels
+        correct = torch.argmax(predicted_logits, dim=-1) == target_labels
         mask = (target_labels != self.ignore_index).nonzero().squeeze()
         return loss, correct[mask]
 

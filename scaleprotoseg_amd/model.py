@@ -40,14 +40,14 @@ class PPNet(PPNetMultiScale):
     def _l2_convolution(self, x):
         return self._scale_l2_convolution(x)  # model.py:250-268
 
-    def forward_from_conv_features(self, conv_features, return_activations=False, return_distances=False):
+    def forward_from_conv_features(self, conv_features, return_activations=False, return_distances=False, **extensions):
         if isinstance(conv_features, list):
             return [self.forward_from_conv_features(c) for c in conv_features]
         if not (hasattr(self, "patch_classification") and self.patch_classification):
             # ProtoPNet global-min-pool branch (model.py:331-344): unused by every config, not built
             raise NotImplementedError("PPNet without patch_classification is outside the hot path")
         return super().forward_from_conv_features(conv_features, return_activations=return_activations,
-                                                  return_distances=False)
+                                                  return_distances=False, **extensions)
 
     def forward_with_features(self, x, **kwargs):
         conv = self.conv_features(x)  # model.py:317-326

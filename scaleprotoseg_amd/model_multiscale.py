@@ -15,8 +15,8 @@ from typing import Any, Dict, List, Optional, Tuple, Union
 import torch
 import torch.nn as nn
 
-from .functional import (MAX_FUSED_HEAD_ROWS, BankLayout, ClassGather, SpxError, class_gather_table, proto_head_forward,
-                         wide_linear)
+from .functional import (MAX_FUSED_HEAD_ROWS, BankLayout, ClassGather, SpxError, class_gather_table,
+                         cross_entropy_from_logits, proto_head_forward, wide_linear)
 from .loss import ClassDistances
 
 
@@ -229,7 +229,8 @@ class PPNetMultiScale(_PrototypeBankMixin, nn.Module):
         return self.last_layer(prototype_activations)  # :243-244 (callers outside the fused path)
 
     def forward_from_conv_features(
-        self, conv_features, return_activations: bool = False, return_distances: bool = False, target_labels=None
+        self, conv_features, return_activations: bool = False, return_distances: bool = False, target_labels=None,
+        ce_target=None,
     ) -> Any:
         """Same return-tuple rules as model_multiscale.py:340-388.
 
@@ -237,7 +238,10 @@ class PPNetMultiScale(_PrototypeBankMixin, nn.Module):
         the tensor the training step passes to the losses, module_multiscale.py:234-242) the distance entry of the
         tuple is a ``ClassDistances`` ([B, J, H*W]: per pixel only the distances to its own class's prototypes, the
         entries KLDLoss reads) and the P-wide fp32 map is never written; ``scaleprotoseg_amd.loss.KLDLoss`` takes it
-        as is."""
+        as is.  With ``ce_target`` (same convention and grid) the pixel-wise cross entropy of the logits is computed in the
+        kernel's logits epilogue and travels on the returned logits as ``logits.spx_ce`` (loss, argmax prediction);
+        ``scaleprotoseg_amd.loss.PixelWiseCrossEntropyLoss(ignore_index=-1)`` called with that ``logits`` and the same
+        ``ce_target`` returns it instead of running a second pass (loss.py:9-48, caller module_multiscale.py:239)."""
         if isinstance(conv_features, list):
             return [self.forward_from_conv_features(c) for c in conv_features]  # flags dropped, as in :359
         if not (hasattr(self, "patch_classification") and self.patch_classification):
@@ -254,16 +258,30 @@ class PPNetMultiScale(_PrototypeBankMixin, nn.Module):
             if tuple(target_labels.shape) != (B, H, W):
                 raise SpxError(f"target_labels must be [{B}, {H}, {W}] (latent grid), got {tuple(target_labels.shape)}")
             gather = self._class_gather(target_labels, layout, conv_features.device)
-        logits, dist, act = proto_head_forward(
+        ce_labels = fused_ce = None
+        if ce_target is not None:
+            if tuple(ce_target.shape) != (B, H, W):
+                raise SpxError(f"ce_target must be [{B}, {H}, {W}] (latent grid), got {tuple(ce_target.shape)}")
+            ce_labels = (ce_target.reshape(B, -1).to(device=conv_features.device, dtype=torch.int32) - 1).contiguous()
+        out = proto_head_forward(
             conv_features, self.prototype_vectors, None if wide else self.last_layer.weight, layout,
             want_distances=want_dist and gather is None, want_activations=return_activations or wide,
             epsilon=self.epsilon, activation=self.prototype_activation_function, class_gather=gather,
+            ce_labels=None if wide else ce_labels,
         )
+        logits, dist, act = out[:3]
         if wide:      # the kernel hands out the activations once; the 182-row head is a plain library GEMM on them
             logits = wide_linear(act, self.last_layer.weight)
+            if ce_labels is not None:
+                fused_ce = cross_entropy_from_logits(logits, ce_labels)
+        elif ce_labels is not None:
+            fused_ce = out[3]
         if gather is not None:
             dist = ClassDistances(values=dist, labels=gather.labels, table=gather.table, grid=(H, W))
         logits = logits.reshape(B, H, W, -1)
+        if fused_ce is not None:
+            fused_ce.target = ce_target
+            logits.spx_ce = fused_ce
         if return_activations and not return_distances:
             return logits, act
         if return_activations and return_distances:

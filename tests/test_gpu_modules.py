@@ -587,3 +587,124 @@ def test_wide_class_heads(K, G):
     _grad_close(net.prototype_vectors.grad, p0.grad, "dPrototypes")
     head = net.last_layer.weight if G is None else net.last_layer_group.weight
     _grad_close(head.grad, w0.grad, "dHead")
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# cross entropy (segmentation/model/loss.py:9-48): stand-alone HIP kernels pinned to the reference's golden, and the form
+# fused into the logits epilogue / the backward's d_logits prologue
+# ------------------------------------------------------------------------------------------------------------------
+def test_cross_entropy_kernels_match_reference_golden(golden):
+    from scaleprotoseg_amd.loss import PixelWiseCrossEntropyLoss
+
+    dev = _dev()
+    g = golden("kld_loss")
+    lg = torch.from_numpy(g["ce_logits"]).to(dev).requires_grad_(True)
+    tgt = torch.from_numpy(g["ce_target"]).to(dev)
+    ce, correct = PixelWiseCrossEntropyLoss(ignore_index=-1, return_correct=True)(lg, tgt)
+    ce.backward()
+    assert abs(ce.item() - float(g["ce_loss"])) <= 1e-5 * max(1.0, abs(float(g["ce_loss"])))
+    scale = np.abs(g["ce_grad"]).max()
+    assert np.abs(lg.grad.cpu().numpy() - g["ce_grad"]).max() <= 1e-5 * scale
+    np.testing.assert_array_equal(correct.cpu().numpy().astype(np.int64), g["ce_correct"])
+    # exact ties: argmax takes the lowest class index (torch.argmax's contract)
+    tie = torch.zeros(4, 7, device=dev)
+    tie[1, 3] = tie[1, 5] = 2.0
+    from scaleprotoseg_amd.functional import cross_entropy_from_logits
+    out = cross_entropy_from_logits(tie, torch.tensor([0, 3, -1, 9], device=dev))
+    assert out.pred.tolist() == [0, 3, 0, 0]
+    ref = torch.nn.functional.cross_entropy(tie.cpu(), torch.tensor([0, 3, -1, -1]), ignore_index=-1)
+    assert abs(out.loss.item() - ref.item()) <= 1e-6
+
+
+@pytest.mark.parametrize("shape,x_dtype,gather", [
+    ((2, 4, 64, 228, 19, 17, 19), torch.float32, False),
+    ((1, 1, 256, 190, 19, 16, 64), torch.bfloat16, False),
+    ((2, 4, 16, 40, 5, 9, 11), torch.float32, True),
+    ((1, 1, 64, 210, 64, 8, 16), torch.float32, False),       # 64 classes: two class blocks
+    ((1, 4, 64, 600, 150, 5, 8), torch.float32, False),       # 150 classes: five class blocks (strided logits path)
+])
+def test_fused_cross_entropy_through_the_module(shape, x_dtype, gather):
+    import scaleprotoseg_amd as spx
+    from scaleprotoseg_amd.loss import ClassDistances, KLDLoss, PixelWiseCrossEntropyLoss
+
+    dev = _dev()
+    B, S, Cs, P, K, H, W = shape
+    gen = torch.Generator().manual_seed(20220227 + 41)
+    conv = O.bf16_representable(torch.sigmoid(torch.randn(B, S * Cs, H, W, generator=gen)))
+    bank = O.bf16_representable(torch.rand(P, Cs, 1, 1, generator=gen))
+    net = spx.PPNetMultiScale(_Backbone(S * Cs), 64, (P, Cs, 1, 1), [], K, add_on_layers_type="deeplab_simple",
+                              patch_classification=True, num_scales=S)
+    with torch.no_grad():
+        net.prototype_vectors.copy_(bank)
+        net.last_layer.weight.add_(0.05 * torch.randn(K, P, generator=gen))
+    net = net.to(dev)
+    target = torch.randint(0, K + 1, (B, H, W), generator=gen)         # 0 = void
+    target[0, 0, :3] = 0
+    ranges = {s: tuple(net.scale_num_prototypes[s]) for s in range(S)}
+    g_dist = torch.randn(B, P, H, W, generator=gen) * 1e-3
+
+    c0 = conv.clone().requires_grad_(True)
+    p0 = bank.clone().requires_grad_(True)
+    w0 = net.last_layer.weight.detach().cpu().clone().requires_grad_(True)
+    rl, rd, _ = O.forward_from_conv_features(c0, p0, ranges, S, w0)
+    ref_ce = torch.nn.functional.cross_entropy(rl.reshape(-1, K), target.reshape(-1) - 1, ignore_index=-1)
+    ref_correct = (rl.reshape(-1, K).argmax(-1) == target.reshape(-1) - 1)[(target.reshape(-1) - 1) != -1]
+    ident = net.prototype_class_identity.cpu()
+    if gather:
+        ref_loss = 0.7 * ref_ce + O.kld_loss(rd, target, ident, S, ranges)
+    else:
+        ref_loss = 0.7 * ref_ce + (rd * g_dist).sum()
+    ref_loss.backward()
+
+    x = conv.to(dev, x_dtype).requires_grad_(True)
+    tgt = target.to(dev)
+    if gather:
+        logits, cd = net.forward_from_conv_features(x, target_labels=tgt, ce_target=tgt)
+        assert isinstance(cd, ClassDistances)
+    else:
+        logits, dist = net.forward_from_conv_features(x, ce_target=tgt)
+    assert hasattr(logits, "spx_ce")
+    _close_fwd(logits, rl.detach(), "logits")
+    ce, correct = PixelWiseCrossEntropyLoss(ignore_index=-1, return_correct=True)(logits, tgt)
+    assert ce is logits.spx_ce.loss                                    # the epilogue's value, no second pass
+    assert abs(ce.item() - ref_ce.item()) <= 1e-4 * max(1.0, abs(ref_ce.item()))
+    agree = (correct.cpu() == ref_correct).float().mean().item()
+    assert agree >= 0.995                                               # argmax may flip where two logits agree to 1e-4
+    if gather:
+        loss = 0.7 * ce + KLDLoss(net.prototype_class_identity, S, net.scale_num_prototypes)(cd, tgt)
+    else:
+        loss = 0.7 * ce + (dist * g_dist.to(dev)).sum()
+    loss.backward()
+    _grad_close(x.grad, c0.grad, "dX", tol=GRAD_TOL if x_dtype == torch.float32 else BF16_DX_TOL * max(1, -(-(P // S) // 192)))
+    _grad_close(net.prototype_vectors.grad, p0.grad, "dPrototypes")
+    _grad_close(net.last_layer.weight.grad, w0.grad, "dLastLayer")
+
+
+def test_fused_cross_entropy_with_a_second_use_of_the_logits():
+    """The logits feed the fused cross entropy AND another term: both gradients reach d_logits."""
+    import scaleprotoseg_amd as spx
+
+    dev = _dev()
+    B, S, Cs, P, K, H, W = 1, 4, 16, 40, 5, 9, 11
+    gen = torch.Generator().manual_seed(3)
+    conv = O.bf16_representable(torch.sigmoid(torch.randn(B, S * Cs, H, W, generator=gen)))
+    net = spx.PPNetMultiScale(_Backbone(S * Cs), 64, (P, Cs, 1, 1), [], K, add_on_layers_type="deeplab_simple",
+                              patch_classification=True, num_scales=S)
+    with torch.no_grad():
+        net.prototype_vectors.copy_(O.bf16_representable(net.prototype_vectors.data))
+    bank = net.prototype_vectors.detach().clone()
+    net = net.to(dev)
+    target = torch.randint(0, K + 1, (B, H, W), generator=gen)
+    r = torch.randn(B, H, W, K, generator=gen) * 1e-2
+    ranges = {s: tuple(net.scale_num_prototypes[s]) for s in range(S)}
+    c0 = conv.clone().requires_grad_(True)
+    p0 = bank.clone().requires_grad_(True)
+    w0 = net.last_layer.weight.detach().cpu().clone().requires_grad_(True)
+    rl, _, _ = O.forward_from_conv_features(c0, p0, ranges, S, w0)
+    (torch.nn.functional.cross_entropy(rl.reshape(-1, K), target.reshape(-1) - 1, ignore_index=-1) + (rl * r).sum()).backward()
+    x = conv.to(dev).requires_grad_(True)
+    logits, _ = net.forward_from_conv_features(x, ce_target=target.to(dev))
+    (logits.spx_ce.loss + (logits * r.to(dev)).sum()).backward()
+    _grad_close(x.grad, c0.grad, "dX")
+    _grad_close(net.prototype_vectors.grad, p0.grad, "dPrototypes")
+    _grad_close(net.last_layer.weight.grad, w0.grad, "dLastLayer")

@@ -277,7 +277,7 @@ def test_cross_entropy_matches_reference(golden):
 
     g = golden("kld_loss")
     lg = torch.from_numpy(g["ce_logits"]).requires_grad_(True)
-    ce, correct = PixelWiseCrossEntropyLoss(ignore_index=-1, return_correct=True)(lg, torch.from_numpy(g["ce_target"]))
+    ce, correct = PixelWiseCrossEntropyLoss(ignore_index=-1, return_correct=True, torch_formulation=True)(lg, torch.from_numpy(g["ce_target"]))
     ce.backward()
     assert abs(ce.item() - float(g["ce_loss"])) <= 1e-6
     np.testing.assert_allclose(lg.grad.numpy(), g["ce_grad"], atol=1e-7)
