@@ -14,9 +14,13 @@
 // registers for the whole launch and leave as one fp32 slab per workgroup.  Straight-line chunk body: panel
 // height, class blocks and the 8 channel blocks are compile-time (channels beyond Cs are zero rows).
 // ------------------------------------------------------------------------------------------------
-#define SPX_BK_PX 64          // pixels per K-chunk (half a kernel-1 tile)
-#define SPX_BK_ROW 144        // LDS row stride of the [channel][px] images (128 + 16: conflict-free ds_read_b128)
+// Pixels per K-chunk (template parameter CPX): 64 = half a kernel-1 tile, ONE LDS buffer, commit -> barrier -> compute ->
+// barrier per chunk; 32 = one kernel-1 wave, TWO LDS buffers: chunk c computes from one buffer while chunk c+1 is
+// converted into the other and chunk c+2's loads are in flight, one barrier per chunk (the loads then have a whole
+// iteration to land instead of the MFMA phase only, and the conversion VALU of one wave runs under the other's MFMAs).
 #define SPX_BK_THREADS 512
+// LDS row stride of the [channel][px] images: 2 CPX + 16 bytes (144 / 80: conflict-free ds_read_b128)
+__host__ __device__ constexpr int spx_bk_row(int cpx) { return 2 * cpx + 16; }
 
 __host__ __device__ inline int spx_bk_wstride(const spx_plan& pl) {
     return ((pl.channels_per_scale + 31) / 32) * 32 + pl.ncb * 32 + 32;   // [dP cols | dW cols | colsum + pad]
@@ -32,11 +36,15 @@ size_t spx_bank_bwd_ws_floats(const spx_plan& pl, int nsplit) {
     return (size_t)nsplit * pl.npanels * pl.npb * 32 * spx_bk_wstride(pl);
 }
 // LDS carve: [G hi | G lo | X] (d_bank instances) then [a hi | a lo | dLogits^T hi | dLogits^T lo] (d_W instances)
-template <int NPB, int NCB, bool DO_P, bool DO_W>
+template <int NPB, int NCB, bool DO_P, bool DO_W, int CPX>
+__host__ __device__ constexpr int spx_bk_buf_bytes() {
+    constexpr int fb = (CPX / 32) * NPB * 2 * 1024;
+    return (DO_P ? 2 * fb + 256 * spx_bk_row(CPX) : 0) + (DO_W ? 2 * fb + 2 * NCB * 32 * spx_bk_row(CPX) : 0);
+}
+template <int NPB, int NCB, bool DO_P, bool DO_W, int CPX>
 __host__ __device__ constexpr int spx_bk_lds_bytes() {
-    constexpr int fb = 2 * NPB * 2 * 1024;
     constexpr int red = (2 * 3 * 2 * 1024 + 2 * 3 * 64) * 4;          // the k-step-split reduction re-uses the staging area
-    constexpr int n = (DO_P ? 2 * fb + 256 * SPX_BK_ROW : 0) + (DO_W ? 2 * fb + 2 * NCB * 32 * SPX_BK_ROW : 0);
+    constexpr int n = (CPX == 32 ? 2 : 1) * spx_bk_buf_bytes<NPB, NCB, DO_P, DO_W, CPX>();
     return n > red ? n : red;
 }
 
@@ -44,8 +52,12 @@ __host__ __device__ constexpr int spx_bk_lds_bytes() {
 // 5-block head (80 d_W accumulators per lane next to 96 for d_bank) the launcher runs two instances, each with its
 // own operands only (G + X, or a + dLogits): no byte is read twice and neither instance spills.
 // KSPLIT: scales of <= 64 channels (see the wave roles below).
-template <int NPB, int NCB, bool XF32, bool VEC, bool DO_P, bool DO_W, bool KSPLIT>
+template <int NPB, int NCB, bool XF32, bool VEC, bool DO_P, bool DO_W, bool KSPLIT, int CPX>
 __global__ __launch_bounds__(SPX_BK_THREADS, 2) void spx_bank_bwd_kernel(const SpxBankBwdArgs a) {
+    constexpr int SPX_BK_PX = CPX, SPX_BK_ROW = spx_bk_row(CPX);
+    constexpr int NW1 = CPX / 32;                     // kernel-1 waves per chunk
+    constexpr bool PIPE = CPX == 32;
+    static_assert(!(PIPE && KSPLIT), "the k-step split needs four pixel k-steps per chunk");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const spx_plan& pl = a.plan;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -59,26 +71,35 @@ __global__ __launch_bounds__(SPX_BK_THREADS, 2) void spx_bank_bwd_kernel(const S
     const int ch0 = pl.panel_ch0[q];
     const int tiles_per_img = (a.HW + SPX_TILE_PX - 1) / SPX_TILE_PX;
     const size_t ntiles = (size_t)a.B * tiles_per_img;
-    const int nci = 2 * tiles_per_img;                       // 64-px chunks per image
+    const int nci = (SPX_TILE_PX / CPX) * tiles_per_img;     // chunks per image
     const long long total = (long long)a.B * nci;
-    const long long per = (total + a.nsplit - 1) / a.nsplit;
-    const long long c_begin = split * per;
-    const long long c_end = (c_begin + per < total) ? c_begin + per : total;
+    // chunk c belongs to workgroup c mod nsplit: the workgroups running at one time then cover CONSECUTIVE chunks, i.e.
+    // one contiguous stretch of every X row (16-32 KB) and of the blobs, instead of 128-B pieces 16 KB apart
+    // (DRAM page locality).  Every slab still sums a fixed chunk set in a fixed order: results stay deterministic.
+    const long long cstep = a.nsplit;
+    const long long c_begin = split;
+    const long long c_end = total;                     // exclusive bound of this workgroup's walk c_begin, c_begin + cstep, ...
+    const long long c_last = c_begin < total ? c_begin + ((total - 1 - c_begin) / cstep) * cstep : c_begin;
     const bool want_w = DO_W && a.d_W != nullptr;
     const bool want_p = DO_P && a.d_bank != nullptr;
     constexpr int ESZ = XF32 ? 4 : 2;
-    constexpr int NFRAG = 2 * NPB * 2;                // fragments per chunk and image: 2 kernel-1 waves x NPB x 2 k-steps
+    constexpr int NFRAG = NW1 * NPB * 2;              // fragments per chunk and image: kernel-1 waves x NPB x 2 k-steps
     constexpr int FBYTES = NFRAG * 1024;
 
     // both blobs are fp16 (G scaled per (lane, block), see kernel 1); each is split into an exact bf16 hi + lo pair
     // while it is committed to LDS, in the blob's own lane order (the split is elementwise)
-    char* Gs = smem;                                  // G fragments: bf16 high part of scale * fp16
-    char* Gs2 = Gs + (DO_P ? FBYTES : 0);             // ... and the bf16 residual (G = hi + lo exactly)
-    char* Xs = Gs2 + (DO_P ? FBYTES : 0);             // [256][144 B]  X rows (rows >= Cs are zero)
-    char* As = Xs + (DO_P ? 256 * SPX_BK_ROW : 0);    // a fragments: bf16 high part of the fp16 blob
-    char* As2 = As + FBYTES;                          // ... and the bf16 residual (a = hi + lo exactly)
-    char* Ls = As2 + FBYTES;                          // [NCB*32][144 B] dLogits^T, bf16 high part
-    char* Ls2 = Ls + NCB * 32 * SPX_BK_ROW;           // ... and the bf16 residual: dLogits enters d_W as hi + lo (~2^-17)
+    constexpr int BUF = spx_bk_buf_bytes<NPB, NCB, DO_P, DO_W, CPX>();
+    char *Gs, *Gs2, *Xs, *As, *As2, *Ls, *Ls2;
+    auto use_buffer = [&](int buf) {
+        Gs = smem + buf * BUF;                        // G fragments: bf16 high part of scale * fp16
+        Gs2 = Gs + (DO_P ? FBYTES : 0);               // ... and the bf16 residual (G = hi + lo exactly)
+        Xs = Gs2 + (DO_P ? FBYTES : 0);               // [256][row]  X rows (rows >= Cs are zero)
+        As = Xs + (DO_P ? 256 * SPX_BK_ROW : 0);      // a fragments: bf16 high part of the fp16 blob
+        As2 = As + FBYTES;                            // ... and the bf16 residual (a = hi + lo exactly)
+        Ls = As2 + FBYTES;                            // [NCB*32][row] dLogits^T, bf16 high part
+        Ls2 = Ls + NCB * 32 * SPX_BK_ROW;             // ... and the bf16 residual: dLogits enters d_W as hi + lo (~2^-17)
+    };
+    use_buffer(0);
 
     // wave roles
     const int cpair = wave & 3;                       // channel blocks 2*cpair, 2*cpair+1
@@ -109,7 +130,9 @@ __global__ __launch_bounds__(SPX_BK_THREADS, 2) void spx_bank_bwd_kernel(const S
 
     // staging registers (512 threads)
     constexpr int FP = (FBYTES / 16 + SPX_BK_THREADS - 1) / SPX_BK_THREADS;   // 16-B pieces per thread per image
-    constexpr int XPT = 256 * 8 / SPX_BK_THREADS;                               // X pieces (8 px) per thread = 4
+    constexpr int PPR = CPX / 8;                                                // 8-px pieces per X row
+    constexpr int RPP = SPX_BK_THREADS / PPR;                                   // rows per staging pass
+    constexpr int XPT = 256 / RPP;                                              // X pieces per thread
     u32x4 gr[FP], ar[FP], xr[XPT][XF32 ? 2 : 1];
     float gsc[FP];                                    // inverse scale of each staged G piece (one lane of one block)
     // piece -> (fragment, lane) of the blob: the inverse of spx_blob_slot.  Fixed per thread for the whole launch.
@@ -125,14 +148,18 @@ __global__ __launch_bounds__(SPX_BK_THREADS, 2) void spx_bank_bwd_kernel(const S
     const size_t blob_total = (size_t)pl.npanels * ntiles * 4 * NPB * 2 * 1024;
     constexpr int LPT = (SPX_BK_PX * 32 * NCB + SPX_BK_THREADS - 1) / SPX_BK_THREADS;   // dLogits elements per thread (upper bound)
     float lr_[LPT];
-    const int piece = tid & 7, prow = tid >> 3;      // X staging: piece of 8 px, row (0..63) within a pass of 64 rows
+    const int piece = tid % PPR, prow = tid / PPR;   // X staging: piece of 8 px, row within a pass of RPP rows
 
     auto issue = [&](long long c) {
+#ifdef SPX_DIAG_BANK_NOLOAD
+        c = c_begin;                                  // timing-only build: every chunk re-reads the first one (cache hits)
+#endif
         const int b = (int)(c / nci);
         const int ci = (int)(c - (long long)b * nci);
-        const size_t tile_g = (size_t)b * tiles_per_img + (ci >> 1);
-        // the chunk's fragments are contiguous: kernel-1 waves 2(ci&1), 2(ci&1)+1 of the tile
-        const size_t blob0 = ((((size_t)q * ntiles + tile_g) * 4 + 2 * (ci & 1)) * NPB * 2) * 1024;
+        constexpr int CPT = SPX_TILE_PX / CPX;            // chunks per kernel-1 tile
+        const size_t tile_g = (size_t)b * tiles_per_img + ci / CPT;
+        // the chunk's fragments are contiguous: kernel-1 waves NW1 (ci % CPT) ... of the tile
+        const size_t blob0 = ((((size_t)q * ntiles + tile_g) * 4 + NW1 * (ci % CPT)) * NPB * 2) * 1024;
         const spx_rsrc grs = make_rsrc_pred(a.g_in ? (const char*)a.g_in + blob0 : nullptr);
         const spx_rsrc ars = make_rsrc_pred(a.a_in ? (const char*)a.a_in + blob0 : nullptr);
         const spx_rsrc gss = make_rsrc_pred(a.g_in ? (const char*)a.g_in + blob_total + blob0 / 8 : nullptr);
@@ -146,9 +173,9 @@ __global__ __launch_bounds__(SPX_BK_THREADS, 2) void spx_bank_bwd_kernel(const S
         const int px = ci * SPX_BK_PX + piece * 8;
 #pragma unroll
         for (int i = 0; i < XPT; ++i) {
-            const int row = prow + 64 * i;
-            // rebase per (image, 64-row block): offsets from the tensor base can exceed 4 GiB for large batches
-            const spx_rsrc xb = make_rsrc_pred((const char*)a.x + ((size_t)b * C + ch0 + 64 * i) * a.HW * ESZ);
+            const int row = prow + RPP * i;
+            // rebase per (image, row block): offsets from the tensor base can exceed 4 GiB for large batches
+            const spx_rsrc xb = make_rsrc_pred((const char*)a.x + ((size_t)b * C + ch0 + RPP * i) * a.HW * ESZ);
             const uint32_t vo = ((uint32_t)prow * (uint32_t)a.HW + (uint32_t)px) * ESZ;
             const bool row_ok = want_p && row < Cs;
             if (VEC) {
@@ -229,7 +256,7 @@ __global__ __launch_bounds__(SPX_BK_THREADS, 2) void spx_bank_bwd_kernel(const S
             } else {
                 v = xr[i][0];
             }
-            if (DO_P) *(u32x4*)(Xs + (prow + 64 * i) * SPX_BK_ROW + piece * 16) = v;
+            if (DO_P) *(u32x4*)(Xs + (prow + RPP * i) * SPX_BK_ROW + piece * 16) = v;
         }
 #pragma unroll
         for (int i = 0; i < LPT; ++i) {
@@ -245,83 +272,85 @@ __global__ __launch_bounds__(SPX_BK_THREADS, 2) void spx_bank_bwd_kernel(const S
     };
 
     // padded class rows of the dLogits^T image stay zero for the whole kernel
-    for (int e = tid; DO_W && e < NCB * 32 * SPX_BK_PX; e += SPX_BK_THREADS) {
-        const int cls = e / SPX_BK_PX, p = e - cls * SPX_BK_PX;
-        if (cls >= K) {
-            *(uint16_t*)(Ls + cls * SPX_BK_ROW + p * 2) = 0;
-            *(uint16_t*)(Ls2 + cls * SPX_BK_ROW + p * 2) = 0;
+    for (int buf = 0; buf < (PIPE ? 2 : 1); ++buf) {
+        use_buffer(buf);
+        for (int e = tid; DO_W && e < NCB * 32 * SPX_BK_PX; e += SPX_BK_THREADS) {
+            const int cls = e / SPX_BK_PX, p = e - cls * SPX_BK_PX;
+            if (cls >= K) {
+                *(uint16_t*)(Ls + cls * SPX_BK_ROW + p * 2) = 0;
+                *(uint16_t*)(Ls2 + cls * SPX_BK_ROW + p * 2) = 0;
+            }
         }
     }
+    use_buffer(0);
 
     // transposed-read lane map of an A fragment (rows = prototypes of block pb, k = 16 px of a k-step):
     // 16-lane group g: prototype sub-block s2 = g & 1, k-half g >> 1; lane 4 qq + pp: pixel row qq, prototype quad pp
     const int tg = lane >> 4, tli = lane & 15, tqq = tli >> 2, tpp = tli & 3;
     const int ts2 = tg & 1, tkh = tg >> 1;
 
-    if (c_begin < c_end) issue(c_begin);
-    for (long long c = c_begin; c < c_end; ++c) {
-        commit();
-        __syncthreads();
-        issue(c + 1 < c_end ? c + 1 : c);       // always issue (branch-free); the last chunk is re-read and ignored
-        __builtin_amdgcn_sched_barrier(0);
-        // d_bank part of one pixel k-step: this wave's prototype blocks x channel blocks 2 cp, 2 cp + 1
-        auto bank_part = [&](int ks, int cp) {
-            const int koff = (ks * 16 + 8 * h) * 2;
-            // this lane's pixel rows of the k-step: px = 16 ks + 8 tkh + tqq (+4): kernel-1 wave px >> 5, lane px & 31
-            const int pxa = ks * 16 + 8 * tkh + tqq;
-            const int wsel = pxa >> 5, ra = pxa & 31;
-            const int fo0 = spx_blob_slot(ra, tpp & 1, ts2) * 16 + 8 * (tpp >> 1);
-            const int fo1 = spx_blob_slot(ra + 4, tpp & 1, ts2) * 16 + 8 * (tpp >> 1);
-            bf16x8 xb[2];
+    // d_bank part of one pixel k-step: this wave's prototype blocks x channel blocks 2 cp, 2 cp + 1
+    auto bank_part = [&](int ks, int cp) {
+        const int koff = (ks * 16 + 8 * h) * 2;
+        // this lane's pixel rows of the k-step: px = 16 ks + 8 tkh + tqq (+4): kernel-1 wave px >> 5, lane px & 31
+        const int pxa = ks * 16 + 8 * tkh + tqq;
+        const int wsel = pxa >> 5, ra = pxa & 31;
+        const int fo0 = spx_blob_slot(ra, tpp & 1, ts2) * 16 + 8 * (tpp >> 1);
+        const int fo1 = spx_blob_slot(ra + 4, tpp & 1, ts2) * 16 + 8 * (tpp >> 1);
+        bf16x8 xb[2];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) xb[t] = *(const bf16x8*)(Xs + ((2 * cp + t) * 32 + r) * SPX_BK_ROW + koff);
+        for (int t = 0; t < 2; ++t) xb[t] = *(const bf16x8*)(Xs + ((2 * cp + t) * 32 + r) * SPX_BK_ROW + koff);
 #pragma unroll
-            for (int i = 0; i < PH; ++i) {
-                const int fb = ((wsel * NPB + pb0 + i) * 2 + ts2) * 1024;
-                const bf16x4 g0 = __builtin_bit_cast(bf16x4, lds_tr_read(Gs + fb + fo0));
-                const bf16x4 g1 = __builtin_bit_cast(bf16x4, lds_tr_read(Gs + fb + fo1));
-                const bf16x4 l0 = __builtin_bit_cast(bf16x4, lds_tr_read(Gs2 + fb + fo0));
-                const bf16x4 l1 = __builtin_bit_cast(bf16x4, lds_tr_read(Gs2 + fb + fo1));
-                const bf16x8 gf = __builtin_shufflevector(g0, g1, 0, 1, 2, 3, 4, 5, 6, 7);
-                const bf16x8 gf2 = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
-                if (cs_role) {   // colsum(G): every lane holds 8 px of its prototype row; lanes r, r+32 cover the k-step
-                    float s8 = 0.0f;
+        for (int i = 0; i < PH; ++i) {
+            const int fb = ((wsel * NPB + pb0 + i) * 2 + ts2) * 1024;
+            const bf16x4 g0 = __builtin_bit_cast(bf16x4, lds_tr_read(Gs + fb + fo0));
+            const bf16x4 g1 = __builtin_bit_cast(bf16x4, lds_tr_read(Gs + fb + fo1));
+            const bf16x4 l0 = __builtin_bit_cast(bf16x4, lds_tr_read(Gs2 + fb + fo0));
+            const bf16x4 l1 = __builtin_bit_cast(bf16x4, lds_tr_read(Gs2 + fb + fo1));
+            const bf16x8 gf = __builtin_shufflevector(g0, g1, 0, 1, 2, 3, 4, 5, 6, 7);
+            const bf16x8 gf2 = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+            if (cs_role) {   // colsum(G): every lane holds 8 px of its prototype row; lanes r, r+32 cover the k-step
+                float s8 = 0.0f;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) s8 += (float)gf[j] + (float)gf2[j];
-                    csum[i] += s8;
-                }
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    accp[i][t] = mfma_bf16(gf, xb[t], accp[i][t]);
-                    accp[i][t] = mfma_bf16(gf2, xb[t], accp[i][t]);
-                }
+                for (int j = 0; j < 8; ++j) s8 += (float)gf[j] + (float)gf2[j];
+                csum[i] += s8;
             }
-        };
-        // d_W part of one pixel k-step (waves 0 .. NPB-1: prototype block `wave`, every class block)
-        auto head_part = [&](int ks) {
-            const int koff = (ks * 16 + 8 * h) * 2;
-            const int pxa = ks * 16 + 8 * tkh + tqq;
-            const int wsel = pxa >> 5, ra = pxa & 31;
-            const int fo0 = spx_blob_slot(ra, tpp & 1, ts2) * 16 + 8 * (tpp >> 1);
-            const int fo1 = spx_blob_slot(ra + 4, tpp & 1, ts2) * 16 + 8 * (tpp >> 1);
-            const int fb = ((wsel * NPB + wave) * 2 + ts2) * 1024;
-            // a = hi + lo (split at commit time): d_W = (hi + lo) . (dl_hi + dl_lo) carries ~2^-12 of a's fp16 rounding
-            // instead of bf16's 2^-9
-            const bf16x4 a0 = __builtin_bit_cast(bf16x4, lds_tr_read(As + fb + fo0));
-            const bf16x4 a1 = __builtin_bit_cast(bf16x4, lds_tr_read(As + fb + fo1));
-            const bf16x4 b0 = __builtin_bit_cast(bf16x4, lds_tr_read(As2 + fb + fo0));
-            const bf16x4 b1 = __builtin_bit_cast(bf16x4, lds_tr_read(As2 + fb + fo1));
-            const bf16x8 af = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
-            const bf16x8 af2 = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
-            for (int cb = 0; cb < NCB; ++cb) {
-                const bf16x8 lf = *(const bf16x8*)(Ls + (cb * 32 + r) * SPX_BK_ROW + koff);
-                const bf16x8 lf2 = *(const bf16x8*)(Ls2 + (cb * 32 + r) * SPX_BK_ROW + koff);
-                accw[cb] = mfma_bf16(af, lf, accw[cb]);
-                accw[cb] = mfma_bf16(af2, lf, accw[cb]);
-                accw[cb] = mfma_bf16(af, lf2, accw[cb]);
+            for (int t = 0; t < 2; ++t) {
+                accp[i][t] = mfma_bf16(gf, xb[t], accp[i][t]);
+                accp[i][t] = mfma_bf16(gf2, xb[t], accp[i][t]);
             }
-        };
+        }
+    };
+    // d_W part of one pixel k-step (waves 0 .. NPB-1: prototype block `wave`, every class block)
+    auto head_part = [&](int ks) {
+        const int koff = (ks * 16 + 8 * h) * 2;
+        const int pxa = ks * 16 + 8 * tkh + tqq;
+        const int wsel = pxa >> 5, ra = pxa & 31;
+        const int fo0 = spx_blob_slot(ra, tpp & 1, ts2) * 16 + 8 * (tpp >> 1);
+        const int fo1 = spx_blob_slot(ra + 4, tpp & 1, ts2) * 16 + 8 * (tpp >> 1);
+        const int fb = ((wsel * NPB + wave) * 2 + ts2) * 1024;
+        // a = hi + lo (split at commit time): d_W = (hi + lo) . (dl_hi + dl_lo) carries ~2^-12 of a's fp16 rounding
+        // instead of bf16's 2^-9
+        const bf16x4 a0 = __builtin_bit_cast(bf16x4, lds_tr_read(As + fb + fo0));
+        const bf16x4 a1 = __builtin_bit_cast(bf16x4, lds_tr_read(As + fb + fo1));
+        const bf16x4 b0 = __builtin_bit_cast(bf16x4, lds_tr_read(As2 + fb + fo0));
+        const bf16x4 b1 = __builtin_bit_cast(bf16x4, lds_tr_read(As2 + fb + fo1));
+        const bf16x8 af = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+        const bf16x8 af2 = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) {
+            const bf16x8 lf = *(const bf16x8*)(Ls + (cb * 32 + r) * SPX_BK_ROW + koff);
+            const bf16x8 lf2 = *(const bf16x8*)(Ls2 + (cb * 32 + r) * SPX_BK_ROW + koff);
+            accw[cb] = mfma_bf16(af, lf, accw[cb]);
+            accw[cb] = mfma_bf16(af2, lf, accw[cb]);
+            accw[cb] = mfma_bf16(af, lf2, accw[cb]);
+        }
+    };
+    auto compute = [&]() {
+#ifdef SPX_DIAG_BANK_NOCOMPUTE
+        return;                                       // timing-only build: data movement + commit alone
+#endif
         if constexpr (KSPLIT) {
             if (DO_P) bank_part(cpair, 0);
             if (DO_W && w_role) {
@@ -335,7 +364,34 @@ __global__ __launch_bounds__(SPX_BK_THREADS, 2) void spx_bank_bwd_kernel(const S
                 if (DO_W && w_role) head_part(ks);
             }
         }
+    };
+    if constexpr (!PIPE) {
+        if (c_begin < c_end) issue(c_begin);
+        for (long long c = c_begin; c < c_end; c += cstep) {
+            commit();
+            __syncthreads();
+            issue(c + cstep < c_end ? c + cstep : c);       // always issue (branch-free); the last chunk is re-read and ignored
+            __builtin_amdgcn_sched_barrier(0);
+            compute();
+            __syncthreads();
+        }
+    } else if (c_begin < c_end) {
+        // software pipeline over two LDS buffers: loads of chunk c+2 in flight | chunk c+1 converted into the other
+        // buffer | chunk c's MFMAs; one barrier per chunk
+        issue(c_begin);
+        commit();                                    // buffer 0 <- the first chunk
+        issue(c_begin + cstep < c_end ? c_begin + cstep : c_begin);
         __syncthreads();
+        int buf = 0;
+        for (long long c = c_begin; c < c_end; c += cstep) {
+            use_buffer(buf);
+            compute();
+            use_buffer(buf ^ 1);
+            commit();                                // the next chunk (after the last one: a harmless re-commit)
+            issue(c + 2 * cstep < c_end ? c + 2 * cstep : c_last);
+            __syncthreads();
+            buf ^= 1;
+        }
     }
 
     // ---- k-step split: sum the four cpair partials of each prototype half through LDS (staging is dead now) ----
@@ -464,16 +520,24 @@ __global__ __launch_bounds__(SPX_RED_ELEMS * SPX_RED_PARTS) void spx_bank_reduce
     }
 }
 
+// 32-px double-buffered chunks (CPX = 32): measured equal to the 64-px single-buffered loop on MI355X (0.876 vs 0.875 ms at
+// the north-star shape, A/B on one box) - the kernel is bound by its on-chip work (LDS fragment reads -> MFMA chains at two
+// waves per SIMD: 0.68-0.73 ms with every load an L2 hit), not by load latency - so it stays off.
+#ifndef SPX_BANK_PIPE
+#define SPX_BANK_PIPE 0
+#endif
 template <int NPB, int NCB, bool DO_P, bool DO_W, bool KSPLIT>
 static hipError_t launch_bank_k(const SpxBankBwdArgs& a, int x_dtype, dim3 grid, hipStream_t s) {
-    constexpr size_t lds = (size_t)spx_bk_lds_bytes<NPB, NCB, DO_P, DO_W>();
+    // 32-px double-buffered chunks wherever the k-step split is not in use and two buffers fit the LDS
+    constexpr int CPX = (SPX_BANK_PIPE && !KSPLIT && 2 * spx_bk_buf_bytes<NPB, NCB, DO_P, DO_W, 32>() <= SPX_LDS_LIMIT) ? 32 : 64;
+    constexpr size_t lds = (size_t)spx_bk_lds_bytes<NPB, NCB, DO_P, DO_W, CPX>();
     static_assert(lds <= SPX_LDS_LIMIT, "bank kernel LDS");
     if (x_dtype == 1) {
-        if (a.vec_ok) hipLaunchKernelGGL((spx_bank_bwd_kernel<NPB, NCB, true, true, DO_P, DO_W, KSPLIT>), grid, dim3(SPX_BK_THREADS), lds, s, a);
-        else hipLaunchKernelGGL((spx_bank_bwd_kernel<NPB, NCB, true, false, DO_P, DO_W, KSPLIT>), grid, dim3(SPX_BK_THREADS), lds, s, a);
+        if (a.vec_ok) hipLaunchKernelGGL((spx_bank_bwd_kernel<NPB, NCB, true, true, DO_P, DO_W, KSPLIT, CPX>), grid, dim3(SPX_BK_THREADS), lds, s, a);
+        else hipLaunchKernelGGL((spx_bank_bwd_kernel<NPB, NCB, true, false, DO_P, DO_W, KSPLIT, CPX>), grid, dim3(SPX_BK_THREADS), lds, s, a);
     } else {
-        if (a.vec_ok) hipLaunchKernelGGL((spx_bank_bwd_kernel<NPB, NCB, false, true, DO_P, DO_W, KSPLIT>), grid, dim3(SPX_BK_THREADS), lds, s, a);
-        else hipLaunchKernelGGL((spx_bank_bwd_kernel<NPB, NCB, false, false, DO_P, DO_W, KSPLIT>), grid, dim3(SPX_BK_THREADS), lds, s, a);
+        if (a.vec_ok) hipLaunchKernelGGL((spx_bank_bwd_kernel<NPB, NCB, false, true, DO_P, DO_W, KSPLIT, CPX>), grid, dim3(SPX_BK_THREADS), lds, s, a);
+        else hipLaunchKernelGGL((spx_bank_bwd_kernel<NPB, NCB, false, false, DO_P, DO_W, KSPLIT, CPX>), grid, dim3(SPX_BK_THREADS), lds, s, a);
     }
     return hipGetLastError();
 }

@@ -28,13 +28,20 @@ for f in glob.glob(root + "/pmc_*/*/*counter_collection.csv"):
             agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 if agg:
     # HBM bytes per launch per operator (C-ABI name), for bench.py's roofline.traffic
-    opmap = {"spx_fwd_kernel": "spx_dist_fwd", "spx_bwd_kernel": "spx_dist_bwd", "spx_bank_bwd_kernel": "spx_bank_bwd"}
+    opmap = {"spx_fwd_kernel": "spx_dist_fwd", "spx_bwd_kernel": "spx_dist_bwd", "spx_bank_bwd_kernel": "spx_bank_bwd",
+             "spx_bank_reduce_kernel": "spx_bank_reduce"}
     traffic = {}
     for k, v in agg.items():
         for kn, op in opmap.items():
             if k.startswith(kn) and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
                 fs = sum(v["FETCH_SIZE"]) / len(v["FETCH_SIZE"]); wsz = sum(v["WRITE_SIZE"]) / len(v["WRITE_SIZE"])
                 traffic[op] = round((2 * fs + wsz) * 1024)
+    import subprocess
+    try:
+        head = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+    except Exception:
+        head = ""
+    traffic["_source"] = f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `{cmd}`" + (f", commit {head}" if head else "")
     json.dump(traffic, open(root + "/traffic.json", "w"), indent=1)
     print("## PMC counters per launch (mean over launches)\n")
     print("FETCH_SIZE / WRITE_SIZE are in KiB as reported; on gfx950 FETCH_SIZE counts a wide coalesced read stream "
