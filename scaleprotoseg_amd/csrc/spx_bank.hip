@@ -133,8 +133,13 @@ __global__ __launch_bounds__(SPX_BK_THREADS, 2) void spx_bank_bwd_kernel(const S
     constexpr int PPR = CPX / 8;                                                // 8-px pieces per X row
     constexpr int RPP = SPX_BK_THREADS / PPR;                                   // rows per staging pass
     constexpr int XPT = 256 / RPP;                                              // X pieces per thread
-    u32x4 gr[FP], ar[FP], xr[XPT][XF32 ? 2 : 1];
-    float gsc[FP];                                    // inverse scale of each staged G piece (one lane of one block)
+    // staging registers: one set per chunk in flight (the pipelined variant keeps two chunks of loads in flight)
+    struct Stage {
+        u32x4 gr[FP], ar[FP], xr[XPT][XF32 ? 2 : 1];
+        float gsc[FP];                                // inverse scale of each staged G piece (one lane of one block)
+        float lr_[(CPX * 32 * NCB + SPX_BK_THREADS - 1) / SPX_BK_THREADS];
+    };
+    Stage stg[PIPE ? 2 : 1];
     // piece -> (fragment, lane) of the blob: the inverse of spx_blob_slot.  Fixed per thread for the whole launch.
     uint32_t gsc_off[FP];
 #pragma unroll
@@ -147,10 +152,9 @@ __global__ __launch_bounds__(SPX_BK_THREADS, 2) void spx_bank_bwd_kernel(const S
     }
     const size_t blob_total = (size_t)pl.npanels * ntiles * 4 * NPB * 2 * 1024;
     constexpr int LPT = (SPX_BK_PX * 32 * NCB + SPX_BK_THREADS - 1) / SPX_BK_THREADS;   // dLogits elements per thread (upper bound)
-    float lr_[LPT];
     const int piece = tid % PPR, prow = tid / PPR;   // X staging: piece of 8 px, row within a pass of RPP rows
 
-    auto issue = [&](long long c) {
+    auto issue = [&](Stage& st, long long c) {
 #ifdef SPX_DIAG_BANK_NOLOAD
         c = c_begin;                                  // timing-only build: every chunk re-reads the first one (cache hits)
 #endif
@@ -166,9 +170,9 @@ __global__ __launch_bounds__(SPX_BK_THREADS, 2) void spx_bank_bwd_kernel(const S
 #pragma unroll
         for (int i = 0; i < FP; ++i) {
             const uint32_t off = (uint32_t)((i * SPX_BK_THREADS + tid) * 16);
-            gr[i] = buf_load_b128_p<SPX_AUX_BLOB_LD>(grs, (want_p && off < (uint32_t)FBYTES) ? off : SPX_OOB, 0);
-            gsc[i] = buf_load_f32(gss, want_p ? gsc_off[i] : SPX_OOB, 0);
-            ar[i] = buf_load_b128_p<SPX_AUX_BLOB_LD>(ars, (want_w && off < (uint32_t)FBYTES) ? off : SPX_OOB, 0);
+            st.gr[i] = buf_load_b128_p<SPX_AUX_BLOB_LD>(grs, (want_p && off < (uint32_t)FBYTES) ? off : SPX_OOB, 0);
+            st.gsc[i] = buf_load_f32(gss, want_p ? gsc_off[i] : SPX_OOB, 0);
+            st.ar[i] = buf_load_b128_p<SPX_AUX_BLOB_LD>(ars, (want_w && off < (uint32_t)FBYTES) ? off : SPX_OOB, 0);
         }
         const int px = ci * SPX_BK_PX + piece * 8;
 #pragma unroll
@@ -180,18 +184,18 @@ __global__ __launch_bounds__(SPX_BK_THREADS, 2) void spx_bank_bwd_kernel(const S
             const bool row_ok = want_p && row < Cs;
             if (VEC) {
                 const uint32_t v = (row_ok && px + 8 <= a.HW) ? vo : SPX_OOB;
-                xr[i][0] = buf_load_b128(xb, v, 0);
-                if (XF32) xr[i][1] = buf_load_b128(xb, v == SPX_OOB ? SPX_OOB : v + 16, 0);
+                st.xr[i][0] = buf_load_b128(xb, v, 0);
+                if (XF32) st.xr[i][1] = buf_load_b128(xb, v == SPX_OOB ? SPX_OOB : v + 16, 0);
             } else if (XF32) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e)
-                    xr[i][e >> 2][e & 3] = __float_as_uint(buf_load_f32(xb, (row_ok && px + e < a.HW) ? vo + 4 * e : SPX_OOB, 0));
+                    st.xr[i][e >> 2][e & 3] = __float_as_uint(buf_load_f32(xb, (row_ok && px + e < a.HW) ? vo + 4 * e : SPX_OOB, 0));
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const uint32_t lo = buf_load_u16(xb, (row_ok && px + 2 * e < a.HW) ? vo + 4 * e : SPX_OOB, 0);
                     const uint32_t hi = buf_load_u16(xb, (row_ok && px + 2 * e + 1 < a.HW) ? vo + 4 * e + 2 : SPX_OOB, 0);
-                    xr[i][0][e] = lo | (hi << 16);
+                    st.xr[i][0][e] = lo | (hi << 16);
                 }
             }
         }
@@ -202,22 +206,22 @@ __global__ __launch_bounds__(SPX_BK_THREADS, 2) void spx_bank_bwd_kernel(const S
         for (int i = 0; i < LPT; ++i) {
             const int e = i * SPX_BK_THREADS + tid;
             const int p = e / K;
-            lr_[i] = buf_load_f32(lb, (want_w && e < SPX_BK_PX * K && px0 + p < a.HW) ? (uint32_t)e * 4u : SPX_OOB, 0);
+            st.lr_[i] = buf_load_f32(lb, (want_w && e < SPX_BK_PX * K && px0 + p < a.HW) ? (uint32_t)e * 4u : SPX_OOB, 0);
         }
     };
 
-    auto commit = [&]() {
+    auto commit = [&](Stage& st) {
 #pragma unroll
         for (int i = 0; i < FP; ++i) {
             const int off = (i * SPX_BK_THREADS + tid) * 16;
             if (off < FBYTES) {
                 if (DO_P) {
-                    const f16x8 hv = __builtin_bit_cast(f16x8, gr[i]);
+                    const f16x8 hv = __builtin_bit_cast(f16x8, st.gr[i]);
                     bf16x8 ghi, glo;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         __bf16 hi, lo;
-                        split_bf16((float)hv[j] * gsc[i], hi, lo);      // 11-bit mantissa: hi + lo is exact
+                        split_bf16((float)hv[j] * st.gsc[i], hi, lo);      // 11-bit mantissa: hi + lo is exact
                         ghi[j] = hi;
                         glo[j] = lo;
                     }
@@ -228,7 +232,7 @@ __global__ __launch_bounds__(SPX_BK_THREADS, 2) void spx_bank_bwd_kernel(const S
                     // the activation blob is fp16: split every element into bf16 hi + lo HERE, with the whole workgroup
                     // and in the blob's own lane order (the split is elementwise), so the waves of the head product
                     // only read fragments
-                    const f16x8 hv = __builtin_bit_cast(f16x8, ar[i]);
+                    const f16x8 hv = __builtin_bit_cast(f16x8, st.ar[i]);
                     bf16x8 ahi, alo;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
@@ -249,12 +253,12 @@ __global__ __launch_bounds__(SPX_BK_THREADS, 2) void spx_bank_bwd_kernel(const S
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     bf16x2 p;
-                    p[0] = (__bf16)__uint_as_float(xr[i][e >> 1][(2 * e) & 3]);
-                    p[1] = (__bf16)__uint_as_float(xr[i][e >> 1][(2 * e + 1) & 3]);
+                    p[0] = (__bf16)__uint_as_float(st.xr[i][e >> 1][(2 * e) & 3]);
+                    p[1] = (__bf16)__uint_as_float(st.xr[i][e >> 1][(2 * e + 1) & 3]);
                     v[e] = __builtin_bit_cast(uint32_t, p);
                 }
             } else {
-                v = xr[i][0];
+                v = st.xr[i][0];
             }
             if (DO_P) *(u32x4*)(Xs + (prow + RPP * i) * SPX_BK_ROW + piece * 16) = v;
         }
@@ -264,7 +268,7 @@ __global__ __launch_bounds__(SPX_BK_THREADS, 2) void spx_bank_bwd_kernel(const S
             if (DO_W && e < SPX_BK_PX * K) {
                 const int p = e / K, cls = e - p * K;
                 __bf16 hi, lo;
-                split_bf16(lr_[i], hi, lo);
+                split_bf16(st.lr_[i], hi, lo);
                 *(uint16_t*)(Ls + cls * SPX_BK_ROW + p * 2) = __builtin_bit_cast(uint16_t, hi);
                 *(uint16_t*)(Ls2 + cls * SPX_BK_ROW + p * 2) = __builtin_bit_cast(uint16_t, lo);
             }
@@ -366,31 +370,39 @@ __global__ __launch_bounds__(SPX_BK_THREADS, 2) void spx_bank_bwd_kernel(const S
         }
     };
     if constexpr (!PIPE) {
-        if (c_begin < c_end) issue(c_begin);
+        if (c_begin < c_end) issue(stg[0], c_begin);
         for (long long c = c_begin; c < c_end; c += cstep) {
-            commit();
+            commit(stg[0]);
             __syncthreads();
-            issue(c + cstep < c_end ? c + cstep : c);       // always issue (branch-free); the last chunk is re-read and ignored
+            issue(stg[0], c + cstep < c_end ? c + cstep : c);   // always issue (branch-free); the last chunk is re-read and ignored
             __builtin_amdgcn_sched_barrier(0);
             compute();
             __syncthreads();
         }
     } else if (c_begin < c_end) {
-        // software pipeline over two LDS buffers: loads of chunk c+2 in flight | chunk c+1 converted into the other
-        // buffer | chunk c's MFMAs; one barrier per chunk
-        issue(c_begin);
-        commit();                                    // buffer 0 <- the first chunk
-        issue(c_begin + cstep < c_end ? c_begin + cstep : c_begin);
+        // three-stage software pipeline: chunk c computes from one LDS buffer | chunk c+1 is converted into the other |
+        // the loads of chunks c+1 / c+2 are in flight in two register sets; one barrier per chunk.  Indices past the
+        // walk's end re-read the last chunk (branch-free, results unused).
+        auto at = [&](long long c) { return c < c_end ? c : c_last; };
+        issue(stg[0], c_begin);
+        commit(stg[0]);                              // buffer 0 <- the first chunk
+        issue(stg[0], at(c_begin + cstep));
+        issue(stg[1], at(c_begin + 2 * cstep));
         __syncthreads();
-        int buf = 0;
-        for (long long c = c_begin; c < c_end; c += cstep) {
-            use_buffer(buf);
-            compute();
-            use_buffer(buf ^ 1);
-            commit();                                // the next chunk (after the last one: a harmless re-commit)
-            issue(c + 2 * cstep < c_end ? c + 2 * cstep : c_last);
+        for (long long c = c_begin; c < c_end; c += 2 * cstep) {
+            use_buffer(0);
+            compute();                               // chunk c
+            use_buffer(1);
+            commit(stg[0]);                          // chunk c + 1
+            issue(stg[0], at(c + 3 * cstep));
             __syncthreads();
-            buf ^= 1;
+            if (c + cstep < c_end) {                 // workgroup-uniform
+                compute();                           // chunk c + 1 (buffer 1)
+                use_buffer(0);
+                commit(stg[1]);                      // chunk c + 2
+                issue(stg[1], at(c + 4 * cstep));
+                __syncthreads();
+            }
         }
     }
 
@@ -520,9 +532,12 @@ __global__ __launch_bounds__(SPX_RED_ELEMS * SPX_RED_PARTS) void spx_bank_reduce
     }
 }
 
-// 32-px double-buffered chunks (CPX = 32): measured equal to the 64-px single-buffered loop on MI355X (0.876 vs 0.875 ms at
-// the north-star shape, A/B on one box) - the kernel is bound by its on-chip work (LDS fragment reads -> MFMA chains at two
-// waves per SIMD: 0.68-0.73 ms with every load an L2 hit), not by load latency - so it stays off.
+// 32-px chunks with two LDS buffers and two register load sets (CPX = 32: a three-stage pipeline, one barrier per chunk):
+// measured EQUAL to the 64-px single-buffered loop on MI355X (0.865 vs 0.865 ms at the north-star shape, A/B on one box,
+// with and without the second load set).  Timing-only builds (SPX_DIAG_BANK_*) say why: commit alone (conversions + LDS
+// writes, every load an L2 hit) 0.32 ms, commit + MFMA phase 0.73 ms, loads + commit without the MFMA phase 0.63 ms - the
+// kernel is bound by its on-chip work (every wave converts, then reads fragments and runs MFMA chains, two waves per
+// SIMD), not by load latency.  Kept as a switch, off.
 #ifndef SPX_BANK_PIPE
 #define SPX_BANK_PIPE 0
 #endif
