@@ -151,6 +151,8 @@ __global__ __launch_bounds__(SPX_BK_THREADS, 2) void spx_bank_bwd_kernel(const S
         gsc_off[i] = off < FBYTES ? (uint32_t)(((frag >> 1) * 64 + rr + 32 * hh) * 4) : SPX_OOB;
     }
     const size_t blob_total = (size_t)pl.npanels * ntiles * 4 * NPB * 2 * 1024;
+    // activation blob format (kernel 1 wrote the word behind the blobs)
+    const bool a_fix = DO_W && a.a_in && *(const uint32_t*)((const char*)a.a_in + blob_total) == SPX_ABLOB_E4M12;
     constexpr int LPT = (SPX_BK_PX * 32 * NCB + SPX_BK_THREADS - 1) / SPX_BK_THREADS;   // dLogits elements per thread (upper bound)
     const int piece = tid % PPR, prow = tid / PPR;   // X staging: piece of 8 px, row within a pass of RPP rows
 
@@ -233,11 +235,12 @@ __global__ __launch_bounds__(SPX_BK_THREADS, 2) void spx_bank_bwd_kernel(const S
                     // and in the blob's own lane order (the split is elementwise), so the waves of the head product
                     // only read fragments
                     const f16x8 hv = __builtin_bit_cast(f16x8, st.ar[i]);
+                    const u16x8 qv = __builtin_bit_cast(u16x8, st.ar[i]);
                     bf16x8 ahi, alo;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         __bf16 hi, lo;
-                        split_bf16((float)hv[j], hi, lo);
+                        split_bf16(a_fix ? ablob_unpack(qv[j]) : (float)hv[j], hi, lo);     // e4m12: hi + lo is exact
                         ahi[j] = hi;
                         alo[j] = lo;
                     }
@@ -528,7 +531,10 @@ __global__ __launch_bounds__(SPX_RED_ELEMS * SPX_RED_PARTS) void spx_bank_reduce
     if (is_p) {
         a.d_bank[(size_t)p * Cs + col] = 2.0f * (a.bank[(size_t)p * Cs + col] * ct - st);
     } else {
-        a.d_W[(size_t)(col - Cs) * P + p] = 0.69314718056f * st;     // kernel 1's activation blob holds a / ln 2
+        // kernel 1's activation blob holds a / ln 2 (fp16) or a / (16 ln 2) (e4m12, the log activation)
+        const size_t ntl = (size_t)a.B * ((a.HW + SPX_TILE_PX - 1) / SPX_TILE_PX);
+        const uint32_t fmt = *(const uint32_t*)((const char*)a.a_in + ntl * pl.npanels * 4 * pl.npb * 2 * 1024);
+        a.d_W[(size_t)(col - Cs) * P + p] = (fmt == SPX_ABLOB_E4M12 ? 0.69314718056f * SPX_ABLOB_SCALE : 0.69314718056f) * st;
     }
 }
 

@@ -323,6 +323,8 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
         // inverse scales of the G blob: one float per (lane, block) behind the blobs, [panel][tile][wave][block][lane]
         const size_t blob_total = (size_t)pl.npanels * ntiles * 4 * NPB * 2 * 1024;
         const spx_rsrc gsr = make_rsrc(a.g_out ? (const char*)a.g_out + blob_total + blob0 / 8 : nullptr);
+        if (a.a_out && blockIdx.x == 0 && panel == 0 && tid == 0)
+            *(uint32_t*)((char*)a.a_out + blob_total) = act_is_log ? SPX_ABLOB_E4M12 : SPX_ABLOB_FP16;
 
         // ---- phase 1: G, a — a ROLLED loop over the panel's 32-prototype blocks.  The block being processed is
         // always acc[0]; acc is rotated after each block and the packed G fragments enter a register queue, so
@@ -383,7 +385,7 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
         // gout = its packed G fragments (k-steps 0 / 1)
         auto block = [&](int pb, auto slot_c, float (&ddc)[16], float (&ddnext)[16], bf16x8 (&gout)[2], bf16x8 (&glo)[2]) {
             constexpr int SLOT = decltype(slot_c)::value;
-            f16x8 anew[2];     // the activation blob is fp16 (a / ln 2 <= 13.3; 11-bit mantissa): the bank side splits it into bf16 hi + lo
+            u16x8 anew[2];     // the activation blob: e4m12 (log) or fp16 bits (linear), see spx_common.h
             // the G blob is fp16 too, scaled per (lane, block) by a power of two so that the lane's largest |G| of the
             // block sits just under 2^15 (a gradient has no fixed range: bf16's exponent with fp16's mantissa); the
             // inverse scale goes to a side array and the bank side rebuilds G = fp16 * scale as an exact bf16 hi + lo pair
@@ -395,7 +397,7 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
                 for (int j = 0; j < 8; ++j) {
                     gout[s2][j] = (__bf16)0.0f;
                     glo[s2][j] = (__bf16)0.0f;
-                    anew[s2][j] = (_Float16)0.0f;
+                    anew[s2][j] = 0;
                     gblob[s2][j] = (_Float16)0.0f;
                 }
             if (pb < nv) {
@@ -497,7 +499,8 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
                     // G's rounding relative to |x - p|, not to |p| (matters where a pixel sits on a prototype)
                     rs += (float)gb + (float)gl;
                     gblob[reg >> 3][reg & 7] = (_Float16)(gv[reg] * gscale_dn);
-                    anew[reg >> 3][reg & 7] = (_Float16)av[reg];
+                    anew[reg >> 3][reg & 7] = act_is_log ? ablob_pack(av[reg])
+                                                         : __builtin_bit_cast(unsigned short, (_Float16)av[reg]);
                 }
             }
             // fragment dump for kernel 2 (wholly padded blocks are written as zeros: kernel 2 reads them)

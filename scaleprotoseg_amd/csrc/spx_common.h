@@ -11,6 +11,7 @@ typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
@@ -132,6 +133,24 @@ __device__ __forceinline__ void tile_set(f32x16 (&t)[N], int i, const f32x16& v)
 
 __device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+// Activation blob of the backward (kernel 1 -> kernel 2).  "log" activations a / ln 2 = log2((d+1)/(d+eps)) lie in
+// [0, 13.3) and are small wherever distances are large (a ~ 1/d), so they need RELATIVE precision over ~16 binades and no
+// sign: a 16-bit float with a 4-bit exponent and a 12-bit mantissa (half-ulp 2^-13, four times finer than fp16's 2^-11 -
+// what carried d_W past 1e-3 - and 13 significant bits are an exact bf16 hi + lo pair).  Encoded value v = a / (16 ln 2) in
+// [0, 1): exponents -16 .. -1; anything below 2^-16 is 0.  "linear" activations (-d: signed, unbounded) stay fp16.  The
+// format word sits behind the blobs.
+#define SPX_ABLOB_FP16 0u
+#define SPX_ABLOB_E4M12 1u
+#define SPX_ABLOB_SCALE 16.0f
+__device__ __forceinline__ unsigned short ablob_pack(float a_over_ln2) {
+    const float v = fminf(a_over_ln2 * (1.0f / SPX_ABLOB_SCALE), 0.9999f);             // < 1 - 2^-14: rounding cannot reach 1.0
+    const uint32_t bits = __float_as_uint(v) + 0x400u;                                  // round to 12 mantissa bits (carry -> exponent)
+    return bits < (111u << 23) ? (unsigned short)0 : (unsigned short)((bits >> 11) - (111u << 12));
+}
+__device__ __forceinline__ float ablob_unpack(unsigned short u) {                       // = a / (16 ln 2); 0 <-> 0
+    return u == 0 ? 0.0f : __uint_as_float((((uint32_t)u >> 12) + 111u) << 23 | ((uint32_t)u & 0xfffu) << 11);
 }
 
 // fp32 -> (hi, lo) bf16 pair with hi + lo == x to ~2^-17 relative.
