@@ -152,7 +152,7 @@ __global__ __launch_bounds__(SPX_BK_THREADS, 2) void spx_bank_bwd_kernel(const S
     }
     const size_t blob_total = (size_t)pl.npanels * ntiles * 4 * NPB * 2 * 1024;
     // activation blob format (kernel 1 wrote the word behind the blobs)
-    const bool a_fix = DO_W && a.a_in && *(const uint32_t*)((const char*)a.a_in + blob_total) == SPX_ABLOB_E4M12;
+    const bool a_fix = SPX_ABLOB_USE_E4M12 && DO_W && a.a_in && *(const uint32_t*)((const char*)a.a_in + blob_total) == SPX_ABLOB_E4M12;
     constexpr int LPT = (SPX_BK_PX * 32 * NCB + SPX_BK_THREADS - 1) / SPX_BK_THREADS;   // dLogits elements per thread (upper bound)
     const int piece = tid % PPR, prow = tid / PPR;   // X staging: piece of 8 px, row within a pass of RPP rows
 

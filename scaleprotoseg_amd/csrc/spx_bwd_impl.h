@@ -324,7 +324,7 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
         const size_t blob_total = (size_t)pl.npanels * ntiles * 4 * NPB * 2 * 1024;
         const spx_rsrc gsr = make_rsrc(a.g_out ? (const char*)a.g_out + blob_total + blob0 / 8 : nullptr);
         if (a.a_out && blockIdx.x == 0 && panel == 0 && tid == 0)
-            *(uint32_t*)((char*)a.a_out + blob_total) = act_is_log ? SPX_ABLOB_E4M12 : SPX_ABLOB_FP16;
+            *(uint32_t*)((char*)a.a_out + blob_total) = (SPX_ABLOB_USE_E4M12 && act_is_log) ? SPX_ABLOB_E4M12 : SPX_ABLOB_FP16;
 
         // ---- phase 1: G, a — a ROLLED loop over the panel's 32-prototype blocks.  The block being processed is
         // always acc[0]; acc is rotated after each block and the packed G fragments enter a register queue, so
@@ -499,7 +499,7 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
                     // G's rounding relative to |x - p|, not to |p| (matters where a pixel sits on a prototype)
                     rs += (float)gb + (float)gl;
                     gblob[reg >> 3][reg & 7] = (_Float16)(gv[reg] * gscale_dn);
-                    anew[reg >> 3][reg & 7] = act_is_log ? ablob_pack(av[reg])
+                    anew[reg >> 3][reg & 7] = (SPX_ABLOB_USE_E4M12 && act_is_log) ? (unsigned short)ablob_pack(av[reg])
                                                          : __builtin_bit_cast(unsigned short, (_Float16)av[reg]);
                 }
             }
