@@ -30,6 +30,8 @@ WORKLOADS = {
     "cityscapes_1024x2048_c256_p190_s1": (256, 190, 1, 19, 1024, 2048),   # north-star shape (SURVEY.md 8d primary)
     "cityscapes_native_129x257_p228_s4": (256, 228, 4, 19, 129, 257),     # scaleproto_cityscapes.gin full image
     "cityscapes_1024x2048_c256_p228_s4": (256, 228, 4, 19, 1024, 2048),   # the gin's 4-scale bank at the north-star grid
+    "odd_1023x2047_c256_p190_s1": (256, 190, 1, 19, 1023, 2047),          # diagnostic: H*W odd -> rows of X are only 2-byte aligned
+    "cityscapes_crops_10x65x65_p228_s4": (256, 228, 4, 19, 650, 65),       # diagnostic: the gin's training crops (10 x 65 x 65) as one 650 x 65 grid
 }
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
 MFMA_BF16_PEAK_TFLOPS = 2500.0

@@ -35,7 +35,7 @@ extern "C" {
 #endif
 
 #define SPX_MAX_PANELS 64   /* (scale, <=192-prototype block) work units per pixel tile */
-#define SPX_ABI_VERSION 6
+#define SPX_ABI_VERSION 7
 
 /* How the prototype bank is cut into MFMA panels.  Filled by spx_make_plan(). */
 typedef struct spx_plan {
@@ -124,6 +124,22 @@ int spx_dist_bwd_cls(const spx_plan* plan, const void* x, int32_t x_dtype, int32
                      const float* d_class_distances, const float* d_act, const float* d_logits,
                      void* dx, void* g_out, void* a_out,
                      float epsilon, int32_t act_fn, void* stream);
+
+/* Scale-parallel forward for pixel grids that do not fill the chip (the reference trains on crops: 10 x 65 x 65 latent
+ * pixels = 331 tiles for 512+ workgroup slots, each tile walking every scale's panels one after the other).  The scales
+ * are independent work (segmentation/model/model_multiscale.py:283-317 is a Python loop over them), so each runs as its
+ * own workgroup; only the logits - a sum over ALL prototypes - need the per-scale partials summed, in scale order, by a
+ * second small kernel.  spx_fwd_split_groups(): how many groups the library uses for this problem (1 = the single walk);
+ * spx_dist_fwd_ws = spx_dist_fwd / spx_dist_fwd_cls (labels_cls / proto_key NULL = the P-wide map) with a workspace of
+ * spx_fwd_split_workspace_bytes() for those partials (NULL or 0 bytes: the single walk).  Launches without a logits
+ * output (and the pixel-side backward, which has no cross-scale term at all) split on their own. */
+int32_t spx_fwd_split_groups(const spx_plan* plan, int32_t B, int32_t HW);
+size_t spx_fwd_split_workspace_bytes(const spx_plan* plan, int32_t B, int32_t HW);
+int spx_dist_fwd_ws(const spx_plan* plan, const void* x, int32_t x_dtype, int32_t B, int32_t HW,
+                    const void* packed_bank, const float* packed_p2, const void* packed_head,
+                    const int32_t* labels_cls, const uint32_t* proto_key, int32_t J, float* class_distances,
+                    float* distances, float* activations, float* logits, void* split_workspace,
+                    float epsilon, int32_t act_fn, void* stream);
 
 /* Pixel-wise cross entropy on the path's logits (segmentation/model/loss.py:9-48, caller
  * segmentation/model/module_multiscale.py:239): CE = mean over the non-ignored pixels of

@@ -37,6 +37,28 @@ static int x_vec_ok(const void* x, int x_dtype, int HW) {
     return HW % 8 == 0;   /* staging pieces are 8 pixels: they must be wholly inside or outside an image row */
 }
 
+// Scale-parallel launch (grid.y = scale): for pixel grids that do not fill the chip (the reference's training crops:
+// 10 x 65 x 65 px = 331 tiles on 512-768 workgroup slots, each walking every panel of every scale serially) the
+// panels of different scales are independent work - different channels of X and dX, different prototype rows - and run
+// as separate workgroups.  Only the logits (a sum over all prototypes) need a second step, a fixed-order sum of the
+// per-scale partials.  Returns the number of groups (1 = keep the single walk) and their first panels.
+#ifndef SPX_SPLIT_MAX_TILES
+#define SPX_SPLIT_MAX_TILES 1024
+#endif
+int spx_split_groups(const spx_plan& pl, int B, int HW, int32_t* group_first) {
+    const long long tiles = (long long)B * ((HW + SPX_TILE_PX - 1) / SPX_TILE_PX);
+    int g = 0;
+    for (int q = 0; q < pl.npanels; ++q)
+        if (q == 0 || pl.panel_ch0[q] != pl.panel_ch0[q - 1]) group_first[g++] = q;
+    group_first[g] = pl.npanels;
+    if (g < 2 || tiles > SPX_SPLIT_MAX_TILES) {
+        group_first[0] = 0;
+        group_first[1] = pl.npanels;
+        return 1;
+    }
+    return g;
+}
+
 hipError_t spx_launch_fwd_npb2(const SpxFwdArgs& a, int x_dtype, hipStream_t s);
 hipError_t spx_launch_fwd_npb4(const SpxFwdArgs& a, int x_dtype, hipStream_t s);
 hipError_t spx_launch_fwd_npb6(const SpxFwdArgs& a, int x_dtype, hipStream_t s);
@@ -145,7 +167,7 @@ static int dist_fwd_impl(const spx_plan* pl, const void* x, int32_t x_dtype, int
                          const void* packed_bank, const float* packed_p2, const void* packed_head, float* distances,
                          const int32_t* labels, const uint32_t* proto_key, int32_t J, float* cls_dist,
                          float* activations, float* logits, float epsilon, int32_t act_fn, void* stream,
-                         SpxTailFwd tail = SpxTailFwd{nullptr, 0, nullptr}, const spx_ce* ce = nullptr) {
+                         SpxTailFwd tail = SpxTailFwd{nullptr, 0, nullptr}, const spx_ce* ce = nullptr, void* split_ws = nullptr) {
     if (check_plan(pl)) return 1;
     if (!x || !packed_bank || !packed_p2) return fail("spx_dist_fwd: NULL operand");
     if (x_dtype != 0 && x_dtype != 1) return fail("spx_dist_fwd: x_dtype %d (0 = bf16, 1 = fp32)", x_dtype);
@@ -191,7 +213,22 @@ static int dist_fwd_impl(const spx_plan* pl, const void* x, int32_t x_dtype, int
     a.eps = epsilon;
     a.act_fn = act_fn;
     a.dbg = g_dbg;
-    return hip_status(spx_launch_fwd(a, x_dtype, (hipStream_t)stream), "spx_dist_fwd");
+    // scale-parallel launch: always when no logits are asked for; with logits when the caller brought the workspace for
+    // the per-scale partials (and neither a grouping tail nor the fused cross entropy rides on the logits tile)
+    a.ngroups = 1;
+    a.logits_group_stride = 0;
+    const int groups = spx_split_groups(*pl, B, HW, a.group_first);
+    if (groups > 1 && !tail.packed_tail && !ce && (!logits || split_ws)) {
+        a.ngroups = groups;
+        if (logits) {
+            a.logits = (float*)split_ws;
+            a.logits_group_stride = (size_t)B * HW * pl->num_classes;
+        }
+    }
+    if (hip_status(spx_launch_fwd(a, x_dtype, (hipStream_t)stream), "spx_dist_fwd")) return 1;
+    if (a.ngroups > 1 && logits)
+        return hip_status(spx_launch_sum_groups((const float*)split_ws, a.logits_group_stride, groups, logits, (hipStream_t)stream), "spx_dist_fwd (sum of the scale partials)");
+    return 0;
 }
 
 int spx_dist_fwd(const spx_plan* pl, const void* x, int32_t x_dtype, int32_t B, int32_t HW, const void* packed_bank,
@@ -279,6 +316,7 @@ static int dist_bwd_impl(const spx_plan* pl, const void* x, int32_t x_dtype, int
     a.eps = epsilon;
     a.act_fn = act_fn;
     a.dbg = g_dbg;
+    a.ngroups = spx_split_groups(*pl, B, HW, a.group_first);      // the backward needs no cross-scale step at all
     return hip_status(spx_launch_bwd(a, x_dtype, (hipStream_t)stream), "spx_dist_bwd");
 }
 
@@ -314,6 +352,28 @@ int spx_dist_bwd_cls(const spx_plan* pl, const void* x, int32_t x_dtype, int32_t
     return dist_bwd_impl(pl, x, x_dtype, B, HW, packed_bank, packed_bankT, packed_p2, packed_headT, nullptr,
                          d_class_distances ? labels : nullptr, proto_key, J, d_class_distances, d_act, d_logits, dx,
                          g_out, a_out, epsilon, act_fn, stream);
+}
+
+int32_t spx_fwd_split_groups(const spx_plan* pl, int32_t B, int32_t HW) {
+    int32_t gf[SPX_MAX_PANELS + 1];
+    return pl ? spx_split_groups(*pl, B, HW, gf) : 1;
+}
+size_t spx_fwd_split_workspace_bytes(const spx_plan* pl, int32_t B, int32_t HW) {
+    const int g = spx_fwd_split_groups(pl, B, HW);
+    return g > 1 ? (size_t)g * B * HW * pl->num_classes * sizeof(float) : 0;
+}
+int spx_dist_fwd_ws(const spx_plan* pl, const void* x, int32_t x_dtype, int32_t B, int32_t HW, const void* packed_bank,
+                    const float* packed_p2, const void* packed_head, const int32_t* labels_cls, const uint32_t* proto_key,
+                    int32_t J, float* class_distances, float* distances, float* activations, float* logits,
+                    void* split_workspace, float epsilon, int32_t act_fn, void* stream) {
+    if (labels_cls) {
+        if (check_cls("spx_dist_fwd_ws", labels_cls, proto_key, J, HW)) return 1;
+        if (!class_distances) return fail("spx_dist_fwd_ws: NULL class_distances");
+        if (distances) return fail("spx_dist_fwd_ws: class-gathered and P-wide distances are exclusive");
+    }
+    return dist_fwd_impl(pl, x, x_dtype, B, HW, packed_bank, packed_p2, packed_head, distances, labels_cls, proto_key,
+                         labels_cls ? J : 0, labels_cls ? class_distances : nullptr, activations, logits, epsilon, act_fn,
+                         stream, SpxTailFwd{nullptr, 0, nullptr}, nullptr, split_workspace);
 }
 
 size_t spx_ce_partials(int32_t B, int32_t HW) { return (size_t)B * ((HW + SPX_TILE_PX - 1) / SPX_TILE_PX) * 4; }

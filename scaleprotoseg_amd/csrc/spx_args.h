@@ -22,6 +22,11 @@ struct SpxFwdArgs {
     const char* packed_tail;   // W_g A-fragments (spx_pack_group_tail); NULL = no tail
     float* gact;               // [B*HW, U] exp(units) (optional)
     int K2;                    // classes of the tail (<= 32)
+    // scale-parallel launch for small pixel grids (grid.y = scale group): workgroup (tile, g) walks only the panels
+    // [group_first[g], group_first[g+1]) of scale g and writes its partial logits to logits + g * logits_group_stride
+    int ngroups;               // 1 = off
+    size_t logits_group_stride;
+    int32_t group_first[SPX_MAX_PANELS + 1];
     // fused cross entropy (spx_dist_fwd_ce): statistics of the logits tile, see spx_hip.h
     const int32_t* ce_labels;  // [B, HW]; NULL = off
     float* ce_lse;             // [B*HW]
@@ -50,6 +55,8 @@ struct SpxBwdArgs {
     const float* gact;          // [B*HW, U] exp(units) of the forward
     float* d_units;             // [B*HW, U] written for the parameter kernel
     int K2;
+    int ngroups;                // scale-parallel launch (see SpxFwdArgs); 1 = off
+    int32_t group_first[SPX_MAX_PANELS + 1];
     // fused cross entropy (spx_dist_bwd_ce): d_logits = coef * (softmax(logits) - onehot(label)) formed in the prologue
     const int32_t* ce_labels;   // [B, HW]; NULL = off (then d_logits above is used)
     const float* ce_logits;     // [B*HW, K] the forward's logits
@@ -100,6 +107,8 @@ hipError_t spx_launch_push_argmin(const float* dist, const int32_t* labels, cons
 hipError_t spx_launch_argmin_images(const float* values, int N, int P, int64_t* best, hipStream_t s);
 hipError_t spx_launch_upsample_argext(const float* src, int N, int C, int h, int w, int H, int W, int take_max,
                                       int64_t* idx, float* val, hipStream_t s);
+hipError_t spx_launch_sum_groups(const float* parts, size_t n, int groups, float* out, hipStream_t s);
+int spx_split_groups(const spx_plan& pl, int B, int HW, int32_t* group_first);
 hipError_t spx_launch_ce_fwd(const float* logits, const int32_t* labels, long long M, int K, float* lse, int32_t* pred,
                              float* partials, hipStream_t s);
 hipError_t spx_launch_ce_bwd(const float* logits, const float* lse, const int32_t* labels, const float* coef, long long M, int K,

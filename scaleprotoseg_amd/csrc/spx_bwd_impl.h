@@ -123,6 +123,10 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
     const bool have_dd = GATHER ? a.d_cls_dist != nullptr : a.d_dist != nullptr;
 
     const bool have_dl = a.d_logits != nullptr || a.ce_labels != nullptr;     // a gradient reaches the logits
+    // scale-parallel launch (grid.y = scale group): this workgroup's panels; group 0 alone writes the per-pixel by-products
+    const int q_begin = a.ngroups > 1 ? a.group_first[blockIdx.y] : 0;
+    const int q_end = a.ngroups > 1 ? a.group_first[blockIdx.y + 1] : pl.npanels;
+    const bool g0 = blockIdx.y == 0;
     const bool act_is_log = a.act_fn == 0;
     const float act_c1 = act_is_log ? -(1.0f - a.eps) : -1.0f;
     // dLogits of this lane's pixel as split-bf16 B fragments: element j of k-step c <-> class 16c + 8h + j
@@ -214,7 +218,7 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
                 } else {
                     const float gval = buf_load_f32(gir, u < K ? voff_u : SPX_OOB, so);
                     dg[reg] *= gval;                               // dropped loads return 0: padded units / pixels
-                    buf_store_f32(dg[reg], dur, u < K ? voff_u : SPX_OOB, so);
+                    buf_store_f32(dg[reg], dur, (u < K && g0) ? voff_u : SPX_OOB, so);
                 }
 #endif
             }
@@ -229,7 +233,7 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
                 }
             }
         }
-        if (BLK) block_flush(a.d_units + (size_t)b * a.HW * K, K);
+        if (BLK && g0) block_flush(a.d_units + (size_t)b * a.HW * K, K);
     } else {
         // d_logits of the wave's pixels: given ([px][K] fp32), or - fused cross entropy - formed here from the forward's
         // logits: coef * (softmax - onehot) on the non-ignored pixels (loss.py:9-48 through autograd), written out once
@@ -263,7 +267,7 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
                     if (BLK) {
                         if (cls < K) bsc[r * K + cls] = v;
                     } else {
-                        buf_store_f32(v, dor, cls < K ? voff_l : SPX_OOB, (uint32_t)((c * 16 + j) * 4));
+                        buf_store_f32(v, dor, (cls < K && g0) ? voff_l : SPX_OOB, (uint32_t)((c * 16 + j) * 4));
                     }
                 }
                 v *= act_c1;
@@ -273,7 +277,7 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
                 dllo[c][j] = lo;
             }
         }
-        if (BLK && ce && a.ce_dlogits_out) block_flush(a.ce_dlogits_out + (size_t)b * a.HW * K, K);
+        if (BLK && ce && a.ce_dlogits_out && g0) block_flush(a.ce_dlogits_out + (size_t)b * a.HW * K, K);
     }
     if (BLK) __syncthreads();      // the scratch sits in the main-loop stages: every wave is done with it before they fill
 
@@ -323,7 +327,7 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
         // inverse scales of the G blob: one float per (lane, block) behind the blobs, [panel][tile][wave][block][lane]
         const size_t blob_total = (size_t)pl.npanels * ntiles * 4 * NPB * 2 * 1024;
         const spx_rsrc gsr = make_rsrc(a.g_out ? (const char*)a.g_out + blob_total + blob0 / 8 : nullptr);
-        if (a.a_out && blockIdx.x == 0 && panel == 0 && tid == 0)
+        if (a.a_out && blockIdx.x == 0 && blockIdx.y == 0 && panel == 0 && tid == 0)
             *(uint32_t*)((char*)a.a_out + blob_total) = (SPX_ABLOB_USE_E4M12 && act_is_log) ? SPX_ABLOB_E4M12 : SPX_ABLOB_FP16;
 
         // ---- phase 1: G, a — a ROLLED loop over the panel's 32-prototype blocks.  The block being processed is
@@ -559,7 +563,7 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
         // ---- phase 2: dX^T[ch x px] = 2 (rs * x - P^T . G), one 32-channel block per (rolled) iteration ----
         const float rs_tot = rs + __shfl_xor(rs, 32);
         if (h == 0) rss[32 * wave + r] = rs_tot;
-        const bool first_of_scale = (panel == 0) || (pl.panel_ch0[panel - 1] != ch0);
+        const bool first_of_scale = (panel == q_begin) || (pl.panel_ch0[panel - 1] != ch0);
         constexpr int BT = spx_bwd_bt_bytes<NPB>();
         char* const bt = smem;                               // 2 x BT  (P^T fragments of one channel block)
         char* const tt0 = smem + 2 * BT;                     // fp32 transpose tile 0
@@ -705,7 +709,7 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
                 }
             }
         }
-        if (panel + 1 < pl.npanels) clear_acc();       // the next panel (if any) accumulates from zero
+        if (panel + 1 < q_end) clear_acc();            // the next panel (if any) accumulates from zero
         __syncthreads();   // T tiles / P^T stages are rewritten by the next panel's main loop
     };
 
@@ -714,7 +718,7 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
 #ifdef SPX_DIAG_STAMPS
     unsigned long long t0 = __builtin_amdgcn_s_memtime(), t1 = 0, t3 = 0;
 #endif
-    for (int panel = 0; panel < pl.npanels; ++panel) {
+    for (int panel = q_begin; panel < q_end; ++panel) {
         const char* bank0 = a.packed_bank + (size_t)(panel * nchunks) * chunk_bytes;
         x2part = 0.0f;
         pipe.run_panel(acc, x2part, tc, smem, bank0, pl.panel_ch0[panel], Cs, lane, wave, tid,
@@ -769,7 +773,7 @@ template <int NPB>
 static hipError_t spx_launch_bwd_npb(const SpxBwdArgs& a, int x_dtype, hipStream_t s) {
     const spx_plan& pl = a.plan;
     const int tiles = (a.HW + SPX_TILE_PX - 1) / SPX_TILE_PX;
-    dim3 grid((unsigned)(tiles * a.B));
+    dim3 grid((unsigned)(tiles * a.B), (unsigned)(a.ngroups > 1 ? a.ngroups : 1));
     if (pl.ncb == 1) return launch_bwd_x<NPB, 1>(a, x_dtype, grid, s);
     if (pl.ncb == 2) return launch_bwd_x<NPB, 2>(a, x_dtype, grid, s);
     return launch_bwd_x<NPB, 5>(a, x_dtype, grid, s);

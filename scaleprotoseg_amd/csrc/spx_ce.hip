@@ -51,6 +51,21 @@ __global__ __launch_bounds__(SPX_CE_THREADS) void spx_ce_bwd_kernel(const float*
     d_logits[i] = valid ? *coef * (ce_exp(logits[i] - lse[m_]) - (k == lab ? 1.0f : 0.0f)) : 0.0f;
 }
 
+// out[i] = sum over the scale groups of parts[g][i], in group order (deterministic): the logits of a scale-parallel forward
+__global__ __launch_bounds__(SPX_CE_THREADS) void spx_sum_groups_kernel(const float* __restrict__ parts, size_t n, int groups,
+                                                                      float* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * SPX_CE_THREADS + threadIdx.x;
+    if (i >= n) return;
+    float s = parts[i];
+    for (int g = 1; g < groups; ++g) s += parts[(size_t)g * n + i];
+    out[i] = s;
+}
+hipError_t spx_launch_sum_groups(const float* parts, size_t n, int groups, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(spx_sum_groups_kernel, dim3((unsigned)((n + SPX_CE_THREADS - 1) / SPX_CE_THREADS)), dim3(SPX_CE_THREADS), 0, s,
+                       parts, n, groups, out);
+    return hipGetLastError();
+}
+
 hipError_t spx_launch_ce_fwd(const float* logits, const int32_t* labels, long long M, int K, float* lse, int32_t* pred,
                              float* partials, hipStream_t s) {
     const unsigned grid = (unsigned)((M + SPX_CE_THREADS - 1) / SPX_CE_THREADS);

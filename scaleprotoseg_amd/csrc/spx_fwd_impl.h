@@ -69,6 +69,10 @@ __global__ __launch_bounds__(256 * SPLIT, (NPB == 2 && NCB == 1 ? 3 : SPX_FWD_WA
     const int C = pl.num_scales * Cs;
     const int P = pl.num_prototypes, K = pl.num_classes;
     const uint32_t HW = (uint32_t)a.HW;
+    // scale-parallel launch: this workgroup's panels and its (partial) logits plane
+    const int q_begin = a.ngroups > 1 ? a.group_first[blockIdx.y] : 0;
+    const int q_end = a.ngroups > 1 ? a.group_first[blockIdx.y + 1] : pl.npanels;
+    float* const logits_out = a.logits ? a.logits + (size_t)blockIdx.y * a.logits_group_stride : nullptr;
     constexpr int XR = SPX_FWD_XRING(XF32);
     using Pipe = SpxPipeline<NPB, XF32, VEC, XR, NT, NH>;
 
@@ -278,7 +282,7 @@ __global__ __launch_bounds__(256 * SPLIT, (NPB == 2 && NCB == 1 ? 3 : SPX_FWD_WA
             }
         }
         // the next panel (if any) accumulates from zero
-        if (panel + 1 < pl.npanels) {
+        if (panel + 1 < q_end) {
 #pragma unroll
             for (int pb = 0; pb < NH; ++pb)
 #pragma unroll
@@ -294,11 +298,11 @@ __global__ __launch_bounds__(256 * SPLIT, (NPB == 2 && NCB == 1 ? 3 : SPX_FWD_WA
     // not what the multi-panel forward waits for - so it is off.
     constexpr bool PREFETCH_NEXT = SPX_FWD_XPANEL && NPB == 2 && NCB <= 2;
     auto bank_of = [&](int panel) { return a.packed_bank + (size_t)(panel * nchunks) * chunk_bytes; };
-    pipe.issue_prologue(tc, bank_of(0), pl.panel_ch0[0], Cs, tid, [&]() { consts_issue(0); });
-    for (int panel = 0; panel < pl.npanels; ++panel) {
+    pipe.issue_prologue(tc, bank_of(q_begin), pl.panel_ch0[q_begin], Cs, tid, [&]() { consts_issue(q_begin); });
+    for (int panel = q_begin; panel < q_end; ++panel) {
         x2part = 0.0f;
         pipe.run_body(acc, x2part, tc, smem, bank_of(panel), pl.panel_ch0[panel], Cs, lane, wave, tid, consts_commit);
-        const bool more = panel + 1 < pl.npanels;
+        const bool more = panel + 1 < q_end;
         if (PREFETCH_NEXT && more)
             pipe.issue_prologue(tc, bank_of(panel + 1), pl.panel_ch0[panel + 1], Cs, tid, [&]() { consts_issue(panel + 1); });
 #ifdef SPX_DIAG_STAMPS
@@ -446,9 +450,9 @@ __global__ __launch_bounds__(256 * SPLIT, (NPB == 2 && NCB == 1 ? 3 : SPX_FWD_WA
                     const int cls = cb * 32 + acc_row(reg, h);
                     if (cls < K) bsc[r * K + cls] = accl[cb][reg];
                 }
-            block_flush(a.logits + (size_t)b * a.HW * K, K);
+            block_flush(logits_out + (size_t)b * a.HW * K, K);
         } else {
-            const spx_rsrc lr = make_rsrc_pred(a.logits + (size_t)b * a.HW * K);
+            const spx_rsrc lr = make_rsrc_pred(logits_out + (size_t)b * a.HW * K);
             const uint32_t voff_l = px_ok ? ((uint32_t)px * (uint32_t)K + (uint32_t)(4 * h)) * 4u : SPX_OOB;   // [px][class]
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb) {
@@ -497,7 +501,7 @@ template <int NPB>
 static hipError_t spx_launch_fwd_npb(const SpxFwdArgs& a, int x_dtype, hipStream_t s) {
     const spx_plan& pl = a.plan;
     const int tiles = (a.HW + SPX_TILE_PX - 1) / SPX_TILE_PX;
-    dim3 grid((unsigned)(tiles * a.B));
+    dim3 grid((unsigned)(tiles * a.B), (unsigned)(a.ngroups > 1 ? a.ngroups : 1));
     // SPX_FWD_SPLIT 2 = 8-wave workgroups (4 waves per SIMD): measured 0.84 vs 0.72 ms at the north-star shape, off
     if (pl.ncb == 1) return launch_fwd_x<NPB, 1, SPX_FWD_SPLIT>(a, x_dtype, grid, s);
     // 33..64 head rows (the grouping head: 3 groups x 19 / 21 classes)

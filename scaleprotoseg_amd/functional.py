@@ -328,49 +328,44 @@ class _ProtoHeadFn(torch.autograd.Function):
                         _lib.ptr(gact), _lib.ptr(logits), float(epsilon), ACT_FN[act_fn], _lib.stream_ptr(),
                     )
                 )
-        elif gather is not None:
-            if tuple(gather.labels.shape) != (B, HW) or gather.labels.dtype != torch.int32:
-                raise SpxError(f"gather labels must be int32 [{B}, {HW}]")
-            # slots no prototype maps to (and pixels without a class) stay 0
-            dist = torch.zeros((B, gather.width, HW), **f32)
-            with _timed("spx_dist_fwd"):
-                if ce is not None:
-                    _lib.check(
-                        lib.spx_dist_fwd_ce(
-                            C.byref(plan), _lib.ptr(x), xd, B, HW, _lib.ptr(packs.bank), _lib.ptr(packs.p2),
-                            _lib.ptr(packs.head), _lib.ptr(gather.labels), _lib.ptr(gather.keys), gather.width,
-                            _lib.ptr(dist), None, _lib.ptr(act), _lib.ptr(logits), C.byref(ce), float(epsilon),
-                            ACT_FN[act_fn], _lib.stream_ptr(),
-                        )
-                    )
-                else:
-                  _lib.check(
-                    lib.spx_dist_fwd_cls(
-                        C.byref(plan), _lib.ptr(x), xd, B, HW, _lib.ptr(packs.bank), _lib.ptr(packs.p2),
-                        _lib.ptr(packs.head), _lib.ptr(gather.labels), _lib.ptr(gather.keys), gather.width,
-                        _lib.ptr(dist), _lib.ptr(act), _lib.ptr(logits), float(epsilon), ACT_FN[act_fn],
-                        _lib.stream_ptr(),
-                    )
-                )
         else:
-            dist = torch.empty((B, P) + tuple(x.shape[2:]), **f32) if want_dist else None
+            if gather is not None:
+                if tuple(gather.labels.shape) != (B, HW) or gather.labels.dtype != torch.int32:
+                    raise SpxError(f"gather labels must be int32 [{B}, {HW}]")
+                # slots no prototype maps to (and pixels without a class) stay 0
+                dist = torch.zeros((B, gather.width, HW), **f32)
+                g_args = (_lib.ptr(gather.labels), _lib.ptr(gather.keys), gather.width, _lib.ptr(dist), None)
+            else:
+                dist = torch.empty((B, P) + tuple(x.shape[2:]), **f32) if want_dist else None
+                g_args = (None, None, 0, None, _lib.ptr(dist))
+            # small pixel grids run one workgroup per (tile, scale) (include/spx_hip.h, "Scale-parallel forward"); the
+            # logits then need a workspace for the per-scale partials, and the cross entropy (which wants the SUMMED
+            # logits) runs as the stand-alone kernel right behind
+            ws_bytes = lib.spx_fwd_split_workspace_bytes(C.byref(plan), B, HW) if head is not None else 0
             with _timed("spx_dist_fwd"):
-                if ce is not None:
+                if ce is not None and ws_bytes == 0:
                     _lib.check(
                         lib.spx_dist_fwd_ce(
                             C.byref(plan), _lib.ptr(x), xd, B, HW, _lib.ptr(packs.bank), _lib.ptr(packs.p2),
-                            _lib.ptr(packs.head), None, None, 0, None, _lib.ptr(dist), _lib.ptr(act), _lib.ptr(logits),
-                            C.byref(ce), float(epsilon), ACT_FN[act_fn], _lib.stream_ptr(),
-                        )
-                    )
-                else:
-                    _lib.check(
-                        lib.spx_dist_fwd(
-                            C.byref(plan), _lib.ptr(x), xd, B, HW, _lib.ptr(packs.bank), _lib.ptr(packs.p2),
-                            _lib.ptr(packs.head), _lib.ptr(dist), _lib.ptr(act), _lib.ptr(logits), float(epsilon),
+                            _lib.ptr(packs.head), *g_args, _lib.ptr(act), _lib.ptr(logits), C.byref(ce), float(epsilon),
                             ACT_FN[act_fn], _lib.stream_ptr(),
                         )
                     )
+                else:
+                    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device) if ws_bytes else None
+                    _lib.check(
+                        lib.spx_dist_fwd_ws(
+                            C.byref(plan), _lib.ptr(x), xd, B, HW, _lib.ptr(packs.bank), _lib.ptr(packs.p2),
+                            _lib.ptr(packs.head), *g_args, _lib.ptr(act), _lib.ptr(logits), _lib.ptr(ws), float(epsilon),
+                            ACT_FN[act_fn], _lib.stream_ptr(),
+                        )
+                    )
+                    if ce is not None:
+                        ce_labels_, lse_, pred_, _ = ce_state
+                        partials = torch.empty((lib.spx_ce_partials_flat(B * HW), 2), **f32)
+                        _lib.check(lib.spx_ce_fwd(_lib.ptr(logits), _lib.ptr(ce_labels_), B * HW, K, _lib.ptr(lse_),
+                                                  _lib.ptr(pred_), _lib.ptr(partials), _lib.stream_ptr()))
+                        ce_state = (ce_labels_, lse_, pred_, partials)
         ctx.gather = gather
         ctx.gact = gact
         ctx.tail2d = tail2d
