@@ -12,6 +12,7 @@ struct SpxFwdArgs {
     float* act;
     float* logits;
     int B, HW, vec_ok;
+    int tile_first, tiles_launch;   // this launch covers tiles [tile_first, tile_first + tiles_launch) of every image
     int dist_vec;              // distances 16-B aligned and HW % 4 == 0: 16-B stores of 4 pixels of a row
     // class-gathered distances (spx_dist_fwd_cls): every pixel keeps only the distances to its own class's prototypes
     const int32_t* labels;     // [B, HW] class per pixel (anything outside 0..0xFFFD = none)
@@ -67,6 +68,7 @@ struct SpxBwdArgs {
     uint16_t* g_out;
     uint16_t* a_out;
     int B, HW, vec_ok;
+    int tile_first, tiles_launch;   // this launch covers tiles [tile_first, tile_first + tiles_launch) of every image
     float eps;
     int act_fn;
     unsigned long long* dbg;
@@ -82,6 +84,8 @@ struct SpxBankBwdArgs {
     float* d_W;
     float* workspace;
     int B, HW, vec_ok, nsplit;
+    int ci_first, nci_launch;   // this launch covers chunks [ci_first, ci_first + nci_launch) of every image ...
+    int slab_first, nslabs;     // ... with nslabs workgroups writing slabs [slab_first, slab_first + nslabs); nsplit = all slabs
 };
 // Slot (16-B unit) of lane (r = pixel, h) inside the 1-KiB fragment blob of k-step s2.  Kernel 2 copies the blobs
 // verbatim into LDS and reads them back with ds_read_b64_tr_b16 (pixel = k): the 32 lanes of a half-wave then

@@ -25,12 +25,22 @@ __host__ __device__ constexpr int spx_bk_row(int cpx) { return 2 * cpx + 16; }
 __host__ __device__ inline int spx_bk_wstride(const spx_plan& pl) {
     return ((pl.channels_per_scale + 31) / 32) * 32 + pl.ncb * 32 + 32;   // [dP cols | dW cols | colsum + pad]
 }
+// The chunk walk is launched in up to two parts (see spx_launch_fwd_npb: vector staging wants whole 8-pixel pieces): the
+// chunks that lie wholly inside their image, and - when H*W is not a multiple of 8 - each image's ragged last chunk(s) on
+// the element-wise path.  Both parts write partial slabs; the reduction kernel sums all of them.
+static void spx_bank_parts(const spx_plan& pl, int B, int HW, int& nci, int& nci_vec, int& slabs_vec, int& slabs_tail) {
+    nci = 2 * ((HW + SPX_TILE_PX - 1) / SPX_TILE_PX);           // 64-px chunks per image (the blobs are tile-granular)
+    nci_vec = HW >= 8 ? nci : 0;                                 // the vector staging path handles a ragged image end itself (H*W >= 8)
+    long long cap = 256 / pl.npanels;
+    if (cap < 1) cap = 1;
+    const long long cv = (long long)B * nci_vec, ct = (long long)B * (nci - nci_vec);
+    slabs_vec = (int)(cv < cap ? cv : cap);
+    slabs_tail = (int)(ct < cap ? ct : cap);
+}
 int spx_bank_bwd_nsplit(const spx_plan& pl, int B, int HW) {
-    const long long chunks = 2LL * B * ((HW + SPX_TILE_PX - 1) / SPX_TILE_PX);
-    long long n = 256 / pl.npanels;
-    if (n < 1) n = 1;
-    if (n > chunks) n = chunks;
-    return (int)n;
+    int nci, nci_vec, sv, st;
+    spx_bank_parts(pl, B, HW, nci, nci_vec, sv, st);
+    return sv + st;
 }
 size_t spx_bank_bwd_ws_floats(const spx_plan& pl, int nsplit) {
     return (size_t)nsplit * pl.npanels * pl.npb * 32 * spx_bk_wstride(pl);
@@ -52,8 +62,9 @@ __host__ __device__ constexpr int spx_bk_lds_bytes() {
 // 5-block head (80 d_W accumulators per lane next to 96 for d_bank) the launcher runs two instances, each with its
 // own operands only (G + X, or a + dLogits): no byte is read twice and neither instance spills.
 // KSPLIT: scales of <= 64 channels (see the wave roles below).
-template <int NPB, int NCB, bool XF32, bool VEC, bool DO_P, bool DO_W, bool KSPLIT, int CPX>
+template <int NPB, int NCB, bool XF32, int VM, bool DO_P, bool DO_W, bool KSPLIT, int CPX>
 __global__ __launch_bounds__(SPX_BK_THREADS, 2) void spx_bank_bwd_kernel(const SpxBankBwdArgs a) {
+    constexpr bool VEC = VM != 0, RAG = VM == 2;
     constexpr int SPX_BK_PX = CPX, SPX_BK_ROW = spx_bk_row(CPX);
     constexpr int NW1 = CPX / 32;                     // kernel-1 waves per chunk
     constexpr bool PIPE = CPX == 32;
@@ -63,7 +74,7 @@ __global__ __launch_bounds__(SPX_BK_THREADS, 2) void spx_bank_bwd_kernel(const S
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
-    const int q = blockIdx.y, split = blockIdx.x;
+    const int q = blockIdx.y, split = blockIdx.x;      // split: this launch's workgroup index; its slab is slab_first + split
     const int Cs = pl.channels_per_scale, K = pl.num_classes;
     const int C = pl.num_scales * Cs;
     const int nchb = (Cs + 31) / 32;
@@ -71,12 +82,14 @@ __global__ __launch_bounds__(SPX_BK_THREADS, 2) void spx_bank_bwd_kernel(const S
     const int ch0 = pl.panel_ch0[q];
     const int tiles_per_img = (a.HW + SPX_TILE_PX - 1) / SPX_TILE_PX;
     const size_t ntiles = (size_t)a.B * tiles_per_img;
-    const int nci = (SPX_TILE_PX / CPX) * tiles_per_img;     // chunks per image
+    static_assert(CPX == 64 || CPX == 32, "chunk width");
+    const int nci = a.nci_launch * (64 / CPX);               // chunks per image IN THIS LAUNCH (the launcher counts 64-px chunks)
+    const int ci0 = a.ci_first * (64 / CPX);
     const long long total = (long long)a.B * nci;
     // chunk c belongs to workgroup c mod nsplit: the workgroups running at one time then cover CONSECUTIVE chunks, i.e.
     // one contiguous stretch of every X row (16-32 KB) and of the blobs, instead of 128-B pieces 16 KB apart
     // (DRAM page locality).  Every slab still sums a fixed chunk set in a fixed order: results stay deterministic.
-    const long long cstep = a.nsplit;
+    const long long cstep = a.nslabs;
     const long long c_begin = split;
     const long long c_end = total;                     // exclusive bound of this workgroup's walk c_begin, c_begin + cstep, ...
     const long long c_last = c_begin < total ? c_begin + ((total - 1 - c_begin) / cstep) * cstep : c_begin;
@@ -138,6 +151,8 @@ __global__ __launch_bounds__(SPX_BK_THREADS, 2) void spx_bank_bwd_kernel(const S
         u32x4 gr[FP], ar[FP], xr[XPT][XF32 ? 2 : 1];
         float gsc[FP];                                // inverse scale of each staged G piece (one lane of one block)
         float lr_[(CPX * 32 * NCB + SPX_BK_THREADS - 1) / SPX_BK_THREADS];
+        uint32_t rot_bits;                            // this thread's X piece straddles the image end (see SpxXStager::make_ctx)
+        bool ragged;                                  // chunk-uniform: some piece of the chunk does
     };
     Stage stg[PIPE ? 2 : 1];
     // piece -> (fragment, lane) of the blob: the inverse of spx_blob_slot.  Fixed per thread for the whole launch.
@@ -161,7 +176,7 @@ __global__ __launch_bounds__(SPX_BK_THREADS, 2) void spx_bank_bwd_kernel(const S
         c = c_begin;                                  // timing-only build: every chunk re-reads the first one (cache hits)
 #endif
         const int b = (int)(c / nci);
-        const int ci = (int)(c - (long long)b * nci);
+        const int ci = ci0 + (int)(c - (long long)b * nci);
         constexpr int CPT = SPX_TILE_PX / CPX;            // chunks per kernel-1 tile
         const size_t tile_g = (size_t)b * tiles_per_img + ci / CPT;
         // the chunk's fragments are contiguous: kernel-1 waves NW1 (ci % CPT) ... of the tile
@@ -177,6 +192,11 @@ __global__ __launch_bounds__(SPX_BK_THREADS, 2) void spx_bank_bwd_kernel(const S
             st.ar[i] = buf_load_b128_p<SPX_AUX_BLOB_LD>(ars, (want_w && off < (uint32_t)FBYTES) ? off : SPX_OOB, 0);
         }
         const int px = ci * SPX_BK_PX + piece * 8;
+        {
+            const int over = px + 8 - a.HW;
+            st.rot_bits = (RAG && over > 0 && over < 8) ? (uint32_t)over * (ESZ * 8) : 0u;
+            st.ragged = RAG && (ci * SPX_BK_PX + SPX_BK_PX > a.HW);
+        }
 #pragma unroll
         for (int i = 0; i < XPT; ++i) {
             const int row = prow + RPP * i;
@@ -185,7 +205,8 @@ __global__ __launch_bounds__(SPX_BK_THREADS, 2) void spx_bank_bwd_kernel(const S
             const uint32_t vo = ((uint32_t)prow * (uint32_t)a.HW + (uint32_t)px) * ESZ;
             const bool row_ok = want_p && row < Cs;
             if (VEC) {
-                const uint32_t v = (row_ok && px + 8 <= a.HW) ? vo : SPX_OOB;
+                const int over = px + 8 - a.HW;                  // elements of the piece past the image
+                const uint32_t v = !row_ok ? SPX_OOB : (over <= 0 ? vo : ((RAG && over < 8) ? vo - (uint32_t)over * ESZ : SPX_OOB));
                 st.xr[i][0] = buf_load_b128(xb, v, 0);
                 if (XF32) st.xr[i][1] = buf_load_b128(xb, v == SPX_OOB ? SPX_OOB : v + 16, 0);
             } else if (XF32) {
@@ -247,6 +268,13 @@ __global__ __launch_bounds__(SPX_BK_THREADS, 2) void spx_bank_bwd_kernel(const S
                     *(u32x4*)(As + off) = __builtin_bit_cast(u32x4, ahi);
                     *(u32x4*)(As2 + off) = __builtin_bit_cast(u32x4, alo);
                 }
+            }
+        }
+        if (RAG && st.ragged) {                              // chunk-uniform: shift the moved-back window into place
+#pragma unroll
+            for (int i = 0; i < XPT; ++i) {
+                if (XF32) spx_shr256(st.xr[i][0], st.xr[i][XF32 ? 1 : 0], st.rot_bits);
+                else st.xr[i][0] = spx_shr128(st.xr[i][0], st.rot_bits);
             }
         }
 #pragma unroll
@@ -442,7 +470,7 @@ __global__ __launch_bounds__(SPX_BK_THREADS, 2) void spx_bank_bwd_kernel(const S
 
     // ---- write this workgroup's partial slab ----
     const int ws = spx_bk_wstride(pl);
-    float* slab = a.workspace + ((size_t)split * pl.npanels + q) * rows * ws;
+    float* slab = a.workspace + ((size_t)(a.slab_first + split) * pl.npanels + q) * rows * ws;
     if (want_p && (!ksplit || cpair == 0)) {
 #pragma unroll
         for (int i = 0; i < PH; ++i) {
@@ -554,11 +582,13 @@ static hipError_t launch_bank_k(const SpxBankBwdArgs& a, int x_dtype, dim3 grid,
     constexpr size_t lds = (size_t)spx_bk_lds_bytes<NPB, NCB, DO_P, DO_W, CPX>();
     static_assert(lds <= SPX_LDS_LIMIT, "bank kernel LDS");
     if (x_dtype == 1) {
-        if (a.vec_ok) hipLaunchKernelGGL((spx_bank_bwd_kernel<NPB, NCB, true, true, DO_P, DO_W, KSPLIT, CPX>), grid, dim3(SPX_BK_THREADS), lds, s, a);
-        else hipLaunchKernelGGL((spx_bank_bwd_kernel<NPB, NCB, true, false, DO_P, DO_W, KSPLIT, CPX>), grid, dim3(SPX_BK_THREADS), lds, s, a);
+        if (a.vec_ok == 2) hipLaunchKernelGGL((spx_bank_bwd_kernel<NPB, NCB, true, 2, DO_P, DO_W, KSPLIT, CPX>), grid, dim3(SPX_BK_THREADS), lds, s, a);
+        else if (a.vec_ok) hipLaunchKernelGGL((spx_bank_bwd_kernel<NPB, NCB, true, 1, DO_P, DO_W, KSPLIT, CPX>), grid, dim3(SPX_BK_THREADS), lds, s, a);
+        else hipLaunchKernelGGL((spx_bank_bwd_kernel<NPB, NCB, true, 0, DO_P, DO_W, KSPLIT, CPX>), grid, dim3(SPX_BK_THREADS), lds, s, a);
     } else {
-        if (a.vec_ok) hipLaunchKernelGGL((spx_bank_bwd_kernel<NPB, NCB, false, true, DO_P, DO_W, KSPLIT, CPX>), grid, dim3(SPX_BK_THREADS), lds, s, a);
-        else hipLaunchKernelGGL((spx_bank_bwd_kernel<NPB, NCB, false, false, DO_P, DO_W, KSPLIT, CPX>), grid, dim3(SPX_BK_THREADS), lds, s, a);
+        if (a.vec_ok == 2) hipLaunchKernelGGL((spx_bank_bwd_kernel<NPB, NCB, false, 2, DO_P, DO_W, KSPLIT, CPX>), grid, dim3(SPX_BK_THREADS), lds, s, a);
+        else if (a.vec_ok) hipLaunchKernelGGL((spx_bank_bwd_kernel<NPB, NCB, false, 1, DO_P, DO_W, KSPLIT, CPX>), grid, dim3(SPX_BK_THREADS), lds, s, a);
+        else hipLaunchKernelGGL((spx_bank_bwd_kernel<NPB, NCB, false, 0, DO_P, DO_W, KSPLIT, CPX>), grid, dim3(SPX_BK_THREADS), lds, s, a);
     }
     return hipGetLastError();
 }
@@ -580,17 +610,32 @@ static hipError_t launch_bank_x(const SpxBankBwdArgs& a, int x_dtype, dim3 grid,
     }
 }
 
-hipError_t spx_launch_bank_bwd(const SpxBankBwdArgs& a, int x_dtype, hipStream_t s) {
+static hipError_t spx_launch_bank_part(const SpxBankBwdArgs& a, int x_dtype, hipStream_t s) {
+    const spx_plan& pl = a.plan;
+    dim3 grid((unsigned)a.nslabs, (unsigned)pl.npanels);
+    if (pl.ncb == 1)
+        return pl.npb == 2 ? launch_bank_x<2, 1>(a, x_dtype, grid, s) : pl.npb == 4 ? launch_bank_x<4, 1>(a, x_dtype, grid, s) : launch_bank_x<6, 1>(a, x_dtype, grid, s);
+    if (pl.ncb == 2)
+        return pl.npb == 2 ? launch_bank_x<2, 2>(a, x_dtype, grid, s) : pl.npb == 4 ? launch_bank_x<4, 2>(a, x_dtype, grid, s) : launch_bank_x<6, 2>(a, x_dtype, grid, s);
+    return pl.npb == 2 ? launch_bank_x<2, 5>(a, x_dtype, grid, s) : pl.npb == 4 ? launch_bank_x<4, 5>(a, x_dtype, grid, s) : launch_bank_x<6, 5>(a, x_dtype, grid, s);
+}
+
+hipError_t spx_launch_bank_bwd(const SpxBankBwdArgs& a0, int x_dtype, hipStream_t s) {
+    SpxBankBwdArgs a = a0;
     const spx_plan& pl = a.plan;
     const int rows = pl.npb * 32;
-    dim3 grid((unsigned)a.nsplit, (unsigned)pl.npanels);
-    hipError_t e;
-    if (pl.ncb == 1)
-        e = pl.npb == 2 ? launch_bank_x<2, 1>(a, x_dtype, grid, s) : pl.npb == 4 ? launch_bank_x<4, 1>(a, x_dtype, grid, s) : launch_bank_x<6, 1>(a, x_dtype, grid, s);
-    else if (pl.ncb == 2)
-        e = pl.npb == 2 ? launch_bank_x<2, 2>(a, x_dtype, grid, s) : pl.npb == 4 ? launch_bank_x<4, 2>(a, x_dtype, grid, s) : launch_bank_x<6, 2>(a, x_dtype, grid, s);
-    else
-        e = pl.npb == 2 ? launch_bank_x<2, 5>(a, x_dtype, grid, s) : pl.npb == 4 ? launch_bank_x<4, 5>(a, x_dtype, grid, s) : launch_bank_x<6, 5>(a, x_dtype, grid, s);
+    int nci, nci_vec, sv, st;
+    spx_bank_parts(pl, a.B, a.HW, nci, nci_vec, sv, st);
+    a.nsplit = sv + st;
+    hipError_t e = hipSuccess;
+    if (sv > 0) {
+        a.vec_ok = a.HW % 8 == 0 ? 1 : 2; a.ci_first = 0; a.nci_launch = nci_vec; a.slab_first = 0; a.nslabs = sv;
+        e = spx_launch_bank_part(a, x_dtype, s);
+    }
+    if (e == hipSuccess && st > 0) {
+        a.vec_ok = 0; a.ci_first = nci_vec; a.nci_launch = nci - nci_vec; a.slab_first = sv; a.nslabs = st;
+        e = spx_launch_bank_part(a, x_dtype, s);
+    }
     if (e != hipSuccess) return e;
     const long long n = (long long)pl.npanels * rows * (pl.channels_per_scale + pl.num_classes);
     hipLaunchKernelGGL(spx_bank_reduce_kernel, dim3((unsigned)((n + SPX_RED_ELEMS - 1) / SPX_RED_ELEMS)),

@@ -66,16 +66,22 @@ static_assert(spx_bwd_lds_bytes<6, 1>() <= 80 * 1024, "pixel kernel must fit two
 // ------------------------------------------------------------------------------------------------
 // GATHER: the distance gradient arrives class-gathered ([B, HW, J], spx_dist_bwd_cls) instead of P-wide.
 // DACT: a gradient arrives on the [pixel][P] activations (kept out of the default instance).
-template <int NPB, int NCB, bool XF32, bool VEC, bool GATHER, bool DACT>
+template <int NPB, int NCB, bool XF32, int VM, bool GATHER, bool DACT>
 __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBwdArgs a) {
+    constexpr bool VEC = VM != 0, RAG = VM == 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const spx_plan& pl = a.plan;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
     const int tiles_per_img = (a.HW + SPX_TILE_PX - 1) / SPX_TILE_PX;
+#ifdef SPX_T_NOTILES
     const int b = blockIdx.x / tiles_per_img;
     const int tile_i = blockIdx.x % tiles_per_img;
+#else
+    const int b = blockIdx.x / a.tiles_launch;
+    const int tile_i = a.tile_first + blockIdx.x % a.tiles_launch;
+#endif
     const int px0 = tile_i * SPX_TILE_PX;
     const size_t ntiles = (size_t)a.B * tiles_per_img;
     const int Cs = pl.channels_per_scale;
@@ -86,10 +92,10 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
     const uint32_t HW = (uint32_t)a.HW;
     constexpr int ESZ = XF32 ? 4 : 2;
     constexpr int XR = SPX_BWD_XRING(XF32);
-    using Pipe = SpxPipeline<NPB, XF32, VEC, XR>;
+    using Pipe = SpxPipeline<NPB, XF32, VM, XR>;
 
     const char* x_img = (const char*)a.x + (size_t)b * C * a.HW * ESZ;
-    const SpxTileCtx tc = SpxXStager<XF32, VEC>::make_ctx(x_img, a.HW, px0, tid);
+    const SpxTileCtx tc = SpxXStager<XF32, VM>::make_ctx(x_img, a.HW, px0, tid);
 
     constexpr int stage = spx_stage_bytes(NPB);
     constexpr int chunk_bytes = NPB * 2 * 1024;
@@ -124,9 +130,15 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
 
     const bool have_dl = a.d_logits != nullptr || a.ce_labels != nullptr;     // a gradient reaches the logits
     // scale-parallel launch (grid.y = scale group): this workgroup's panels; group 0 alone writes the per-pixel by-products
+#ifdef SPX_T_NOGROUPS
+    const int q_begin = 0;
+    const int q_end = pl.npanels;
+    const bool g0 = true;
+#else
     const int q_begin = a.ngroups > 1 ? a.group_first[blockIdx.y] : 0;
     const int q_end = a.ngroups > 1 ? a.group_first[blockIdx.y + 1] : pl.npanels;
     const bool g0 = blockIdx.y == 0;
+#endif
     const bool act_is_log = a.act_fn == 0;
     const float act_c1 = act_is_log ? -(1.0f - a.eps) : -1.0f;
     // dLogits of this lane's pixel as split-bf16 B fragments: element j of k-step c <-> class 16c + 8h + j
@@ -238,7 +250,11 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
         // d_logits of the wave's pixels: given ([px][K] fp32), or - fused cross entropy - formed here from the forward's
         // logits: coef * (softmax - onehot) on the non-ignored pixels (loss.py:9-48 through autograd), written out once
         // for the parameter kernel
+#ifdef SPX_T_NOCE
+        const bool ce = false;
+#else
         const bool ce = a.ce_labels != nullptr;
+#endif
         const float* const lsrc = ce ? a.ce_logits : a.d_logits;
         const spx_rsrc lr = make_rsrc_pred(lsrc ? lsrc + (size_t)b * a.HW * K : nullptr);
         const uint32_t voff_l = (lsrc && px_ok) ? ((uint32_t)px * (uint32_t)K + (uint32_t)(8 * h)) * 4u : SPX_OOB;
@@ -389,7 +405,11 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
         // gout = its packed G fragments (k-steps 0 / 1)
         auto block = [&](int pb, auto slot_c, float (&ddc)[16], float (&ddnext)[16], bf16x8 (&gout)[2], bf16x8 (&glo)[2]) {
             constexpr int SLOT = decltype(slot_c)::value;
+#if SPX_ABLOB_USE_E4M12
             u16x8 anew[2];     // the activation blob: e4m12 (log) or fp16 bits (linear), see spx_common.h
+#else
+            f16x8 anew[2];     // the activation blob is fp16 (a / ln 2 <= 13.3; 11-bit mantissa): the bank side splits it into bf16 hi + lo
+#endif
             // the G blob is fp16 too, scaled per (lane, block) by a power of two so that the lane's largest |G| of the
             // block sits just under 2^15 (a gradient has no fixed range: bf16's exponent with fp16's mantissa); the
             // inverse scale goes to a side array and the bank side rebuilds G = fp16 * scale as an exact bf16 hi + lo pair
@@ -401,7 +421,11 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
                 for (int j = 0; j < 8; ++j) {
                     gout[s2][j] = (__bf16)0.0f;
                     glo[s2][j] = (__bf16)0.0f;
+#if SPX_ABLOB_USE_E4M12
                     anew[s2][j] = 0;
+#else
+                    anew[s2][j] = (_Float16)0.0f;
+#endif
                     gblob[s2][j] = (_Float16)0.0f;
                 }
             if (pb < nv) {
@@ -503,8 +527,12 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
                     // G's rounding relative to |x - p|, not to |p| (matters where a pixel sits on a prototype)
                     rs += (float)gb + (float)gl;
                     gblob[reg >> 3][reg & 7] = (_Float16)(gv[reg] * gscale_dn);
-                    anew[reg >> 3][reg & 7] = (SPX_ABLOB_USE_E4M12 && act_is_log) ? (unsigned short)ablob_pack(av[reg])
+#if SPX_ABLOB_USE_E4M12
+                    anew[reg >> 3][reg & 7] = act_is_log ? (unsigned short)ablob_pack(av[reg])
                                                          : __builtin_bit_cast(unsigned short, (_Float16)av[reg]);
+#else
+                    anew[reg >> 3][reg & 7] = (_Float16)av[reg];
+#endif
                 }
             }
             // fragment dump for kernel 2 (wholly padded blocks are written as zeros: kernel 2 reads them)
@@ -602,11 +630,30 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
                 const spx_rsrc dxr = make_rsrc_pred((char*)a.dx + ((size_t)b * C + ch0 + chb * 32) * a.HW * ESZ);
 #pragma unroll
                 for (int v = 0; v < NV; ++v) {
-                    const bool ok = ch_ok && (fpx + (v + 1) * PV <= a.HW);
-                    xw[v] = buf_load_b128(xir, ok ? fvo + 16u * v : SPX_OOB, 0);
+                    // a vector wholly inside the image as it lies; the one straddling the image end (H*W % PV != 0) from a
+                    // window moved back to end at the image end, shifted into place below (see SpxXStager::make_ctx)
+                    uint32_t vo;
+                    if constexpr (RAG) {
+                        const int over = fpx + (v + 1) * PV - a.HW;
+                        vo = !ch_ok ? SPX_OOB : (over <= 0 ? fvo + 16u * v : (over < PV ? fvo + 16u * v - (uint32_t)over * ESZ : SPX_OOB));
+                    } else {
+                        vo = (ch_ok && (fpx + (v + 1) * PV <= a.HW)) ? fvo + 16u * v : SPX_OOB;
+                    }
+                    xw[v] = buf_load_b128(xir, vo, 0);
                     // first panel of a scale: nothing to accumulate onto (dropped load returns 0)
-                    pw[v] = buf_load_b128(dxr, (ok && !first_of_scale) ? fvo + 16u * v : SPX_OOB, 0);
+                    pw[v] = buf_load_b128(dxr, first_of_scale ? SPX_OOB : vo, 0);
                 }
+            }
+        };
+        const bool ragged = RAG && !tile_full && (a.HW % PV != 0);       // tile-uniform: some vector straddles the image end
+        auto x_fix = [&]() {
+            if (!ragged) return;
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const int over = fpx + (v + 1) * PV - a.HW;
+                const uint32_t bits = (over > 0 && over < PV) ? (uint32_t)over * (ESZ * 8) : 0u;
+                xw[v] = spx_shr128(xw[v], bits);
+                pw[v] = spx_shr128(pw[v], bits);
             }
         };
         bt_load(0);
@@ -620,6 +667,7 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
             const spx_rsrc dxr = make_rsrc_pred((char*)a.dx + ((size_t)b * C + ch0 + chb * 32) * a.HW * ESZ);
             float xv[16], pv[16];
             if (VEC) {
+                x_fix();
 #pragma unroll
                 for (int v = 0; v < NV; ++v) {
 #pragma unroll
@@ -697,6 +745,17 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
                         }
                     }
                     buf_store_b128_p<SPX_AUX_DX_ST>(w, dxr, ok ? fvo + 16u * v : SPX_OOB, 0);
+                    if (ragged) {       // the straddling vector leaves element by element (nothing may land past the image)
+                        const int over = fpx + (v + 1) * PV - a.HW;
+                        if (ch_ok && over > 0 && over < PV) {
+#pragma unroll
+                            for (int e = 0; e < PV; ++e) {
+                                const uint32_t eo = e < PV - over ? fvo + 16u * v + (uint32_t)e * ESZ : SPX_OOB;
+                                if (XF32) buf_store_f32(__uint_as_float(w[e % 4]), dxr, eo, 0);
+                                else buf_store_u16((uint16_t)(w[e >> 1] >> (16 * (e & 1))), dxr, eo, 0);
+                            }
+                        }
+                    }
                 }
             } else {
 #pragma unroll
@@ -752,11 +811,13 @@ static hipError_t launch_bwd_gd(const SpxBwdArgs& a, int x_dtype, dim3 grid, hip
     constexpr size_t lds = (size_t)spx_bwd_lds_bytes<NPB, NCB>();
 #endif
     if (x_dtype == 1) {
-        if (a.vec_ok) hipLaunchKernelGGL((spx_bwd_kernel<NPB, NCB, true, true, GATHER, DACT>), grid, dim3(256), lds, s, a);
-        else hipLaunchKernelGGL((spx_bwd_kernel<NPB, NCB, true, false, GATHER, DACT>), grid, dim3(256), lds, s, a);
+        if (a.vec_ok == 2) hipLaunchKernelGGL((spx_bwd_kernel<NPB, NCB, true, 2, GATHER, DACT>), grid, dim3(256), lds, s, a);
+        else if (a.vec_ok) hipLaunchKernelGGL((spx_bwd_kernel<NPB, NCB, true, 1, GATHER, DACT>), grid, dim3(256), lds, s, a);
+        else hipLaunchKernelGGL((spx_bwd_kernel<NPB, NCB, true, 0, GATHER, DACT>), grid, dim3(256), lds, s, a);
     } else {
-        if (a.vec_ok) hipLaunchKernelGGL((spx_bwd_kernel<NPB, NCB, false, true, GATHER, DACT>), grid, dim3(256), lds, s, a);
-        else hipLaunchKernelGGL((spx_bwd_kernel<NPB, NCB, false, false, GATHER, DACT>), grid, dim3(256), lds, s, a);
+        if (a.vec_ok == 2) hipLaunchKernelGGL((spx_bwd_kernel<NPB, NCB, false, 2, GATHER, DACT>), grid, dim3(256), lds, s, a);
+        else if (a.vec_ok) hipLaunchKernelGGL((spx_bwd_kernel<NPB, NCB, false, 1, GATHER, DACT>), grid, dim3(256), lds, s, a);
+        else hipLaunchKernelGGL((spx_bwd_kernel<NPB, NCB, false, 0, GATHER, DACT>), grid, dim3(256), lds, s, a);
     }
     return hipGetLastError();
 }
@@ -768,13 +829,20 @@ static hipError_t launch_bwd_x(const SpxBwdArgs& a, int x_dtype, dim3 grid, hipS
                    : launch_bwd_gd<NPB, NCB, false, false>(a, x_dtype, grid, s);
 }
 
-// one translation unit per panel height, so the variants compile in parallel
 template <int NPB>
-static hipError_t spx_launch_bwd_npb(const SpxBwdArgs& a, int x_dtype, hipStream_t s) {
+static hipError_t spx_launch_bwd_tiles(const SpxBwdArgs& a, int x_dtype, hipStream_t s) {
     const spx_plan& pl = a.plan;
-    const int tiles = (a.HW + SPX_TILE_PX - 1) / SPX_TILE_PX;
-    dim3 grid((unsigned)(tiles * a.B), (unsigned)(a.ngroups > 1 ? a.ngroups : 1));
+    dim3 grid((unsigned)(a.tiles_launch * a.B), (unsigned)(a.ngroups > 1 ? a.ngroups : 1));
     if (pl.ncb == 1) return launch_bwd_x<NPB, 1>(a, x_dtype, grid, s);
     if (pl.ncb == 2) return launch_bwd_x<NPB, 2>(a, x_dtype, grid, s);
     return launch_bwd_x<NPB, 5>(a, x_dtype, grid, s);
+}
+// one translation unit per panel height, so the variants compile in parallel (vector staging: see spx_launch_fwd_npb)
+template <int NPB>
+static hipError_t spx_launch_bwd_npb(const SpxBwdArgs& a0, int x_dtype, hipStream_t s) {
+    SpxBwdArgs a = a0;
+    a.vec_ok = a.HW < 8 ? 0 : (a.HW % 8 == 0 ? 1 : 2);      // the element-wise path only for images of fewer than 8 pixels
+    a.tile_first = 0;
+    a.tiles_launch = (a.HW + SPX_TILE_PX - 1) / SPX_TILE_PX;
+    return spx_launch_bwd_tiles<NPB>(a, x_dtype, s);
 }

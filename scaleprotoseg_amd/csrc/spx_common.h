@@ -101,6 +101,55 @@ __device__ __forceinline__ void buf_store_b128_p(u32x4 v, spx_rsrc r, uint32_t v
     __builtin_amdgcn_raw_buffer_store_b128(v, r, voff + soff, 0, AUX);      // see buf_store_b128
 }
 
+// Logical right shift of a 128-bit value (4 dwords, little endian) by `bits` in [0, 128), zeros shifted in.  Used on the
+// ONE 16-byte piece per feature row that straddles the end of an image whose H*W is not a multiple of the piece: the
+// piece is loaded from a window moved back to end exactly at the row's end (never reading past the tensor) and shifted
+// into place here, which also zero-fills the elements past the image.  Wave-uniformly skipped in tiles without such a piece.
+__device__ __forceinline__ u32x4 spx_shr128(u32x4 v, uint32_t bits) {
+    const uint64_t lo = (uint64_t)v[0] | ((uint64_t)v[1] << 32), hi = (uint64_t)v[2] | ((uint64_t)v[3] << 32);
+    const uint32_t s = bits & 63u;
+    uint64_t olo, ohi;
+    if (bits >= 64u) {
+        olo = hi >> s;
+        ohi = 0;
+    } else {
+        olo = s ? (lo >> s) | (hi << (64u - s)) : lo;
+        ohi = hi >> s;
+    }
+    u32x4 o;
+    o[0] = (uint32_t)olo; o[1] = (uint32_t)(olo >> 32); o[2] = (uint32_t)ohi; o[3] = (uint32_t)(ohi >> 32);
+    return o;
+}
+
+__device__ __forceinline__ u32x4 spx_shl128(u32x4 v, uint32_t bits) {       // bits in (0, 128]
+    const uint64_t lo = (uint64_t)v[0] | ((uint64_t)v[1] << 32), hi = (uint64_t)v[2] | ((uint64_t)v[3] << 32);
+    const uint32_t s = bits & 63u;
+    uint64_t olo, ohi;
+    if (bits >= 128u) {
+        olo = 0; ohi = 0;
+    } else if (bits >= 64u) {
+        olo = 0;
+        ohi = lo << s;
+    } else {
+        olo = lo << s;
+        ohi = s ? (hi << s) | (lo >> (64u - s)) : hi;
+    }
+    u32x4 o;
+    o[0] = (uint32_t)olo; o[1] = (uint32_t)(olo >> 32); o[2] = (uint32_t)ohi; o[3] = (uint32_t)(ohi >> 32);
+    return o;
+}
+// the same for a 256-bit value (lo, hi), bits in [0, 256)
+__device__ __forceinline__ void spx_shr256(u32x4& lo, u32x4& hi, uint32_t bits) {
+    if (bits >= 128u) {
+        lo = spx_shr128(hi, bits - 128u);
+        hi = u32x4{0u, 0u, 0u, 0u};
+    } else if (bits) {
+        const u32x4 a = spx_shr128(lo, bits), c = spx_shl128(hi, 128u - bits);
+        lo = u32x4{a[0] | c[0], a[1] | c[1], a[2] | c[2], a[3] | c[3]};
+        hi = spx_shr128(hi, bits);
+    }
+}
+
 // Row of a 32x32 MFMA accumulator held in register `reg` of lane half `h`
 // (cdna guide §3: row = (reg&3) + 8*(reg>>2) + 4*(lane>>5), col = lane&31).
 __device__ __forceinline__ int acc_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }

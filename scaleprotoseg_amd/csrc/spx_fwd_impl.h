@@ -52,7 +52,7 @@ __host__ __device__ constexpr int spx_fwd_lds_bytes() {
 // GATHER: class-gathered distances (spx_dist_fwd_cls) instead of the P-wide map.
 // (2-block panels with a one-block head fit 168 VGPRs: three waves per SIMD.)
 // ACT: the [pixel][P] activation output is requested (kept out of the default instance: its code costs registers).
-template <int NPB, int NCB, bool XF32, bool VEC, int SPLIT, bool GATHER, bool ACT>
+template <int NPB, int NCB, bool XF32, int VM, int SPLIT, bool GATHER, bool ACT>
 __global__ __launch_bounds__(256 * SPLIT, (NPB == 2 && NCB == 1 ? 3 : SPX_FWD_WAVES) * SPLIT) void spx_fwd_kernel(const SpxFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NT = 256 * SPLIT, NH = NPB / SPLIT;
@@ -63,8 +63,9 @@ __global__ __launch_bounds__(256 * SPLIT, (NPB == 2 && NCB == 1 ? 3 : SPX_FWD_WA
     const int pg = wave & 3, ph = wave >> 2;       // pixel group, prototype half
     const int r = lane & 31, h = lane >> 5;
     const int tiles_per_img = (a.HW + SPX_TILE_PX - 1) / SPX_TILE_PX;
-    const int b = blockIdx.x / tiles_per_img;
-    const int px0 = (blockIdx.x % tiles_per_img) * SPX_TILE_PX;
+    const int b = blockIdx.x / a.tiles_launch;
+    const int tile_i = a.tile_first + blockIdx.x % a.tiles_launch;
+    const int px0 = tile_i * SPX_TILE_PX;
     const int Cs = pl.channels_per_scale;
     const int C = pl.num_scales * Cs;
     const int P = pl.num_prototypes, K = pl.num_classes;
@@ -74,14 +75,14 @@ __global__ __launch_bounds__(256 * SPLIT, (NPB == 2 && NCB == 1 ? 3 : SPX_FWD_WA
     const int q_end = a.ngroups > 1 ? a.group_first[blockIdx.y + 1] : pl.npanels;
     float* const logits_out = a.logits ? a.logits + (size_t)blockIdx.y * a.logits_group_stride : nullptr;
     constexpr int XR = SPX_FWD_XRING(XF32);
-    using Pipe = SpxPipeline<NPB, XF32, VEC, XR, NT, NH>;
+    using Pipe = SpxPipeline<NPB, XF32, VM, XR, NT, NH>;
 
 #ifdef SPX_DIAG_STAGGER
     // experiment: de-phase the two workgroups that share a CU (blocks i and i+256 of the first dispatch round)
     if (blockIdx.x >= 256 && blockIdx.x < 512)
         for (int i = 0; i < SPX_DIAG_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
 #endif
-    const SpxTileCtx tc = SpxXStager<XF32, VEC, NT>::make_ctx((const char*)a.x + (size_t)b * C * a.HW * (XF32 ? 4 : 2), a.HW, px0, tid);
+    const SpxTileCtx tc = SpxXStager<XF32, VM, NT>::make_ctx((const char*)a.x + (size_t)b * C * a.HW * (XF32 ? 4 : 2), a.HW, px0, tid);
 
     constexpr int chunk_bytes = NPB * 2 * 1024;
     constexpr int head_lds = spx_fwd_head_lds_bytes<NPB, NCB>();
@@ -437,7 +438,7 @@ __global__ __launch_bounds__(256 * SPLIT, (NPB == 2 && NCB == 1 ? 3 : SPX_FWD_WA
                 cnt += __shfl_xor(cnt, off);
             }
             if (lane == 0) {
-                float* const pp = a.ce_partials + ((size_t)blockIdx.x * 4 + pg) * 2;
+                float* const pp = a.ce_partials + (((size_t)b * tiles_per_img + tile_i) * 4 + pg) * 2;
                 pp[0] = lossv;
                 pp[1] = cnt;
             }
@@ -479,12 +480,15 @@ template <int NPB, int NCB, int SPLIT, bool GATHER, bool ACT>
 static hipError_t launch_fwd_ga(const SpxFwdArgs& a, int x_dtype, dim3 grid, hipStream_t s) {
     constexpr size_t lds = (size_t)spx_fwd_lds_bytes<NPB, NCB, SPLIT>();
     const dim3 blk(256 * SPLIT);
+    // a.vec_ok: 0 = element-wise staging, 1 = vector staging, 2 = vector staging with a ragged image end (H*W % 8 != 0)
     if (x_dtype == 1) {
-        if (a.vec_ok) hipLaunchKernelGGL((spx_fwd_kernel<NPB, NCB, true, true, SPLIT, GATHER, ACT>), grid, blk, lds, s, a);
-        else hipLaunchKernelGGL((spx_fwd_kernel<NPB, NCB, true, false, SPLIT, GATHER, ACT>), grid, blk, lds, s, a);
+        if (a.vec_ok == 2) hipLaunchKernelGGL((spx_fwd_kernel<NPB, NCB, true, 2, SPLIT, GATHER, ACT>), grid, blk, lds, s, a);
+        else if (a.vec_ok) hipLaunchKernelGGL((spx_fwd_kernel<NPB, NCB, true, 1, SPLIT, GATHER, ACT>), grid, blk, lds, s, a);
+        else hipLaunchKernelGGL((spx_fwd_kernel<NPB, NCB, true, 0, SPLIT, GATHER, ACT>), grid, blk, lds, s, a);
     } else {
-        if (a.vec_ok) hipLaunchKernelGGL((spx_fwd_kernel<NPB, NCB, false, true, SPLIT, GATHER, ACT>), grid, blk, lds, s, a);
-        else hipLaunchKernelGGL((spx_fwd_kernel<NPB, NCB, false, false, SPLIT, GATHER, ACT>), grid, blk, lds, s, a);
+        if (a.vec_ok == 2) hipLaunchKernelGGL((spx_fwd_kernel<NPB, NCB, false, 2, SPLIT, GATHER, ACT>), grid, blk, lds, s, a);
+        else if (a.vec_ok) hipLaunchKernelGGL((spx_fwd_kernel<NPB, NCB, false, 1, SPLIT, GATHER, ACT>), grid, blk, lds, s, a);
+        else hipLaunchKernelGGL((spx_fwd_kernel<NPB, NCB, false, 0, SPLIT, GATHER, ACT>), grid, blk, lds, s, a);
     }
     return hipGetLastError();
 }
@@ -497,15 +501,29 @@ static hipError_t launch_fwd_x(const SpxFwdArgs& a, int x_dtype, dim3 grid, hipS
 }
 
 // one translation unit per panel height (SPX_TU_NPB), so the variants compile in parallel
+// Features rows need no alignment: gfx950 under ROCm serves 16-B buffer accesses at any byte address
+// (tools/ubench/unaligned.hip), so the vector staging path only asks that every 8-pixel piece lies wholly inside or
+// outside the image.  That holds for every tile except an image's last one when H*W is not a multiple of 8 - and it is
+// odd for every grid the reference uses (65 x 65 crops, 129 x 257 images): the ONE piece per feature row that straddles
+// the image end is loaded from a window moved back to end exactly at the image end and shifted into place in registers
+// (SpxXStager::make_ctx / fix_ragged), so nothing is read past the tensor and the whole launch stays on the vector path.
 template <int NPB>
-static hipError_t spx_launch_fwd_npb(const SpxFwdArgs& a, int x_dtype, hipStream_t s) {
+static hipError_t spx_launch_fwd_tiles(const SpxFwdArgs& a, int x_dtype, hipStream_t s) {
     const spx_plan& pl = a.plan;
-    const int tiles = (a.HW + SPX_TILE_PX - 1) / SPX_TILE_PX;
-    dim3 grid((unsigned)(tiles * a.B), (unsigned)(a.ngroups > 1 ? a.ngroups : 1));
+    dim3 grid((unsigned)(a.tiles_launch * a.B), (unsigned)(a.ngroups > 1 ? a.ngroups : 1));
     // SPX_FWD_SPLIT 2 = 8-wave workgroups (4 waves per SIMD): measured 0.84 vs 0.72 ms at the north-star shape, off
     if (pl.ncb == 1) return launch_fwd_x<NPB, 1, SPX_FWD_SPLIT>(a, x_dtype, grid, s);
     // 33..64 head rows (the grouping head: 3 groups x 19 / 21 classes)
     if (pl.ncb == 2) return launch_fwd_x<NPB, 2, 1>(a, x_dtype, grid, s);
     // up to 160 classes: 80 logits accumulators per lane
     return launch_fwd_x<NPB, 5, 1>(a, x_dtype, grid, s);
+}
+// one translation unit per panel height (SPX_TU_NPB), so the variants compile in parallel
+template <int NPB>
+static hipError_t spx_launch_fwd_npb(const SpxFwdArgs& a0, int x_dtype, hipStream_t s) {
+    SpxFwdArgs a = a0;
+    a.vec_ok = a.HW < 8 ? 0 : (a.HW % 8 == 0 ? 1 : 2);      // the element-wise path only for images of fewer than 8 pixels
+    a.tile_first = 0;
+    a.tiles_launch = (a.HW + SPX_TILE_PX - 1) / SPX_TILE_PX;
+    return spx_launch_fwd_tiles<NPB>(a, x_dtype, s);
 }

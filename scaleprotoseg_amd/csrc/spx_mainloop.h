@@ -30,6 +30,9 @@ struct SpxTileCtx {
     uint32_t hw;          // pixels per image
     int px;               // first of this thread's 8 staged pixels
     int row0;             // this thread's row inside a pass of NT/16 rows
+    uint32_t rot_bits;    // vector path: this thread's piece straddles the image end - loaded from a window moved back by
+                          // this many bits' worth of elements and shifted into place at LDS-commit time (0 = ordinary piece)
+    bool ragged;          // tile-uniform: some piece of this tile straddles the image end
 };
 
 // One staged K-chunk: acc[i] += Bank_chunk[pb0 + i] . X_chunk (i < NH: the wave's share of the panel's NPB blocks),
@@ -67,8 +70,11 @@ __device__ __forceinline__ void spx_compute_chunk(f32x16 (&acc)[NH], float& x2pa
 
 // X stager: the registers of one 32-channel chunk of the tile (XPASS passes of NT/16 rows x 8 px per thread;
 // NT = threads of the workgroup, 256 or 512)
-template <bool XF32, bool VEC, int NT = 256>
+// VM: 0 = element-wise loads, 1 = 16-B vector loads (every piece wholly inside or outside the image), 2 = vector loads
+// with the in-register fix for the piece that straddles a ragged image end
+template <bool XF32, int VM, int NT = 256>
 struct SpxXStager {
+    static constexpr bool VEC = VM != 0, RAG = VM == 2;
     static constexpr int RPP = NT / 16;           // rows per pass
     static constexpr int XPASS = SPX_KC / RPP;
     static constexpr int ESZ = XF32 ? 4 : 2;
@@ -81,8 +87,19 @@ struct SpxXStager {
         t.px = px0 + (tid & 15) * 8;
         t.row0 = tid >> 4;
         const uint32_t off = ((uint32_t)t.row0 * (uint32_t)hw + (uint32_t)t.px) * ESZ;
-        // vector path: a piece is wholly inside or wholly outside the image (HW % 8 == 0)
-        t.x_voff = (!VEC || t.px + 8 <= hw) ? off : SPX_OOB;
+        // vector path: a piece wholly inside the image is loaded as it lies (any byte alignment: gfx950 serves misaligned
+        // 16-B buffer accesses), one wholly outside is dropped, and the one that straddles the image end (H*W not a multiple
+        // of 8) comes from a window moved back to END at the image end (hw >= 8 is the launcher's condition for this path)
+        if constexpr (RAG) {
+            const int over = t.px + 8 - hw;                  // elements of the piece past the image
+            t.rot_bits = (over > 0 && over < 8) ? (uint32_t)over * (ESZ * 8) : 0u;
+            t.ragged = px0 + SPX_TILE_PX > hw;
+            t.x_voff = over <= 0 ? off : (over < 8 ? off - (uint32_t)over * ESZ : SPX_OOB);
+        } else {
+            t.rot_bits = 0u;
+            t.ragged = false;
+            t.x_voff = (!VEC || t.px + 8 <= hw) ? off : SPX_OOB;
+        }
         return t;
     }
 
@@ -112,6 +129,17 @@ struct SpxXStager {
                     xr[i][0][e] = lo | (hi << 16);
                 }
             }
+        }
+    }
+
+    // the straddling piece of a ragged tile: shift the moved-back window into place (bf16: one 16-B register; fp32: the
+    // 32-B piece is a 256-bit value - shift the pair)
+    __device__ __forceinline__ void fix_ragged(const SpxTileCtx& t) {
+        if (!RAG || !t.ragged) return;                     // tile-uniform
+#pragma unroll
+        for (int i = 0; i < XPASS; ++i) {
+            if (XF32) spx_shr256(xr[i][0], xr[i][XF32 ? 1 : 0], t.rot_bits);
+            else xr[i][0] = spx_shr128(xr[i][0], t.rot_bits);
         }
     }
 
@@ -173,9 +201,9 @@ struct SpxAStager {
 // indices past the panel's last real chunk load and stage zeros.
 // NT threads per workgroup; each wave accumulates NH of the panel's NPB blocks (NT = 256: NH = NPB, one wave per
 // 32-pixel group; NT = 512: NH = NPB / 2, two waves per pixel group, each with half of the prototype blocks).
-template <int NPB, bool XF32, bool VEC, int XR, int NT = 256, int NH = NPB>
+template <int NPB, bool XF32, int VM, int XR, int NT = 256, int NH = NPB>
 struct SpxPipeline {
-    SpxXStager<XF32, VEC, NT> xs[XR];
+    SpxXStager<XF32, VM, NT> xs[XR];
     SpxAStager<NPB, NT> as_[2];
     static constexpr int CHUNK_BYTES = NPB * 2 * 1024;
     static constexpr int STAGE = SPX_STAGE_X_BYTES + CHUNK_BYTES;
@@ -203,6 +231,7 @@ struct SpxPipeline {
         __builtin_amdgcn_sched_barrier(0);
 #endif
         char* dst = smem + ((I + 1) % 2) * STAGE;
+        xs[(I + 1) % XR].fix_ragged(tc);
         xs[(I + 1) % XR].write(dst, tid);
         as_[(I + 1) % 2].write(dst + SPX_STAGE_X_BYTES, tid);
 #ifdef SPX_DIAG_STAMPS
@@ -242,6 +271,7 @@ struct SpxPipeline {
                                              G consts_commit) {
         const int nchunks = (Cs + SPX_KC - 1) / SPX_KC;
         const int nrounds = (nchunks + XR - 1) / XR;       // chunks are processed XR at a time
+        xs[0].fix_ragged(tc);
         xs[0].write(smem, tid);
         as_[0].write(smem + SPX_STAGE_X_BYTES, tid);
         __syncthreads();
