@@ -632,13 +632,9 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
                 for (int v = 0; v < NV; ++v) {
                     // a vector wholly inside the image as it lies; the one straddling the image end (H*W % PV != 0) from a
                     // window moved back to end at the image end, shifted into place below (see SpxXStager::make_ctx)
-                    uint32_t vo;
-                    if constexpr (RAG) {
-                        const int over = fpx + (v + 1) * PV - a.HW;
-                        vo = !ch_ok ? SPX_OOB : (over <= 0 ? fvo + 16u * v : (over < PV ? fvo + 16u * v - (uint32_t)over * ESZ : SPX_OOB));
-                    } else {
-                        vo = (ch_ok && (fpx + (v + 1) * PV <= a.HW)) ? fvo + 16u * v : SPX_OOB;
-                    }
+                    // a vector wholly inside the image as it lies (any alignment); the one straddling a ragged image end is
+                    // fetched element by element below, in the image's last tile only
+                    const uint32_t vo = (ch_ok && (fpx + (v + 1) * PV <= a.HW)) ? fvo + 16u * v : SPX_OOB;
                     xw[v] = buf_load_b128(xir, vo, 0);
                     // first panel of a scale: nothing to accumulate onto (dropped load returns 0)
                     pw[v] = buf_load_b128(dxr, first_of_scale ? SPX_OOB : vo, 0);
@@ -646,14 +642,30 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
             }
         };
         const bool ragged = RAG && !tile_full && (a.HW % PV != 0);       // tile-uniform: some vector straddles the image end
-        auto x_fix = [&]() {
+        auto x_fix = [&](int chb) {
             if (!ragged) return;
+            const bool ch_ok = chb * 32 + frow < Cs;
+            const spx_rsrc xir = make_rsrc_pred(x_img + (size_t)(ch0 + chb * 32) * a.HW * ESZ);
+            const spx_rsrc dxr = make_rsrc_pred((char*)a.dx + ((size_t)b * C + ch0 + chb * 32) * a.HW * ESZ);
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
                 const int over = fpx + (v + 1) * PV - a.HW;
-                const uint32_t bits = (over > 0 && over < PV) ? (uint32_t)over * (ESZ * 8) : 0u;
-                xw[v] = spx_shr128(xw[v], bits);
-                pw[v] = spx_shr128(pw[v], bits);
+                if (ch_ok && over > 0 && over < PV) {             // this thread's straddling vector: element-wise
+                    u32x4 xe = {0u, 0u, 0u, 0u}, pe = {0u, 0u, 0u, 0u};
+#pragma unroll
+                    for (int e = 0; e < PV; ++e) {
+                        const uint32_t eo = e < PV - over ? fvo + 16u * v + (uint32_t)e * ESZ : SPX_OOB;
+                        if (XF32) {
+                            xe[e % 4] = __float_as_uint(buf_load_f32(xir, eo, 0));
+                            pe[e % 4] = first_of_scale ? 0u : __float_as_uint(buf_load_f32(dxr, eo, 0));
+                        } else {
+                            xe[e >> 1] |= (uint32_t)buf_load_u16(xir, eo, 0) << (16 * (e & 1));
+                            pe[e >> 1] |= (first_of_scale ? 0u : (uint32_t)buf_load_u16(dxr, eo, 0)) << (16 * (e & 1));
+                        }
+                    }
+                    xw[v] = xe;
+                    pw[v] = pe;
+                }
             }
         };
         bt_load(0);
@@ -667,7 +679,7 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
             const spx_rsrc dxr = make_rsrc_pred((char*)a.dx + ((size_t)b * C + ch0 + chb * 32) * a.HW * ESZ);
             float xv[16], pv[16];
             if (VEC) {
-                x_fix();
+                x_fix(chb);
 #pragma unroll
                 for (int v = 0; v < NV; ++v) {
 #pragma unroll

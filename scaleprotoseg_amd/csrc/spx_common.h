@@ -106,21 +106,17 @@ __device__ __forceinline__ void buf_store_b128_p(u32x4 v, spx_rsrc r, uint32_t v
 // piece is loaded from a window moved back to end exactly at the row's end (never reading past the tensor) and shifted
 // into place here, which also zero-fills the elements past the image.  Wave-uniformly skipped in tiles without such a piece.
 __device__ __forceinline__ u32x4 spx_shr128(u32x4 v, uint32_t bits) {
-    const uint64_t lo = (uint64_t)v[0] | ((uint64_t)v[1] << 32), hi = (uint64_t)v[2] | ((uint64_t)v[3] << 32);
-    const uint32_t s = bits & 63u;
-    uint64_t olo, ohi;
-    if (bits >= 64u) {
-        olo = hi >> s;
-        ohi = 0;
-    } else {
-        olo = s ? (lo >> s) | (hi << (64u - s)) : lo;
-        ohi = hi >> s;
-    }
+    // bit part with four funnel shifts, dword part with selects: no 64-bit temporaries (this runs at 256 VGPRs)
+    const uint32_t b = bits & 31u, k = bits >> 5;
+    const uint32_t t0 = __builtin_amdgcn_alignbit(v[1], v[0], b), t1 = __builtin_amdgcn_alignbit(v[2], v[1], b),
+                   t2 = __builtin_amdgcn_alignbit(v[3], v[2], b), t3 = v[3] >> b;
     u32x4 o;
-    o[0] = (uint32_t)olo; o[1] = (uint32_t)(olo >> 32); o[2] = (uint32_t)ohi; o[3] = (uint32_t)(ohi >> 32);
+    o[0] = k == 0 ? t0 : k == 1 ? t1 : k == 2 ? t2 : k == 3 ? t3 : 0u;
+    o[1] = k == 0 ? t1 : k == 1 ? t2 : k == 2 ? t3 : 0u;
+    o[2] = k == 0 ? t2 : k == 1 ? t3 : 0u;
+    o[3] = k == 0 ? t3 : 0u;
     return o;
 }
-
 __device__ __forceinline__ u32x4 spx_shl128(u32x4 v, uint32_t bits) {       // bits in (0, 128]
     const uint64_t lo = (uint64_t)v[0] | ((uint64_t)v[1] << 32), hi = (uint64_t)v[2] | ((uint64_t)v[3] << 32);
     const uint32_t s = bits & 63u;
