@@ -123,7 +123,11 @@ __global__ __launch_bounds__(SPX_BK_THREADS, 2) void spx_bank_bwd_kernel(const S
     // waves of a prototype half then split the chunk's four pixel k-steps instead (wave cpair takes k-step cpair for
     // both channel blocks) and their partial tiles are summed through LDS once, after the last chunk.
     constexpr bool ksplit = KSPLIT;
-    const bool cs_role = ksplit || cpair == 0;        // colsum(G): per k-step owner (split) / one wave per prototype half
+    // colsum(G) of prototype block i of the half: per k-step owner (split); otherwise the wave cs_owner(i), chosen among the
+    // waves with the least other work (waves 0..NPB-1 also carry the d_W tiles; waves wave and wave + 4 share a SIMD)
+    // (per SIMD beyond the bank MFMAs: two d_W tiles + one colsum on SIMDs 0 and 1, one d_W tile + two colsums on 2 and 3)
+    const int cs_first = wave >> 2;                   // half 0: blocks -> cpair 0, 2, 3; half 1: cpair 1, 2, 3
+    auto cs_owner = [&](int i) { return i == 0 ? cs_first : i + 1; };
 
     f32x16 accp[PH][2];
     f32x16 accw[NCB];
@@ -344,7 +348,7 @@ __global__ __launch_bounds__(SPX_BK_THREADS, 2) void spx_bank_bwd_kernel(const S
             const bf16x4 l1 = __builtin_bit_cast(bf16x4, lds_tr_read(Gs2 + fb + fo1));
             const bf16x8 gf = __builtin_shufflevector(g0, g1, 0, 1, 2, 3, 4, 5, 6, 7);
             const bf16x8 gf2 = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
-            if (cs_role) {   // colsum(G): every lane holds 8 px of its prototype row; lanes r, r+32 cover the k-step
+            if (ksplit || cpair == cs_owner(i)) {   // colsum(G): every lane holds 8 px of its prototype row; lanes r, r+32 cover the k-step
                 float s8 = 0.0f;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) s8 += (float)gf[j] + (float)gf2[j];
@@ -484,7 +488,7 @@ __global__ __launch_bounds__(SPX_BK_THREADS, 2) void spx_bank_bwd_kernel(const S
                         slab[(size_t)(pb * 32 + acc_row(reg, h)) * ws + chb * 32 + r] = accp[i][t][reg];
                 }
             }
-            if (cpair == 0) {
+            if (ksplit ? cpair == 0 : cpair == cs_owner(i)) {
                 const float s = csum[i] + __shfl_xor(csum[i], 32);
                 if (h == 0) slab[(size_t)(pb * 32 + r) * ws + nchb * 32 + NCB * 32] = s;
             }
