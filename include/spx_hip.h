@@ -35,7 +35,7 @@ extern "C" {
 #endif
 
 #define SPX_MAX_PANELS 64   /* (scale, <=192-prototype block) work units per pixel tile */
-#define SPX_ABI_VERSION 7
+#define SPX_ABI_VERSION 8
 
 /* How the prototype bank is cut into MFMA panels.  Filled by spx_make_plan(). */
 typedef struct spx_plan {
@@ -185,6 +185,25 @@ int spx_ce_fwd(const float* logits, const int32_t* labels, int64_t M, int32_t K,
                float* partials, void* stream);
 int spx_ce_bwd(const float* logits, const float* lse, const int32_t* labels, const float* coef, int64_t M, int32_t K,
                float* d_logits, void* stream);
+
+/* Grouping head with the tail as its own kernel: the unit product runs in the distance kernel (scale-parallel for small
+ * pixel grids: the tail needs the SUMMED units), then one pixel-per-thread fp32 kernel forms units = sum of the per-scale
+ * partials, g = exp(units), logits = W_g . g and - when `ce` is given - the cross-entropy statistics of the logits it still
+ * holds in registers (partials: spx_ce_partials_flat(B*HW) pairs).  Wg: the RAW last_layer_group.weight [K2, U] fp32.
+ * workspace: spx_group_tail_workspace_bytes().  spx_dist_bwd_group_ce = spx_dist_bwd_group with (logits, lse, labels,
+ * coef) in place of d_logits; d_logits_out then carries the formed [B*HW, K2] gradient (for d_W_g = d_logits^T . g). */
+size_t spx_group_tail_workspace_bytes(const spx_plan* plan, int32_t B, int32_t HW);
+int spx_dist_fwd_group_ws(const spx_plan* plan, const void* x, int32_t x_dtype, int32_t B, int32_t HW,
+                          const void* packed_bank, const float* packed_p2, const void* packed_head,
+                          const float* Wg, int32_t K2, float* distances, float* activations,
+                          float* group_activations, float* logits, const spx_ce* ce, void* workspace,
+                          float epsilon, int32_t act_fn, void* stream);
+int spx_dist_bwd_group_ce(const spx_plan* plan, const void* x, int32_t x_dtype, int32_t B, int32_t HW,
+                          const void* packed_bank, const void* packed_bankT, const float* packed_p2,
+                          const void* packed_headT_units, const void* packed_tailT, int32_t K2,
+                          const float* group_activations, const float* d_dist, const float* d_act,
+                          const spx_ce* ce, float* d_units, void* dx, void* g_out, void* a_out,
+                          float epsilon, int32_t act_fn, void* stream);
 
 /* Grouping head with its tail fused (segmentation/model/model_multiscale_group.py:283-308, run_last_layer):
  *   units = act . Wd^T   (Wd = the dense [U = G*K', P] form of the per-class group_projection matrices, packed with

@@ -165,7 +165,8 @@ static int dist_fwd_impl(const spx_plan* pl, const void* x, int32_t x_dtype, int
                          const void* packed_bank, const float* packed_p2, const void* packed_head, float* distances,
                          const int32_t* labels, const uint32_t* proto_key, int32_t J, float* cls_dist,
                          float* activations, float* logits, float epsilon, int32_t act_fn, void* stream,
-                         SpxTailFwd tail = SpxTailFwd{nullptr, 0, nullptr}, const spx_ce* ce = nullptr, void* split_ws = nullptr) {
+                         SpxTailFwd tail = SpxTailFwd{nullptr, 0, nullptr}, const spx_ce* ce = nullptr, void* split_ws = nullptr,
+                         bool keep_partials = false) {
     if (check_plan(pl)) return 1;
     if (!x || !packed_bank || !packed_p2) return fail("spx_dist_fwd: NULL operand");
     if (x_dtype != 0 && x_dtype != 1) return fail("spx_dist_fwd: x_dtype %d (0 = bf16, 1 = fp32)", x_dtype);
@@ -224,7 +225,7 @@ static int dist_fwd_impl(const spx_plan* pl, const void* x, int32_t x_dtype, int
         }
     }
     if (hip_status(spx_launch_fwd(a, x_dtype, (hipStream_t)stream), "spx_dist_fwd")) return 1;
-    if (a.ngroups > 1 && logits)
+    if (a.ngroups > 1 && logits && !keep_partials)
         return hip_status(spx_launch_sum_groups((const float*)split_ws, a.logits_group_stride, groups, logits, (hipStream_t)stream), "spx_dist_fwd (sum of the scale partials)");
     return 0;
 }
@@ -253,6 +254,35 @@ static int check_cls(const char* who, const int32_t* labels, const uint32_t* pro
     return 0;
 }
 
+size_t spx_group_tail_workspace_bytes(const spx_plan* pl, int32_t B, int32_t HW) {
+    int32_t gf[SPX_MAX_PANELS + 1];
+    const int g = pl ? spx_split_groups(*pl, B, HW, gf) : 1;
+    return pl ? (size_t)g * B * HW * pl->num_classes * sizeof(float) : 0;
+}
+
+int spx_dist_fwd_group_ws(const spx_plan* pl, const void* x, int32_t x_dtype, int32_t B, int32_t HW,
+                          const void* packed_bank, const float* packed_p2, const void* packed_head,
+                          const float* Wg, int32_t K2, float* distances, float* activations,
+                          float* group_activations, float* logits, const spx_ce* ce, void* workspace,
+                          float epsilon, int32_t act_fn, void* stream) {
+    if (!packed_head || !Wg || !logits || !workspace) return fail("spx_dist_fwd_group_ws: NULL head / W_g / logits / workspace");
+    if (K2 < 1 || K2 > 32) return fail("spx_dist_fwd_group_ws: %d classes (at most 32)", K2);
+    if (check_plan(pl)) return 1;
+    if (ce && (!ce->labels || !ce->lse || !ce->partials)) return fail("spx_dist_fwd_group_ws: NULL labels / lse / partials");
+    // the unit product as the kernel's (per-scale partial) \"logits\" into the workspace, then the tail kernel
+    int32_t gf[SPX_MAX_PANELS + 1];
+    const int groups = spx_split_groups(*pl, B, HW, gf);
+    float* const parts = (float*)workspace;
+    if (dist_fwd_impl(pl, x, x_dtype, B, HW, packed_bank, packed_p2, packed_head, distances, nullptr, nullptr, 0, nullptr,
+                      activations, parts, epsilon, act_fn, stream, SpxTailFwd{nullptr, 0, nullptr}, nullptr,
+                      groups > 1 ? (void*)parts : nullptr, /*keep_partials=*/true))
+        return 1;
+    const long long M = (long long)B * HW;
+    return hip_status(spx_launch_group_tail(parts, groups, M, pl->num_classes, Wg, K2, group_activations, logits,
+                                            ce ? ce->labels : nullptr, ce ? ce->lse : nullptr, ce ? ce->pred : nullptr,
+                                            ce ? ce->partials : nullptr, (hipStream_t)stream), "spx_dist_fwd_group_ws (tail)");
+}
+
 int spx_dist_fwd_cls(const spx_plan* pl, const void* x, int32_t x_dtype, int32_t B, int32_t HW,
                      const void* packed_bank, const float* packed_p2, const void* packed_head,
                      const int32_t* labels, const uint32_t* proto_key, int32_t J, float* class_distances,
@@ -275,7 +305,7 @@ static int dist_bwd_impl(const spx_plan* pl, const void* x, int32_t x_dtype, int
     if (B < 1 || HW < 1) return fail("spx_dist_bwd: empty input");
     if (dx && !packed_bankT) return fail("spx_dist_bwd: dx requested without packed bank^T");
     if ((d_logits || ce) && !packed_headT) return fail("spx_dist_bwd: d_logits given without packed head^T");
-    if (ce && (d_logits || tail.packed_tailT)) return fail("spx_dist_bwd_ce: the fused cross entropy replaces d_logits and has no tail variant");
+    if (ce && d_logits) return fail("spx_dist_bwd_ce: the fused cross entropy replaces d_logits");
     if (ce && (!ce->labels || !ce->lse || !ce->logits || !ce->coef)) return fail("spx_dist_bwd_ce: NULL labels / lse / logits / coef");
     if ((long long)pl->num_prototypes * HW >= (1LL << 29)) return fail("spx_dist_bwd: P*HW too large for 32-bit offsets");
     const long long tiles = (long long)B * ((HW + SPX_TILE_PX - 1) / SPX_TILE_PX);
@@ -338,6 +368,20 @@ int spx_dist_bwd_group(const spx_plan* pl, const void* x, int32_t x_dtype, int32
     return dist_bwd_impl(pl, x, x_dtype, B, HW, packed_bank, packed_bankT, packed_p2, packed_headT_units, d_dist,
                          nullptr, nullptr, 0, nullptr, d_act, d_logits, dx, g_out, a_out, epsilon, act_fn, stream,
                          SpxTailBwd{packed_tailT, K2, group_activations, d_units});
+}
+
+int spx_dist_bwd_group_ce(const spx_plan* pl, const void* x, int32_t x_dtype, int32_t B, int32_t HW,
+                          const void* packed_bank, const void* packed_bankT, const float* packed_p2,
+                          const void* packed_headT_units, const void* packed_tailT, int32_t K2,
+                          const float* group_activations, const float* d_dist, const float* d_act, const spx_ce* ce,
+                          float* d_units, void* dx, void* g_out, void* a_out, float epsilon, int32_t act_fn, void* stream) {
+    if (!ce) return fail("spx_dist_bwd_group_ce: NULL ce");
+    if (!packed_headT_units || !packed_tailT || !group_activations || !d_units)
+        return fail("spx_dist_bwd_group_ce: NULL tail operand");
+    if (K2 < 1 || K2 > 32) return fail("spx_dist_bwd_group_ce: %d classes (at most 32)", K2);
+    return dist_bwd_impl(pl, x, x_dtype, B, HW, packed_bank, packed_bankT, packed_p2, packed_headT_units, d_dist,
+                         nullptr, nullptr, 0, nullptr, d_act, nullptr, dx, g_out, a_out, epsilon, act_fn, stream,
+                         SpxTailBwd{packed_tailT, K2, group_activations, d_units}, ce);
 }
 
 int spx_dist_bwd_cls(const spx_plan* pl, const void* x, int32_t x_dtype, int32_t B, int32_t HW,

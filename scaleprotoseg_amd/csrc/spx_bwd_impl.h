@@ -179,10 +179,22 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
         // formed here as accumulator tiles (rows = units), written out for the parameter kernel, and becomes the
         // B operand of the head^T product below in ACCUMULATOR row order (packed_headT is the _units variant).
         const int K2 = a.K2;
-        const spx_rsrc lr = make_rsrc_pred(a.d_logits + (size_t)b * a.HW * K2);
+        // d_logits [px][K2]: given, or - fused cross entropy - formed from the forward's logits (see the plain branch below)
+        const bool ce = a.ce_labels != nullptr;
+        const float* const lsrc = ce ? a.ce_logits : a.d_logits;
+        const spx_rsrc lr = make_rsrc_pred(lsrc + (size_t)b * a.HW * K2);
         const uint32_t voff_l = px_ok ? ((uint32_t)px * (uint32_t)K2 + (uint32_t)(8 * h)) * 4u : SPX_OOB;
+        float ce_lse = 0.0f, ce_c = 0.0f;
+        int ce_lab = -1;
+        if (ce) {
+            const uint32_t vo1 = px_ok ? (uint32_t)px * 4u : SPX_OOB;
+            ce_lab = (int)__builtin_amdgcn_raw_buffer_load_b32(make_rsrc_pred(a.ce_labels + (size_t)b * a.HW), vo1, 0, 0);
+            ce_lse = buf_load_f32(make_rsrc_pred(a.ce_lse + (size_t)b * a.HW), vo1, 0);
+            ce_c = (px_ok && (uint32_t)ce_lab < (uint32_t)K2) ? *a.ce_coef : 0.0f;
+        }
+        const spx_rsrc dor = make_rsrc_pred((ce && a.ce_dlogits_out) ? a.ce_dlogits_out + (size_t)b * a.HW * K2 : nullptr);
         bf16x8 l2hi[2], l2lo[2];
-        if (BLK) block_fetch(a.d_logits + (size_t)b * a.HW * K2, K2);
+        if (BLK) block_fetch(lsrc + (size_t)b * a.HW * K2, K2);
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
 #pragma unroll
@@ -191,12 +203,21 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
                 float v;
                 if (BLK) v = cls < K2 ? bsc[r * K2 + cls] : 0.0f;
                 else v = buf_load_f32(lr, cls < K2 ? voff_l : SPX_OOB, (uint32_t)((c * 16 + j) * 4));
+                if (ce) {
+                    v = cls < K2 ? ce_c * (ce_exp(v - ce_lse) - (cls == ce_lab ? 1.0f : 0.0f)) : 0.0f;
+                    if (BLK) {
+                        if (cls < K2) bsc[r * K2 + cls] = v;
+                    } else {
+                        buf_store_f32(v, dor, (cls < K2 && g0) ? voff_l : SPX_OOB, (uint32_t)((c * 16 + j) * 4));
+                    }
+                }
                 __bf16 hi, lo;
                 split_bf16(v, hi, lo);
                 l2hi[c][j] = hi;
                 l2lo[c][j] = lo;
             }
         }
+        if (BLK && ce && a.ce_dlogits_out && g0) block_flush(a.ce_dlogits_out + (size_t)b * a.HW * K2, K2);
         const spx_rsrc ttr = make_rsrc(a.packed_tailT);
         const spx_rsrc gir = make_rsrc_pred(a.gact + (size_t)b * a.HW * K);
         const spx_rsrc dur = make_rsrc_pred(a.d_units + (size_t)b * a.HW * K);

@@ -66,6 +66,78 @@ hipError_t spx_launch_sum_groups(const float* parts, size_t n, int groups, float
     return hipGetLastError();
 }
 
+// Grouping-head tail as its own kernel (segmentation/model/model_multiscale_group.py:303-308): per pixel
+//   units = sum over the scale groups of the partial unit products, g = exp(units), logits = W_g . g
+// in plain fp32, for launches whose unit product ran scale-parallel (the tail needs the SUMMED units) or that carry the
+// cross entropy (computed here, on the logits still in registers).  One pixel per thread, W_g in LDS (broadcast reads).
+__global__ __launch_bounds__(SPX_CE_THREADS) void spx_group_tail_kernel(const float* __restrict__ parts, int groups, long long M,
+                                                                      int U, const float* __restrict__ Wg, int K2,
+                                                                      float* __restrict__ gact, float* __restrict__ logits,
+                                                                      const int32_t* __restrict__ labels, float* __restrict__ lse_out,
+                                                                      int32_t* __restrict__ pred, float* __restrict__ partials) {
+    extern __shared__ float wg_s[];                       // [K2][U]
+    for (int i = threadIdx.x; i < K2 * U; i += SPX_CE_THREADS) wg_s[i] = Wg[i];
+    __syncthreads();
+    const long long m_ = (long long)blockIdx.x * SPX_CE_THREADS + threadIdx.x;
+    const bool in = m_ < M;
+    const size_t row = (size_t)(in ? m_ : 0) * U;
+    float acc[32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) acc[k] = 0.0f;
+    for (int u = 0; u < U; ++u) {
+        float un = parts[row + u];
+        for (int g = 1; g < groups; ++g) un += parts[(size_t)g * M * U + row + u];     // scale order: deterministic
+        const float gv = ce_exp(un);
+        if (in && gact) gact[row + u] = gv;
+#pragma unroll
+        for (int k = 0; k < 32; ++k)
+            if (k < K2) acc[k] = __builtin_fmaf(wg_s[k * U + u], gv, acc[k]);
+    }
+    if (in) {
+#pragma unroll
+        for (int k = 0; k < 32; ++k)
+            if (k < K2) logits[(size_t)m_ * K2 + k] = acc[k];
+    }
+    if (!labels) return;
+    const int lab = in ? labels[m_] : -1;
+    const bool valid = in && (unsigned)lab < (unsigned)K2;
+    float mx = -3.0e38f, picked = 0.0f;
+    int best = 0x7fffffff;
+#pragma unroll
+    for (int k = 0; k < 32; ++k)
+        if (k < K2) {
+            ce_best(acc[k], k, mx, best);
+            picked = k == lab ? acc[k] : picked;
+        }
+    float ssum = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 32; ++k)
+        if (k < K2) ssum += ce_exp(acc[k] - mx);
+    const float lse = mx + ce_log(ssum);
+    if (in) {
+        lse_out[m_] = lse;
+        if (pred) pred[m_] = best;
+    }
+    float lossv = valid ? lse - picked : 0.0f, cnt = valid ? 1.0f : 0.0f;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        lossv += __shfl_xor(lossv, off);
+        cnt += __shfl_xor(cnt, off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        float* const pp = partials + ((size_t)blockIdx.x * (SPX_CE_THREADS / 64) + (threadIdx.x >> 6)) * 2;
+        pp[0] = lossv;
+        pp[1] = cnt;
+    }
+}
+hipError_t spx_launch_group_tail(const float* parts, int groups, long long M, int U, const float* Wg, int K2, float* gact,
+                                 float* logits, const int32_t* labels, float* lse, int32_t* pred, float* partials, hipStream_t s) {
+    const unsigned grid = (unsigned)((M + SPX_CE_THREADS - 1) / SPX_CE_THREADS);
+    hipLaunchKernelGGL(spx_group_tail_kernel, dim3(grid), dim3(SPX_CE_THREADS), (size_t)K2 * U * sizeof(float), s, parts, groups, M, U,
+                       Wg, K2, gact, logits, labels, lse, pred, partials);
+    return hipGetLastError();
+}
+
 hipError_t spx_launch_ce_fwd(const float* logits, const int32_t* labels, long long M, int K, float* lse, int32_t* pred,
                              float* partials, hipStream_t s) {
     const unsigned grid = (unsigned)((M + SPX_CE_THREADS - 1) / SPX_CE_THREADS);

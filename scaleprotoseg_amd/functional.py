@@ -305,14 +305,16 @@ class _ProtoHeadFn(torch.autograd.Function):
         gact = None
         ce = ce_state = None
         if ce_labels is not None:
-            if head is None or tail2d is not None:
-                raise SpxError("the fused cross entropy needs the plain class head (no grouping tail)")
+            if head is None:
+                raise SpxError("the fused cross entropy needs a head (logits)")
             if tuple(ce_labels.shape) != (B, HW) or ce_labels.dtype != torch.int32 or not ce_labels.is_cuda:
                 raise SpxError(f"ce labels must be int32 [{B}, {HW}] on the GPU (class 0..K-1, anything else = ignored)")
             ce_labels = ce_labels.contiguous()
             lse = torch.empty((B * HW,), **f32)
             pred = torch.empty((B * HW,), dtype=torch.int32, device=x.device)
-            partials = torch.empty((lib.spx_ce_partials(B, HW), 2), **f32)
+            # the grouping tail's kernel is pixel-per-thread (flat partial count); the plain head's epilogue is per tile
+            n_part = lib.spx_ce_partials_flat(B * HW) if tail2d is not None else lib.spx_ce_partials(B, HW)
+            partials = torch.empty((n_part, 2), **f32)
             ce = _lib.SpxCe(labels=_lib.ptr(ce_labels), lse=_lib.ptr(lse), pred=_lib.ptr(pred), partials=_lib.ptr(partials))
             ce_state = (ce_labels, lse, pred, partials)
         if tail2d is not None:
@@ -320,14 +322,28 @@ class _ProtoHeadFn(torch.autograd.Function):
             logits = torch.empty((B * HW, K2), **f32)
             gact = torch.empty((B * HW, K), **f32)
             dist = torch.empty((B, P) + tuple(x.shape[2:]), **f32) if want_dist else None
+            # the tail as its own kernel when the unit product runs scale-parallel (small pixel grids) or the cross
+            # entropy rides on the logits; otherwise fused into the distance kernel's epilogue
+            tail_ws = ce is not None or lib.spx_fwd_split_groups(C.byref(plan), B, HW) > 1
             with _timed("spx_dist_fwd"):
-                _lib.check(
-                    lib.spx_dist_fwd_group(
-                        C.byref(plan), _lib.ptr(x), xd, B, HW, _lib.ptr(packs.bank), _lib.ptr(packs.p2),
-                        _lib.ptr(packs.head), _lib.ptr(packs.tail), K2, _lib.ptr(dist), _lib.ptr(act),
-                        _lib.ptr(gact), _lib.ptr(logits), float(epsilon), ACT_FN[act_fn], _lib.stream_ptr(),
+                if tail_ws:
+                    ws = torch.empty(lib.spx_group_tail_workspace_bytes(C.byref(plan), B, HW), dtype=torch.uint8, device=x.device)
+                    _lib.check(
+                        lib.spx_dist_fwd_group_ws(
+                            C.byref(plan), _lib.ptr(x), xd, B, HW, _lib.ptr(packs.bank), _lib.ptr(packs.p2),
+                            _lib.ptr(packs.head), _lib.ptr(tail2d), K2, _lib.ptr(dist), _lib.ptr(act), _lib.ptr(gact),
+                            _lib.ptr(logits), C.byref(ce) if ce is not None else None, _lib.ptr(ws), float(epsilon),
+                            ACT_FN[act_fn], _lib.stream_ptr(),
+                        )
                     )
-                )
+                else:
+                    _lib.check(
+                        lib.spx_dist_fwd_group(
+                            C.byref(plan), _lib.ptr(x), xd, B, HW, _lib.ptr(packs.bank), _lib.ptr(packs.p2),
+                            _lib.ptr(packs.head), _lib.ptr(packs.tail), K2, _lib.ptr(dist), _lib.ptr(act),
+                            _lib.ptr(gact), _lib.ptr(logits), float(epsilon), ACT_FN[act_fn], _lib.stream_ptr(),
+                        )
+                    )
         else:
             if gather is not None:
                 if tuple(gather.labels.shape) != (B, HW) or gather.labels.dtype != torch.int32:
@@ -417,20 +433,30 @@ class _ProtoHeadFn(torch.autograd.Function):
                 # kernel, add, and take the ordinary d_logits path
                 dl = torch.empty_like(ctx.ce_logits)
                 _lib.check(lib.spx_ce_bwd(_lib.ptr(ctx.ce_logits), _lib.ptr(lse), _lib.ptr(ce_labels), _lib.ptr(coef),
-                                          B * HW, K, _lib.ptr(dl), s))
+                                          B * HW, int(ctx.ce_logits.shape[1]), _lib.ptr(dl), s))
                 gl = gl.reshape(dl.shape) + dl
             else:
-                d_logits_ce = torch.empty_like(ctx.ce_logits) if need_head else None
+                d_logits_ce = torch.empty_like(ctx.ce_logits) if (need_head or (ctx.tail2d is not None and ctx.needs_input_grad[9])) else None
                 ce = _lib.SpxCe(labels=_lib.ptr(ce_labels), lse=_lib.ptr(lse), logits=_lib.ptr(ctx.ce_logits),
                                 coef=_lib.ptr(coef), d_logits_out=_lib.ptr(d_logits_ce))
         dx = torch.empty_like(x) if need_x else None
         g_scr = torch.empty(scr, dtype=torch.uint8, device=dev) if need_bank else None
         a_scr = torch.empty(scr, dtype=torch.uint8, device=dev) if need_head else None
         tail2d, d_units, d_tail = ctx.tail2d, None, None
-        if tail2d is not None and gl is None:
+        if tail2d is not None and gl is None and ce is None:
             raise SpxError("backward through the fused group tail without a logits gradient")
         with _timed("spx_dist_bwd"):
-            if tail2d is not None:
+            if tail2d is not None and ce is not None:
+                d_units = torch.empty((B * HW, K), dtype=torch.float32, device=dev)
+                _lib.check(
+                    lib.spx_dist_bwd_group_ce(
+                        pp, _lib.ptr(x), xd, B, HW, _lib.ptr(packs.bank), _lib.ptr(packs.bankT), _lib.ptr(packs.p2),
+                        _lib.ptr(packs.headT), _lib.ptr(packs.tailT), int(tail2d.shape[0]), _lib.ptr(ctx.gact),
+                        _lib.ptr(gd), _lib.ptr(ga), C.byref(ce), _lib.ptr(d_units), _lib.ptr(dx), _lib.ptr(g_scr),
+                        _lib.ptr(a_scr), ctx.epsilon, ACT_FN[ctx.act_fn], s,
+                    )
+                )
+            elif tail2d is not None:
                 d_units = torch.empty((B * HW, K), dtype=torch.float32, device=dev)
                 _lib.check(
                     lib.spx_dist_bwd_group(
@@ -469,12 +495,12 @@ class _ProtoHeadFn(torch.autograd.Function):
                         _lib.ptr(dx), _lib.ptr(g_scr), _lib.ptr(a_scr), ctx.epsilon, ACT_FN[ctx.act_fn], s,
                     )
                 )
+        if ce is not None:
+            gl = d_logits_ce                          # formed by the pixel kernel's prologue
         if tail2d is not None:
             if ctx.needs_input_grad[9]:
                 d_tail = _pixel_outer(gl, ctx.gact)   # d W_g [K2, U]: one small product over the pixels
             gl = d_units                              # the parameter kernel's d_logits operand
-        if ce is not None:
-            gl = d_logits_ce                          # formed by the pixel kernel's prologue
         d_bank = d_head = None
         if need_bank or need_head:
             ws = torch.empty(lib.spx_bank_bwd_workspace_bytes(pp, B, HW) // 4, dtype=torch.float32, device=dev)

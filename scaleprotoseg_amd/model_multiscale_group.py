@@ -18,7 +18,8 @@ from typing import Any, List, Optional, Tuple
 import torch
 import torch.nn as nn
 
-from .functional import MAX_FUSED_HEAD_ROWS, MAX_FUSED_TAIL_CLASSES, SpxError, proto_head_forward, wide_linear
+from .functional import (MAX_FUSED_HEAD_ROWS, MAX_FUSED_TAIL_CLASSES, SpxError, cross_entropy_from_logits,
+                         proto_head_forward, wide_linear)
 from .model_multiscale import _PrototypeBankMixin, _build_add_on, _first_add_on_channels
 from .utils import projection_simplex_sort
 
@@ -132,9 +133,11 @@ class PPNetMultiScale(_PrototypeBankMixin, nn.Module):
 
     # ---- forward ------------------------------------------------------------------------------------
     def forward_from_conv_features(
-        self, conv_features, return_activations: bool = False, return_distances: bool = False
+        self, conv_features, return_activations: bool = False, return_distances: bool = False, ce_target=None
     ) -> Any:
-        """Same return-tuple rules as model_multiscale_group.py:404-452."""
+        """Same return-tuple rules as model_multiscale_group.py:404-452.  Extension: ``ce_target`` ([B, H, W] at the latent
+        resolution, 0 = void, 1..K) computes the pixel-wise cross entropy in the kernel that produces the logits and hangs
+        it on the returned logits (``logits.spx_ce``), exactly as the prototype-phase module does."""
         if isinstance(conv_features, list):
             return [self.forward_from_conv_features(c) for c in conv_features]
         if not (hasattr(self, "patch_classification") and self.patch_classification):
@@ -148,12 +151,20 @@ class PPNetMultiScale(_PrototypeBankMixin, nn.Module):
         wg = self.last_layer_group.weight
         rows, k2 = int(wd.shape[0]), int(wg.shape[0])
         kw = dict(want_distances=want_dist, epsilon=self.epsilon, activation=self.prototype_activation_function)
+        ce_labels = fused_ce = None
+        if ce_target is not None:
+            if tuple(ce_target.shape) != (B, H, W):
+                raise SpxError(f"ce_target must be [{B}, {H}, {W}] (latent grid), got {tuple(ce_target.shape)}")
+            ce_labels = (ce_target.reshape(B, -1).to(device=conv_features.device, dtype=torch.int32) - 1).contiguous()
         if rows <= MAX_FUSED_HEAD_ROWS and k2 <= MAX_FUSED_TAIL_CLASSES:
-            # whole grouping head in the kernel: units = act . Wd^T, exp, last_layer_group (:303-308)
-            logits, dist, act, _ = proto_head_forward(
+            # whole grouping head in the kernels: units = act . Wd^T, exp, last_layer_group (:303-308)
+            out = proto_head_forward(
                 conv_features, self.prototype_vectors, wd, self._layout(rows), want_activations=return_activations,
-                group_tail=wg, **kw,
+                group_tail=wg, ce_labels=ce_labels, **kw,
             )
+            logits, dist, act = out[:3]
+            if ce_labels is not None:
+                fused_ce = out[3]
         elif rows <= MAX_FUSED_HEAD_ROWS:
             # up to 160 units but more than 32 classes: the unit product stays in the kernel, the tail is a library GEMM
             units, dist, act = proto_head_forward(
@@ -167,7 +178,12 @@ class PPNetMultiScale(_PrototypeBankMixin, nn.Module):
                 conv_features, self.prototype_vectors, None, self._layout(1), want_activations=True, **kw,
             )
             logits = wide_linear(torch.exp(wide_linear(act, wd)), wg)
+        if ce_labels is not None and fused_ce is None:
+            fused_ce = cross_entropy_from_logits(logits, ce_labels)       # heads the fused kernels do not carry
         logits = logits.reshape(B, H, W, -1)
+        if fused_ce is not None:
+            fused_ce.target = ce_target
+            logits.spx_ce = fused_ce
         if return_activations and not return_distances:
             return logits, act
         if return_activations and return_distances:

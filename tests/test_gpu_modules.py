@@ -708,3 +708,52 @@ def test_fused_cross_entropy_with_a_second_use_of_the_logits():
     _grad_close(x.grad, c0.grad, "dX")
     _grad_close(net.prototype_vectors.grad, p0.grad, "dPrototypes")
     _grad_close(net.last_layer.weight.grad, w0.grad, "dLastLayer")
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 9, 11), (1, 40, 65)])
+def test_group_module_fused_cross_entropy(golden, B, H, W):
+    """Group phase: ce_target through the module (tail kernel: summed units -> exp -> W_g -> logits -> CE statistics),
+    forward value, `correct`, and the gradients of CE + a distance term against the oracle's autograd."""
+    from scaleprotoseg_amd.loss import PixelWiseCrossEntropyLoss
+    from scaleprotoseg_amd.model_multiscale_group import PPNetMultiScale as GroupNet
+
+    dev = _dev()
+    S, Cs, K, G, P = 4, 16, 5, 3, 40
+    gen = torch.Generator().manual_seed(20220227 + 53)
+    conv = O.bf16_representable(torch.sigmoid(torch.randn(B, S * Cs, H, W, generator=gen)))
+    torch.manual_seed(9)
+    net = GroupNet(_Backbone(S * Cs), 64, (P, Cs, 1, 1), [], K, add_on_layers_type="deeplab_simple",
+                   patch_classification=True, num_scales=S, num_groups=G)
+    with torch.no_grad():
+        net.prototype_vectors.copy_(O.bf16_representable(net.prototype_vectors.data))
+        net.last_layer_group.weight.add_(0.05 * torch.randn(K, G * K, generator=gen))
+    bank = net.prototype_vectors.detach().clone()
+    net = net.to(dev)
+    target = torch.randint(0, K + 1, (B, H, W), generator=gen)
+    ranges = {s: tuple(net.scale_num_prototypes[s]) for s in range(S)}
+    g_dist = torch.randn(B, P, H, W, generator=gen) * 1e-3
+    c0 = conv.clone().requires_grad_(True)
+    p0 = bank.clone().requires_grad_(True)
+    gw = [gp.weight.detach().cpu().clone().requires_grad_(True) for gp in net.group_projection]
+    wg = net.last_layer_group.weight.detach().cpu().clone().requires_grad_(True)
+    rl, rd, _ = O.forward_from_conv_features(c0, p0, ranges, S, None, class_identity=net.prototype_class_identity.cpu(),
+                                             group_weights=gw, last_layer_group_weight=wg)
+    ref_ce = torch.nn.functional.cross_entropy(rl.reshape(-1, K), target.reshape(-1) - 1, ignore_index=-1)
+    (ref_ce + (rd * g_dist).sum()).backward()
+
+    x = conv.to(dev).requires_grad_(True)
+    tgt = target.to(dev)
+    logits, dist = net.forward_from_conv_features(x, ce_target=tgt)
+    _close_fwd(logits, rl.detach(), "logits")
+    _close_fwd(dist, rd.detach(), "distances")
+    ce, correct = PixelWiseCrossEntropyLoss(ignore_index=-1, return_correct=True)(logits, tgt)
+    assert ce is logits.spx_ce.loss
+    assert abs(ce.item() - ref_ce.item()) <= 1e-4 * max(1.0, abs(ref_ce.item()))
+    (ce + (dist * g_dist.to(dev)).sum()).backward()
+    _grad_close(x.grad, c0.grad, "dX")
+    _grad_close(net.prototype_vectors.grad, p0.grad, "dPrototypes")
+    _grad_close(net.last_layer_group.weight.grad, wg.grad, "dLastLayerGroup")
+    scale = max(w.grad.abs().max().item() for w in gw)
+    for i, gp in enumerate(net.group_projection):
+        err = (gp.weight.grad.cpu() - gw[i].grad).abs().max().item()
+        assert err <= GRAD_TOL * scale, f"d group_projection[{i}]: {err:.3e} vs {scale:.3e}"
