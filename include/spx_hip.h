@@ -186,10 +186,9 @@ int spx_ce_fwd(const float* logits, const int32_t* labels, int64_t M, int32_t K,
 int spx_ce_bwd(const float* logits, const float* lse, const int32_t* labels, const float* coef, int64_t M, int32_t K,
                float* d_logits, void* stream);
 
-/* Grouping head with the tail as its own kernel: the unit product runs in the distance kernel (scale-parallel for small
- * pixel grids: the tail needs the SUMMED units), then one pixel-per-thread fp32 kernel forms units = sum of the per-scale
- * partials, g = exp(units), logits = W_g . g and - when `ce` is given - the cross-entropy statistics of the logits it still
- * holds in registers (partials: spx_ce_partials_flat(B*HW) pairs).  Wg: the RAW last_layer_group.weight [K2, U] fp32.
+/* Grouping head with the tail as its own kernel: the unit product runs in the distance kernel, then a small fp32 kernel
+ * forms g = exp(units), logits = W_g . g and - when `ce` is given - the cross-entropy statistics of the logits it has just
+ * formed (partials: spx_ce_partials_flat(B*HW) pairs).  Wg: the RAW last_layer_group.weight [K2, U] fp32.
  * workspace: spx_group_tail_workspace_bytes().  spx_dist_bwd_group_ce = spx_dist_bwd_group with (logits, lse, labels,
  * coef) in place of d_logits; d_logits_out then carries the formed [B*HW, K2] gradient (for d_W_g = d_logits^T . g). */
 size_t spx_group_tail_workspace_bytes(const spx_plan* plan, int32_t B, int32_t HW);

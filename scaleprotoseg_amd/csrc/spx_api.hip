@@ -255,9 +255,7 @@ static int check_cls(const char* who, const int32_t* labels, const uint32_t* pro
 }
 
 size_t spx_group_tail_workspace_bytes(const spx_plan* pl, int32_t B, int32_t HW) {
-    int32_t gf[SPX_MAX_PANELS + 1];
-    const int g = pl ? spx_split_groups(*pl, B, HW, gf) : 1;
-    return pl ? (size_t)g * B * HW * pl->num_classes * sizeof(float) : 0;
+    return pl ? (size_t)B * HW * pl->num_classes * sizeof(float) : 0;
 }
 
 int spx_dist_fwd_group_ws(const spx_plan* pl, const void* x, int32_t x_dtype, int32_t B, int32_t HW,
@@ -269,15 +267,18 @@ int spx_dist_fwd_group_ws(const spx_plan* pl, const void* x, int32_t x_dtype, in
     if (K2 < 1 || K2 > 32) return fail("spx_dist_fwd_group_ws: %d classes (at most 32)", K2);
     if (check_plan(pl)) return 1;
     if (ce && (!ce->labels || !ce->lse || !ce->partials)) return fail("spx_dist_fwd_group_ws: NULL labels / lse / partials");
-    // the unit product as the kernel's (per-scale partial) \"logits\" into the workspace, then the tail kernel
-    int32_t gf[SPX_MAX_PANELS + 1];
-    const int groups = spx_split_groups(*pl, B, HW, gf);
+    // the unit product as the kernel's \"logits\" into the workspace, then the tail kernel.  NOT scale-parallel: measured on
+    // the Cityscapes crops (10 x 65 x 65, 57 units) the per-scale partial units cost more traffic (4 x [M][57] written and
+    // re-read: +30 us) than the shorter panel walk saves
+    const int groups = 1;
     float* const parts = (float*)workspace;
     if (dist_fwd_impl(pl, x, x_dtype, B, HW, packed_bank, packed_p2, packed_head, distances, nullptr, nullptr, 0, nullptr,
-                      activations, parts, epsilon, act_fn, stream, SpxTailFwd{nullptr, 0, nullptr}, nullptr,
-                      groups > 1 ? (void*)parts : nullptr, /*keep_partials=*/true))
+                      activations, parts, epsilon, act_fn, stream, SpxTailFwd{nullptr, 0, nullptr}, nullptr, nullptr, true))
         return 1;
     const long long M = (long long)B * HW;
+    // the tail writes one (sum, count) pair per 64 pixels; the caller sized `partials` with spx_ce_partials_flat (>= that)
+    if (ce && hipMemsetAsync(ce->partials, 0, spx_ce_partials_flat(M) * 2 * sizeof(float), (hipStream_t)stream) != hipSuccess)
+        return fail("spx_dist_fwd_group_ws: clearing the partials failed");
     return hip_status(spx_launch_group_tail(parts, groups, M, pl->num_classes, Wg, K2, group_activations, logits,
                                             ce ? ce->labels : nullptr, ce ? ce->lse : nullptr, ce ? ce->pred : nullptr,
                                             ce ? ce->partials : nullptr, (hipStream_t)stream), "spx_dist_fwd_group_ws (tail)");

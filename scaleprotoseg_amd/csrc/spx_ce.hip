@@ -69,71 +69,89 @@ hipError_t spx_launch_sum_groups(const float* parts, size_t n, int groups, float
 // Grouping-head tail as its own kernel (segmentation/model/model_multiscale_group.py:303-308): per pixel
 //   units = sum over the scale groups of the partial unit products, g = exp(units), logits = W_g . g
 // in plain fp32, for launches whose unit product ran scale-parallel (the tail needs the SUMMED units) or that carry the
-// cross entropy (computed here, on the logits still in registers).  One pixel per thread, W_g in LDS (broadcast reads).
+// cross entropy (computed here, on the logits the kernel has just formed).  A workgroup takes 64 pixels: their [64][U]
+// unit rows are ONE contiguous block per group - summed, exponentiated and staged in LDS with coalesced accesses - then
+// thread (pixel, class quarter) forms up to 8 logits (W_g rows broadcast from LDS, the g row of a lane at an odd stride).
+#define SPX_TAIL_PX 64
 __global__ __launch_bounds__(SPX_CE_THREADS) void spx_group_tail_kernel(const float* __restrict__ parts, int groups, long long M,
                                                                       int U, const float* __restrict__ Wg, int K2,
                                                                       float* __restrict__ gact, float* __restrict__ logits,
                                                                       const int32_t* __restrict__ labels, float* __restrict__ lse_out,
                                                                       int32_t* __restrict__ pred, float* __restrict__ partials) {
-    extern __shared__ float wg_s[];                       // [K2][U]
+    extern __shared__ float tail_s[];
+    const int US = U | 1;                                 // odd row stride: conflict-free column walks
+    float* const wg_s = tail_s;                           // [K2][U]
+    float* const g_s = wg_s + K2 * U;                     // [64][US]
+    float* const l_s = g_s + SPX_TAIL_PX * US;            // [64][33]
+    const long long m0 = (long long)blockIdx.x * SPX_TAIL_PX;
+    const int npx = (int)((M - m0) < SPX_TAIL_PX ? (M - m0) : SPX_TAIL_PX);
     for (int i = threadIdx.x; i < K2 * U; i += SPX_CE_THREADS) wg_s[i] = Wg[i];
-    __syncthreads();
-    const long long m_ = (long long)blockIdx.x * SPX_CE_THREADS + threadIdx.x;
-    const bool in = m_ < M;
-    const size_t row = (size_t)(in ? m_ : 0) * U;
-    float acc[32];
-#pragma unroll
-    for (int k = 0; k < 32; ++k) acc[k] = 0.0f;
-    for (int u = 0; u < U; ++u) {
-        float un = parts[row + u];
-        for (int g = 1; g < groups; ++g) un += parts[(size_t)g * M * U + row + u];     // scale order: deterministic
-        const float gv = ce_exp(un);
-        if (in && gact) gact[row + u] = gv;
-#pragma unroll
-        for (int k = 0; k < 32; ++k)
-            if (k < K2) acc[k] = __builtin_fmaf(wg_s[k * U + u], gv, acc[k]);
-    }
-    if (in) {
-#pragma unroll
-        for (int k = 0; k < 32; ++k)
-            if (k < K2) logits[(size_t)m_ * K2 + k] = acc[k];
-    }
-    if (!labels) return;
-    const int lab = in ? labels[m_] : -1;
-    const bool valid = in && (unsigned)lab < (unsigned)K2;
-    float mx = -3.0e38f, picked = 0.0f;
-    int best = 0x7fffffff;
-#pragma unroll
-    for (int k = 0; k < 32; ++k)
-        if (k < K2) {
-            ce_best(acc[k], k, mx, best);
-            picked = k == lab ? acc[k] : picked;
+    const size_t base = (size_t)m0 * U;
+    for (int i = threadIdx.x; i < SPX_TAIL_PX * U; i += SPX_CE_THREADS) {
+        const int p = i / U, u = i - p * U;
+        float gv = 0.0f;
+        if (p < npx) {
+            float un = parts[base + i];
+            for (int g = 1; g < groups; ++g) un += parts[(size_t)g * M * U + base + i];     // scale order: deterministic
+            gv = ce_exp(un);
+            if (gact) gact[base + i] = gv;
         }
-    float ssum = 0.0f;
+        g_s[p * US + u] = gv;
+    }
+    __syncthreads();
+    const int p = threadIdx.x & (SPX_TAIL_PX - 1), kq = threadIdx.x / SPX_TAIL_PX;     // pixel, class quarter (8 classes)
+    float acc[8];
 #pragma unroll
-    for (int k = 0; k < 32; ++k)
-        if (k < K2) ssum += ce_exp(acc[k] - mx);
+    for (int j = 0; j < 8; ++j) acc[j] = 0.0f;
+    for (int u = 0; u < U; ++u) {
+        const float gv = g_s[p * US + u];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = kq * 8 + j;
+            if (k < K2) acc[j] = __builtin_fmaf(wg_s[k * U + u], gv, acc[j]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = kq * 8 + j;
+        if (k < K2) l_s[p * 33 + k] = acc[j];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < npx * K2; i += SPX_CE_THREADS) {       // coalesced [px][K2] rows
+        const int pp = i / K2, k = i - pp * K2;
+        logits[(size_t)m0 * K2 + i] = l_s[pp * 33 + k];
+    }
+    if (!labels || threadIdx.x >= SPX_TAIL_PX) return;                      // wave 0: one pixel per lane
+    const bool in = p < npx;
+    const int lab = in ? labels[m0 + p] : -1;
+    const bool valid = in && (unsigned)lab < (unsigned)K2;
+    float mx = -3.0e38f;
+    int best = 0x7fffffff;
+    for (int k = 0; k < K2; ++k) ce_best(l_s[p * 33 + k], k, mx, best);
+    float ssum = 0.0f;
+    for (int k = 0; k < K2; ++k) ssum += ce_exp(l_s[p * 33 + k] - mx);
     const float lse = mx + ce_log(ssum);
     if (in) {
-        lse_out[m_] = lse;
-        if (pred) pred[m_] = best;
+        lse_out[m0 + p] = lse;
+        if (pred) pred[m0 + p] = best;
     }
-    float lossv = valid ? lse - picked : 0.0f, cnt = valid ? 1.0f : 0.0f;
+    float lossv = valid ? lse - l_s[p * 33 + lab] : 0.0f, cnt = valid ? 1.0f : 0.0f;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
         lossv += __shfl_xor(lossv, off);
         cnt += __shfl_xor(cnt, off);
     }
-    if ((threadIdx.x & 63) == 0) {
-        float* const pp = partials + ((size_t)blockIdx.x * (SPX_CE_THREADS / 64) + (threadIdx.x >> 6)) * 2;
-        pp[0] = lossv;
-        pp[1] = cnt;
+    if (threadIdx.x == 0) {
+        partials[(size_t)blockIdx.x * 2] = lossv;
+        partials[(size_t)blockIdx.x * 2 + 1] = cnt;
     }
 }
+size_t spx_group_tail_partials(long long M) { return (size_t)((M + SPX_TAIL_PX - 1) / SPX_TAIL_PX); }
 hipError_t spx_launch_group_tail(const float* parts, int groups, long long M, int U, const float* Wg, int K2, float* gact,
                                  float* logits, const int32_t* labels, float* lse, int32_t* pred, float* partials, hipStream_t s) {
-    const unsigned grid = (unsigned)((M + SPX_CE_THREADS - 1) / SPX_CE_THREADS);
-    hipLaunchKernelGGL(spx_group_tail_kernel, dim3(grid), dim3(SPX_CE_THREADS), (size_t)K2 * U * sizeof(float), s, parts, groups, M, U,
+    const unsigned grid = (unsigned)((M + SPX_TAIL_PX - 1) / SPX_TAIL_PX);
+    const size_t lds = ((size_t)K2 * U + (size_t)SPX_TAIL_PX * (U | 1) + SPX_TAIL_PX * 33) * sizeof(float);
+    hipLaunchKernelGGL(spx_group_tail_kernel, dim3(grid), dim3(SPX_CE_THREADS), lds, s, parts, groups, M, U,
                        Wg, K2, gact, logits, labels, lse, pred, partials);
     return hipGetLastError();
 }

@@ -322,9 +322,9 @@ class _ProtoHeadFn(torch.autograd.Function):
             logits = torch.empty((B * HW, K2), **f32)
             gact = torch.empty((B * HW, K), **f32)
             dist = torch.empty((B, P) + tuple(x.shape[2:]), **f32) if want_dist else None
-            # the tail as its own kernel when the unit product runs scale-parallel (small pixel grids) or the cross
-            # entropy rides on the logits; otherwise fused into the distance kernel's epilogue
-            tail_ws = ce is not None or lib.spx_fwd_split_groups(C.byref(plan), B, HW) > 1
+            # the tail as its own (fp32) kernel when the cross entropy rides on the logits; otherwise fused into the
+            # distance kernel's epilogue
+            tail_ws = ce is not None
             with _timed("spx_dist_fwd"):
                 if tail_ws:
                     ws = torch.empty(lib.spx_group_tail_workspace_bytes(C.byref(plan), B, HW), dtype=torch.uint8, device=x.device)
@@ -388,7 +388,9 @@ class _ProtoHeadFn(torch.autograd.Function):
         ctx.layout, ctx.plan, ctx.packs = layout, plan, packs
         ctx.epsilon, ctx.act_fn = float(epsilon), act_fn
         ctx.have = (logits is not None, dist is not None, act is not None)
-        ctx.save_for_backward(x, bank2d, head2d)
+        # (the logits are an OUTPUT: kept through save_for_backward, never as a ctx attribute - that would be a reference
+        # cycle node -> ctx -> tensor -> node that outlives the backward and keeps the leaves' AccumulateGrad nodes alive)
+        ctx.save_for_backward(x, bank2d, head2d, logits if ce_state is not None else None)
         ctx.bank_shape = tuple(bank.shape)
         outs = tuple(t if t is not None else x.new_empty(0) for t in (logits, dist, act))
         extra = gact if tail2d is not None else x.new_empty(0)     # exp(units): an output for the caller, no gradient path
@@ -398,7 +400,7 @@ class _ProtoHeadFn(torch.autograd.Function):
             tot = ce_state[3].sum(dim=0)                          # (sum of the pixel losses, non-ignored pixels): fixed order
             ce_loss = tot[0] / tot[1]                               # 0 / 0 = nan when every pixel is ignored, as torch's mean
             ce_pred = ce_state[2]
-            ctx.ce_state, ctx.ce_count, ctx.ce_logits = ce_state, tot[1], logits
+            ctx.ce_state, ctx.ce_count = ce_state, tot[1]
         ctx.mark_non_differentiable(*([o for o, h in zip(outs, ctx.have) if not h] + [extra, ce_pred]
                                       + ([ce_loss] if ce_state is None else [])))
         return outs + (extra, ce_loss, ce_pred)
@@ -406,7 +408,7 @@ class _ProtoHeadFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_logits, g_dist, g_act, _g_gact=None, g_ce=None, _g_pred=None):
         lib = _lib.load()
-        x, bank2d, head2d = ctx.saved_tensors
+        x, bank2d, head2d, ce_logits = ctx.saved_tensors
         layout, plan, packs = ctx.layout, ctx.plan, ctx.packs
         B, HW = _check_x(x, layout)
         P, K, Cs = layout.num_prototypes, layout.num_classes, layout.channels_per_scale
@@ -431,13 +433,13 @@ class _ProtoHeadFn(torch.autograd.Function):
             if gl is not None:
                 # the logits ALSO carry a gradient of their own: form the cross entropy's part with the stand-alone
                 # kernel, add, and take the ordinary d_logits path
-                dl = torch.empty_like(ctx.ce_logits)
-                _lib.check(lib.spx_ce_bwd(_lib.ptr(ctx.ce_logits), _lib.ptr(lse), _lib.ptr(ce_labels), _lib.ptr(coef),
-                                          B * HW, int(ctx.ce_logits.shape[1]), _lib.ptr(dl), s))
+                dl = torch.empty_like(ce_logits)
+                _lib.check(lib.spx_ce_bwd(_lib.ptr(ce_logits), _lib.ptr(lse), _lib.ptr(ce_labels), _lib.ptr(coef),
+                                          B * HW, int(ce_logits.shape[1]), _lib.ptr(dl), s))
                 gl = gl.reshape(dl.shape) + dl
             else:
-                d_logits_ce = torch.empty_like(ctx.ce_logits) if (need_head or (ctx.tail2d is not None and ctx.needs_input_grad[9])) else None
-                ce = _lib.SpxCe(labels=_lib.ptr(ce_labels), lse=_lib.ptr(lse), logits=_lib.ptr(ctx.ce_logits),
+                d_logits_ce = torch.empty_like(ce_logits) if (need_head or (ctx.tail2d is not None and ctx.needs_input_grad[9])) else None
+                ce = _lib.SpxCe(labels=_lib.ptr(ce_labels), lse=_lib.ptr(lse), logits=_lib.ptr(ce_logits),
                                 coef=_lib.ptr(coef), d_logits_out=_lib.ptr(d_logits_ce))
         dx = torch.empty_like(x) if need_x else None
         g_scr = torch.empty(scr, dtype=torch.uint8, device=dev) if need_bank else None

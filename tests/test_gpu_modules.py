@@ -757,3 +757,39 @@ def test_group_module_fused_cross_entropy(golden, B, H, W):
     for i, gp in enumerate(net.group_projection):
         err = (gp.weight.grad.cpu() - gw[i].grad).abs().max().item()
         assert err <= GRAD_TOL * scale, f"d group_projection[{i}]: {err:.3e} vs {scale:.3e}"
+
+
+def test_fused_cross_entropy_leaves_no_graph_alive():
+    """The step's autograd graph must die with the step (an operator that kept an output on its ctx would form a
+    node -> ctx -> tensor -> node cycle: a memory leak, and a stale graph that capture_step rightly refuses)."""
+    import gc
+    import scaleprotoseg_amd as spx
+    from scaleprotoseg_amd.graphs import capture_step
+    from scaleprotoseg_amd.loss import PixelWiseCrossEntropyLoss
+
+    dev = _dev()
+    gc.collect()
+    gc.disable()                                        # the claim is about reference counts, not about the collector
+    try:
+        B, S, Cs, P, K, H, W = 2, 4, 16, 40, 5, 9, 11
+        net = spx.PPNetMultiScale(_Backbone(S * Cs), 64, (P, Cs, 1, 1), [], K, add_on_layers_type="deeplab_simple",
+                                  patch_classification=True, num_scales=S).to(dev)
+        net.add_on_layers = nn.Sequential()
+        x = torch.rand(B, S * Cs, H, W, device=dev).requires_grad_(True)
+        tgt = torch.randint(0, K + 1, (B, H, W), device=dev)
+        lossf = PixelWiseCrossEntropyLoss(ignore_index=-1)
+
+        def step():
+            x.grad = None
+            for p in net.parameters():
+                p.grad = None
+            logits, _ = net.forward_from_conv_features(x, ce_target=tgt)
+            lossf(logits, tgt).backward()
+
+        step()
+        step()
+        graph, _ = capture_step(step, warmup=1)          # raises SpxError if an eager graph is still alive
+        graph.replay()
+        torch.cuda.synchronize()
+    finally:
+        gc.enable()
