@@ -35,7 +35,7 @@ extern "C" {
 #endif
 
 #define SPX_MAX_PANELS 64   /* (scale, <=192-prototype block) work units per pixel tile */
-#define SPX_ABI_VERSION 8
+#define SPX_ABI_VERSION 9
 
 /* How the prototype bank is cut into MFMA panels.  Filled by spx_make_plan(). */
 typedef struct spx_plan {
@@ -185,6 +185,12 @@ int spx_ce_fwd(const float* logits, const int32_t* labels, int64_t M, int32_t K,
                float* partials, void* stream);
 int spx_ce_bwd(const float* logits, const float* lse, const int32_t* labels, const float* coef, int64_t M, int32_t K,
                float* d_logits, void* stream);
+
+/* out [n1, n2] = a^T . b for tall-skinny fp32 operands a [M, n1], b [M, n2] with n1 * n2 <= 8192: the d W_g = d_logits^T . g
+ * product of the grouping tail (segmentation/model/model_multiscale_group.py:305-308 through autograd) and its relatives.
+ * Deterministic (per-workgroup partials summed in workgroup order).  workspace: spx_pixel_outer_workspace_bytes(). */
+size_t spx_pixel_outer_workspace_bytes(int64_t M, int32_t n1, int32_t n2);
+int spx_pixel_outer(const float* a, const float* b, int64_t M, int32_t n1, int32_t n2, float* out, void* workspace, void* stream);
 
 /* Grouping head with the tail as its own kernel: the unit product runs in the distance kernel, then a small fp32 kernel
  * forms g = exp(units), logits = W_g . g and - when `ce` is given - the cross-entropy statistics of the logits it has just

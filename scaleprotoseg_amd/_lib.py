@@ -15,7 +15,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libspx_hip.so")
 SPX_MAX_PANELS = 64
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class SpxError(RuntimeError):
@@ -96,6 +96,8 @@ SIGNATURES = {
     "spx_group_tail_workspace_bytes": (C.c_size_t, [_PP, _I, _I]),
     "spx_dist_fwd_group_ws": (C.c_int, [_PP, _V, _I, _I, _I, _V, _V, _V, _V, _I, _V, _V, _V, _V, _PCE, _V, _F, _I, _V]),
     "spx_dist_bwd_group_ce": (C.c_int, [_PP, _V, _I, _I, _I, _V, _V, _V, _V, _V, _I, _V, _V, _V, _PCE, _V, _V, _V, _V, _F, _I, _V]),
+    "spx_pixel_outer_workspace_bytes": (C.c_size_t, [C.c_int64, _I, _I]),
+    "spx_pixel_outer": (C.c_int, [_V, _V, C.c_int64, _I, _I, _V, _V, _V]),
     "spx_ce_partials": (C.c_size_t, [_I, _I]),
     "spx_ce_partials_flat": (C.c_size_t, [C.c_int64]),
     "spx_dist_fwd_ce": (C.c_int, [_PP, _V, _I, _I, _I, _V, _V, _V, _V, _V, _I, _V, _V, _V, _V, _PCE, _F, _I, _V]),

@@ -451,6 +451,15 @@ int spx_dist_bwd_ce(const spx_plan* pl, const void* x, int32_t x_dtype, int32_t 
                          SpxTailBwd{nullptr, 0, nullptr, nullptr}, ce);
 }
 
+size_t spx_pixel_outer_workspace_bytes(int64_t M, int32_t n1, int32_t n2) {
+    return (size_t)spx_pixel_outer_blocks(M) * n1 * n2 * sizeof(float);
+}
+int spx_pixel_outer(const float* a, const float* b, int64_t M, int32_t n1, int32_t n2, float* out, void* workspace, void* stream) {
+    if (!a || !b || !out || !workspace) return fail("spx_pixel_outer: NULL buffer");
+    if (M < 1 || n1 < 1 || n2 < 1 || (long long)n1 * n2 > 8192) return fail("spx_pixel_outer: bad sizes (M=%lld, %d x %d; n1*n2 <= 8192)", (long long)M, n1, n2);
+    return hip_status(spx_launch_pixel_outer(a, b, M, n1, n2, out, (float*)workspace, (hipStream_t)stream), "spx_pixel_outer");
+}
+
 int spx_ce_fwd(const float* logits, const int32_t* labels, int64_t M, int32_t K, float* lse, int32_t* pred, float* partials,
                void* stream) {
     if (!logits || !labels || !lse || !partials) return fail("spx_ce_fwd: NULL buffer");

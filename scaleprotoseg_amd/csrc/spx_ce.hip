@@ -60,9 +60,37 @@ __global__ __launch_bounds__(SPX_CE_THREADS) void spx_sum_groups_kernel(const fl
     for (int g = 1; g < groups; ++g) s += parts[(size_t)g * n + i];
     out[i] = s;
 }
+// the same for MANY groups (the per-workgroup partials of spx_pixel_outer): 8 slices of the group range per output summed in
+// parallel (slice j takes groups j, j + 8, ...), combined through LDS in slice order - a fixed order, so still deterministic
+__global__ __launch_bounds__(SPX_CE_THREADS) void spx_sum_many_groups_kernel(const float* __restrict__ parts, size_t n, int groups,
+                                                                           float* __restrict__ out) {
+    __shared__ float red[8][32];
+    const int el = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const size_t i = (size_t)blockIdx.x * 32 + el;
+    float s0 = 0.0f, s1 = 0.0f;
+    if (i < n) {
+        int g = sl;
+        for (; g + 8 < groups; g += 16) {
+            s0 += parts[(size_t)g * n + i];
+            s1 += parts[(size_t)(g + 8) * n + i];
+        }
+        if (g < groups) s0 += parts[(size_t)g * n + i];
+    }
+    red[sl][el] = s0 + s1;
+    __syncthreads();
+    if (sl == 0 && i < n) {
+        float t = red[0][el];
+#pragma unroll
+        for (int j = 1; j < 8; ++j) t += red[j][el];
+        out[i] = t;
+    }
+}
 hipError_t spx_launch_sum_groups(const float* parts, size_t n, int groups, float* out, hipStream_t s) {
-    hipLaunchKernelGGL(spx_sum_groups_kernel, dim3((unsigned)((n + SPX_CE_THREADS - 1) / SPX_CE_THREADS)), dim3(SPX_CE_THREADS), 0, s,
-                       parts, n, groups, out);
+    if (groups > 16)
+        hipLaunchKernelGGL(spx_sum_many_groups_kernel, dim3((unsigned)((n + 31) / 32)), dim3(SPX_CE_THREADS), 0, s, parts, n, groups, out);
+    else
+        hipLaunchKernelGGL(spx_sum_groups_kernel, dim3((unsigned)((n + SPX_CE_THREADS - 1) / SPX_CE_THREADS)), dim3(SPX_CE_THREADS), 0, s,
+                           parts, n, groups, out);
     return hipGetLastError();
 }
 
@@ -154,6 +182,63 @@ hipError_t spx_launch_group_tail(const float* parts, int groups, long long M, in
     hipLaunchKernelGGL(spx_group_tail_kernel, dim3(grid), dim3(SPX_CE_THREADS), lds, s, parts, groups, M, U,
                        Wg, K2, gact, logits, labels, lse, pred, partials);
     return hipGetLastError();
+}
+
+// out[i][j] = sum over the pixels of a[m][i] * b[m][j] for tall-skinny fp32 operands (n1 * n2 <= 8192): d W_g = d_logits^T . g
+// of the grouping tail (19 x 57) and its relatives.  Every workgroup walks its pixel range in 32-pixel tiles staged in LDS
+// (coalesced), every thread keeps its outputs in registers, the per-workgroup partials are summed in workgroup order by
+// spx_sum_groups_kernel: deterministic, and no single-workgroup-shaped library GEMM (2.9 ms for 2 Mpx as a.t() @ b).
+#define SPX_OUTER_MAX 8192
+#define SPX_OUTER_EPT (SPX_OUTER_MAX / SPX_CE_THREADS)
+__global__ __launch_bounds__(SPX_CE_THREADS) void spx_pixel_outer_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                                       long long M, int n1, int n2, float* __restrict__ parts) {
+    extern __shared__ float po_s[];
+    float* const a_s = po_s;                 // [32][n1]
+    float* const b_s = po_s + 32 * n1;       // [32][n2]
+    const int nout = n1 * n2;
+    float acc[SPX_OUTER_EPT];
+    int oi[SPX_OUTER_EPT], oj[SPX_OUTER_EPT];
+#pragma unroll
+    for (int t = 0; t < SPX_OUTER_EPT; ++t) {
+        const int e = threadIdx.x + SPX_CE_THREADS * t;
+        acc[t] = 0.0f;
+        oi[t] = e < nout ? e / n2 : 0;
+        oj[t] = e < nout ? e - oi[t] * n2 : 0;
+    }
+    const long long per = ((M + gridDim.x - 1) / gridDim.x + 31) / 32 * 32;
+    const long long m_begin = (long long)blockIdx.x * per, m_end = m_begin + per < M ? m_begin + per : M;
+    for (long long m0 = m_begin; m0 < m_end; m0 += 32) {
+        const int np = (int)(m_end - m0 < 32 ? m_end - m0 : 32);
+        __syncthreads();
+        for (int i = threadIdx.x; i < 32 * n1; i += SPX_CE_THREADS) a_s[i] = i < np * n1 ? a[(size_t)m0 * n1 + i] : 0.0f;
+        for (int i = threadIdx.x; i < 32 * n2; i += SPX_CE_THREADS) b_s[i] = i < np * n2 ? b[(size_t)m0 * n2 + i] : 0.0f;
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < SPX_OUTER_EPT; ++t) {
+            if (threadIdx.x + SPX_CE_THREADS * t < nout) {
+                float s_ = acc[t];
+                for (int p = 0; p < 32; ++p) s_ = __builtin_fmaf(a_s[p * n1 + oi[t]], b_s[p * n2 + oj[t]], s_);
+                acc[t] = s_;
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < SPX_OUTER_EPT; ++t) {
+        const int e = threadIdx.x + SPX_CE_THREADS * t;
+        if (e < nout) parts[(size_t)blockIdx.x * nout + e] = acc[t];
+    }
+}
+int spx_pixel_outer_blocks(long long M) {
+    long long n = (M + 127) / 128;          // a workgroup per 128 pixels (4 LDS tiles) until the chip is well covered
+    return (int)(n < 1 ? 1 : (n > 1024 ? 1024 : n));
+}
+hipError_t spx_launch_pixel_outer(const float* a, const float* b, long long M, int n1, int n2, float* out, float* parts, hipStream_t s) {
+    const int blocks = spx_pixel_outer_blocks(M);
+    hipLaunchKernelGGL(spx_pixel_outer_kernel, dim3((unsigned)blocks), dim3(SPX_CE_THREADS), (size_t)32 * (n1 + n2) * sizeof(float), s,
+                       a, b, M, n1, n2, parts);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    return spx_launch_sum_groups(parts, (size_t)n1 * n2, blocks, out, s);
 }
 
 hipError_t spx_launch_ce_fwd(const float* logits, const int32_t* labels, long long M, int K, float* lse, int32_t* pred,

@@ -200,11 +200,20 @@ def _check_x(x: torch.Tensor, layout: BankLayout) -> Tuple[int, int]:
 
 
 def _pixel_outer(a: torch.Tensor, b: torch.Tensor, chunk: int = 4096) -> torch.Tensor:
-    """a^T . b for tall-skinny [M, n] operands (M = pixels, n <= a few dozen): chunked batched product + one sum.
-    The plain ``a.t() @ b`` is a single-workgroup-shaped GEMM (2.9 ms for 2 Mpx x 19 x 57 on MI355X vs 0.13 ms)."""
-    M = a.shape[0]
+    """a^T . b for tall-skinny [M, n] operands (M = pixels).  Up to 8192 output elements (d W_g of the grouping tail:
+    19 x 57) in the HIP kernel spx_pixel_outer; larger ones (the heads wider than the fused kernels: 450 x 1800) as a
+    chunked batched library product + one sum (the plain ``a.t() @ b`` is a single-workgroup-shaped GEMM: 2.9 ms for
+    2 Mpx x 19 x 57 on MI355X)."""
+    M, n1, n2 = a.shape[0], a.shape[1], b.shape[1]
+    if a.is_cuda and n1 * n2 <= 8192 and a.dtype == torch.float32 and b.dtype == torch.float32:
+        lib = _lib.load()
+        a, b = a.contiguous(), b.contiguous()
+        out = torch.empty((n1, n2), dtype=torch.float32, device=a.device)
+        ws = torch.empty(lib.spx_pixel_outer_workspace_bytes(M, n1, n2), dtype=torch.uint8, device=a.device)
+        _lib.check(lib.spx_pixel_outer(_lib.ptr(a), _lib.ptr(b), M, n1, n2, _lib.ptr(out), _lib.ptr(ws), _lib.stream_ptr()))
+        return out
     n = M // chunk
-    out = torch.zeros((a.shape[1], b.shape[1]), dtype=torch.float32, device=a.device)
+    out = torch.zeros((n1, n2), dtype=torch.float32, device=a.device)
     if n:
         out = out + torch.bmm(a[: n * chunk].view(n, chunk, -1).transpose(1, 2), b[: n * chunk].view(n, chunk, -1)).sum(0)
     if M % chunk:
