@@ -349,10 +349,21 @@ __global__ __launch_bounds__(SPX_BK_THREADS, 2) void spx_bank_bwd_kernel(const S
             const bf16x8 gf = __builtin_shufflevector(g0, g1, 0, 1, 2, 3, 4, 5, 6, 7);
             const bf16x8 gf2 = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
             if (ksplit || cpair == cs_owner(i)) {   // colsum(G): every lane holds 8 px of its prototype row; lanes r, r+32 cover the k-step
-                float s8 = 0.0f;
+                // 8 bf16 of the hi and of the lo fragment against ones: four 2-element dot products each (v_dot2_f32_bf16)
+                // instead of 16 unpack + add pairs
+                bf16x2 one2;
+                one2[0] = (__bf16)1.0f;
+                one2[1] = (__bf16)1.0f;
+                float s8 = csum[i];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) s8 += (float)gf[j] + (float)gf2[j];
-                csum[i] += s8;
+                for (int e = 0; e < 4; ++e) {
+                    bf16x2 ph, pl;
+                    ph[0] = gf[2 * e]; ph[1] = gf[2 * e + 1];
+                    pl[0] = gf2[2 * e]; pl[1] = gf2[2 * e + 1];
+                    s8 = __builtin_amdgcn_fdot2_f32_bf16(ph, one2, s8, false);
+                    s8 = __builtin_amdgcn_fdot2_f32_bf16(pl, one2, s8, false);
+                }
+                csum[i] = s8;
             }
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
