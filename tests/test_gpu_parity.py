@@ -1145,3 +1145,56 @@ def test_pixel_outer_kernel(M, n1, n2):
     scale = ref.abs().max().item() + 1e-30
     assert (out - ref).abs().max().item() <= 2e-5 * scale + 1e-6 * (M ** 0.5)
     assert torch.equal(out, _pixel_outer(a, b))
+
+
+@pytest.mark.parametrize("H,W", [(2, 2), (1, 7), (3, 3), (1, 8), (5, 13)])
+@pytest.mark.parametrize("x_dtype", [torch.float32, torch.bfloat16])
+def test_tiny_and_ragged_grids(H, W, x_dtype):
+    """Images of fewer than 8 pixels (element-wise staging), exactly one piece, and ragged ends below one tile."""
+    from scaleprotoseg_amd.functional import proto_head_forward
+
+    dev = _dev()
+    shape = (2, 4, 16, 40, 5, H, W)
+    B, S, Cs, P, K, _, _ = shape
+    conv, bank, Wl, ident, ranges = _problem(*shape, seed=5)
+    g = torch.Generator().manual_seed(9)
+    g_logits = torch.randn(B, H, W, K, generator=g) * 1e-3
+    g_dist = torch.randn(B, P, H, W, generator=g) * 1e-3
+    rl, rd, _, dx_ref, dp_ref, dw_ref = O.fwd_bwd_reference(conv, bank, ranges, S, Wl, g_logits, g_dist)
+    x = conv.to(dev, x_dtype).requires_grad_(True)
+    pv = bank.to(dev).requires_grad_(True)
+    w = Wl.to(dev).requires_grad_(True)
+    logits, dist, _ = proto_head_forward(x, pv, w, _layout(P, K, S, Cs, ranges))
+    _assert_fwd(logits, dist, None, rl, rd, None)
+    torch.autograd.backward([logits, dist], [g_logits.reshape(-1, K).to(dev), g_dist.to(dev)])
+    _grad_close(x.grad, dx_ref, "dX", tol=_dx_tol(x_dtype, ranges))
+    _grad_close(pv.grad, dp_ref, "dPrototypes")
+    _grad_close(w.grad, dw_ref, "dLastLayer")
+
+
+@pytest.mark.parametrize("x_dtype,offset", [(torch.bfloat16, 1), (torch.bfloat16, 3), (torch.float32, 1)])
+def test_features_at_an_unaligned_address(x_dtype, offset):
+    """A feature tensor that starts at an odd element of its storage (2- / 4-byte aligned base): the vector staging path
+    takes any alignment (gfx950 serves misaligned 16-B buffer accesses)."""
+    from scaleprotoseg_amd.functional import proto_head_forward
+
+    dev = _dev()
+    shape = (1, 1, 64, 210, 21, 8, 16)
+    B, S, Cs, P, K, H, W = shape
+    conv, bank, Wl, ident, ranges = _problem(*shape, seed=6)
+    g = torch.Generator().manual_seed(4)
+    g_logits = torch.randn(B, H, W, K, generator=g) * 1e-3
+    g_dist = torch.randn(B, P, H, W, generator=g) * 1e-3
+    rl, rd, _, dx_ref, dp_ref, dw_ref = O.fwd_bwd_reference(conv, bank, ranges, S, Wl, g_logits, g_dist)
+    store = torch.zeros(conv.numel() + 8, dtype=x_dtype, device=dev)
+    store[offset:offset + conv.numel()] = conv.to(dev, x_dtype).reshape(-1)
+    x = store[offset:offset + conv.numel()].view(conv.shape).requires_grad_(True)
+    assert x.data_ptr() % 16 != 0
+    pv = bank.to(dev).requires_grad_(True)
+    w = Wl.to(dev).requires_grad_(True)
+    logits, dist, _ = proto_head_forward(x, pv, w, _layout(P, K, S, Cs, ranges))
+    _assert_fwd(logits, dist, None, rl, rd, None)
+    gx, gp, gw = torch.autograd.grad([logits, dist], [x, pv, w], [g_logits.reshape(-1, K).to(dev), g_dist.to(dev)])
+    _grad_close(gx, dx_ref, "dX", tol=_dx_tol(x_dtype, ranges))
+    _grad_close(gp, dp_ref, "dPrototypes")
+    _grad_close(gw, dw_ref, "dLastLayer")
