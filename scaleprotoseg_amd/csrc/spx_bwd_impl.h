@@ -642,10 +642,12 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
                 if (f < 2 * NPB) *(u32x4*)(bt + buf * BT + f * 1024 + lane * 16) = bt_reg[i];
             }
         };
-        // x (and the previous partial dX) of a finish segment, as raw 16-B vectors; loaded one block ahead
+        // x (and the previous partial dX) of a finish segment, as raw 16-B vectors; loaded one block ahead.  A ragged image end
+        // (H*W not a multiple of the vector) sends the image's LAST tile down the element-wise path (tile-uniform switch).
+        const bool use_vec = VEC && !(RAG && !tile_full);
         u32x4 xw[VEC ? NV : 1], pw[VEC ? NV : 1];
         auto x_load = [&](int chb) {
-            if (VEC) {
+            if (use_vec) {
                 const bool ch_ok = chb * 32 + frow < Cs;
                 const spx_rsrc xir = make_rsrc_pred(x_img + (size_t)(ch0 + chb * 32) * a.HW * ESZ);
                 const spx_rsrc dxr = make_rsrc_pred((char*)a.dx + ((size_t)b * C + ch0 + chb * 32) * a.HW * ESZ);
@@ -662,33 +664,6 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
                 }
             }
         };
-        const bool ragged = RAG && !tile_full && (a.HW % PV != 0);       // tile-uniform: some vector straddles the image end
-        auto x_fix = [&](int chb) {
-            if (!ragged) return;
-            const bool ch_ok = chb * 32 + frow < Cs;
-            const spx_rsrc xir = make_rsrc_pred(x_img + (size_t)(ch0 + chb * 32) * a.HW * ESZ);
-            const spx_rsrc dxr = make_rsrc_pred((char*)a.dx + ((size_t)b * C + ch0 + chb * 32) * a.HW * ESZ);
-#pragma unroll
-            for (int v = 0; v < NV; ++v) {
-                const int over = fpx + (v + 1) * PV - a.HW;
-                if (ch_ok && over > 0 && over < PV) {             // this thread's straddling vector: element-wise
-                    u32x4 xe = {0u, 0u, 0u, 0u}, pe = {0u, 0u, 0u, 0u};
-#pragma unroll
-                    for (int e = 0; e < PV; ++e) {
-                        const uint32_t eo = e < PV - over ? fvo + 16u * v + (uint32_t)e * ESZ : SPX_OOB;
-                        if (XF32) {
-                            xe[e % 4] = __float_as_uint(buf_load_f32(xir, eo, 0));
-                            pe[e % 4] = first_of_scale ? 0u : __float_as_uint(buf_load_f32(dxr, eo, 0));
-                        } else {
-                            xe[e >> 1] |= (uint32_t)buf_load_u16(xir, eo, 0) << (16 * (e & 1));
-                            pe[e >> 1] |= (first_of_scale ? 0u : (uint32_t)buf_load_u16(dxr, eo, 0)) << (16 * (e & 1));
-                        }
-                    }
-                    xw[v] = xe;
-                    pw[v] = pe;
-                }
-            }
-        };
         bt_load(0);
         x_load(0);
         if (DACT) __syncthreads();     // the dAct scratch of slower waves sits where the P^T stages go
@@ -699,8 +674,7 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
             const spx_rsrc xir = make_rsrc_pred(x_img + (size_t)(ch0 + chb * 32) * a.HW * ESZ);
             const spx_rsrc dxr = make_rsrc_pred((char*)a.dx + ((size_t)b * C + ch0 + chb * 32) * a.HW * ESZ);
             float xv[16], pv[16];
-            if (VEC) {
-                x_fix(chb);
+            if (use_vec) {
 #pragma unroll
                 for (int v = 0; v < NV; ++v) {
 #pragma unroll
@@ -761,7 +735,7 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
 #pragma unroll
                 for (int e = 0; e < 4; ++e) ov[4 * v + e] = pv[4 * v + e] + 2.0f * (rv[e] * xv[4 * v + e] - tv[e]);
             }
-            if (VEC) {
+            if (use_vec) {
 #pragma unroll
                 for (int v = 0; v < NV; ++v) {
                     const bool ok = ch_ok && (fpx + (v + 1) * PV <= a.HW);
@@ -778,17 +752,6 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
                         }
                     }
                     buf_store_b128_p<SPX_AUX_DX_ST>(w, dxr, ok ? fvo + 16u * v : SPX_OOB, 0);
-                    if (ragged) {       // the straddling vector leaves element by element (nothing may land past the image)
-                        const int over = fpx + (v + 1) * PV - a.HW;
-                        if (ch_ok && over > 0 && over < PV) {
-#pragma unroll
-                            for (int e = 0; e < PV; ++e) {
-                                const uint32_t eo = e < PV - over ? fvo + 16u * v + (uint32_t)e * ESZ : SPX_OOB;
-                                if (XF32) buf_store_f32(__uint_as_float(w[e % 4]), dxr, eo, 0);
-                                else buf_store_u16((uint16_t)(w[e >> 1] >> (16 * (e & 1))), dxr, eo, 0);
-                            }
-                        }
-                    }
                 }
             } else {
 #pragma unroll
