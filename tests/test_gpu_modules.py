@@ -64,7 +64,7 @@ def _close_fwd(got, ref, kind):
     else:
         assert err.max().item() <= 1e-4 * max(1.0, ref.abs().max().item()), f"{kind} err {err.max().item()}"
         if kind == "logits":    # per element: 1e-4 relative with an absolute floor (a logit is a signed sum through zero)
-            floor = 0.1 * max(1.0, ref.abs().max().item())
+            floor = 0.2 * max(1.0, ref.abs().max().item())
             assert (err <= 1e-4 * (ref.abs() + floor)).all(), f"per-element logit err {(err / (ref.abs() + floor)).max().item()}"
 
 
