@@ -19,6 +19,12 @@
 // converted into the other and chunk c+2's loads are in flight, one barrier per chunk (the loads then have a whole
 // iteration to land instead of the MFMA phase only, and the conversion VALU of one wave runs under the other's MFMAs).
 #define SPX_BK_THREADS 512
+#ifndef SPX_BANK_PIPE
+#define SPX_BANK_PIPE 0
+#endif
+#ifndef SPX_BANK_STAGGER
+#define SPX_BANK_STAGGER 0
+#endif
 // LDS row stride of the [channel][px] images: 2 CPX + 16 bytes (144 / 80: conflict-free ds_read_b128)
 __host__ __device__ constexpr int spx_bk_row(int cpx) { return 2 * cpx + 16; }
 
@@ -92,7 +98,6 @@ __global__ __launch_bounds__(SPX_BK_THREADS, 2) void spx_bank_bwd_kernel(const S
     const long long cstep = a.nslabs;
     const long long c_begin = split;
     const long long c_end = total;                     // exclusive bound of this workgroup's walk c_begin, c_begin + cstep, ...
-    const long long c_last = c_begin < total ? c_begin + ((total - 1 - c_begin) / cstep) * cstep : c_begin;
     const bool want_w = DO_W && a.d_W != nullptr;
     const bool want_p = DO_P && a.d_bank != nullptr;
     constexpr int ESZ = XF32 ? 4 : 2;
@@ -175,12 +180,26 @@ __global__ __launch_bounds__(SPX_BK_THREADS, 2) void spx_bank_bwd_kernel(const S
     constexpr int LPT = (SPX_BK_PX * 32 * NCB + SPX_BK_THREADS - 1) / SPX_BK_THREADS;   // dLogits elements per thread (upper bound)
     const int piece = tid % PPR, prow = tid / PPR;   // X staging: piece of 8 px, row within a pass of RPP rows
 
-    auto issue = [&](Stage& st, long long c) {
-#ifdef SPX_DIAG_BANK_NOLOAD
-        c = c_begin;                                  // timing-only build: every chunk re-reads the first one (cache hits)
+    // The walk issues its chunks strictly in order (c_begin, c_begin + cstep, ...; past the end the last one again), so
+    // the (image, chunk-in-image) position advances incrementally: one 64-bit division per launch instead of one per chunk.
+    long long nx_c = c_begin;
+    int nx_b = (int)(c_begin / nci);
+    int nx_ci = (int)(c_begin - (long long)nx_b * nci);
+    const int step_b = (int)(cstep / nci), step_ci = (int)(cstep - (long long)step_b * nci);
+    auto issue = [&](Stage& st) {
+        const int b = nx_b;
+        const int ci = ci0 + nx_ci;
+#ifndef SPX_DIAG_BANK_NOLOAD                          // (timing-only build: every chunk re-reads the first one: cache hits)
+        if (nx_c + cstep < c_end) {
+            nx_c += cstep;
+            nx_b += step_b;
+            nx_ci += step_ci;
+            if (nx_ci >= nci) {
+                nx_ci -= nci;
+                ++nx_b;
+            }
+        }
 #endif
-        const int b = (int)(c / nci);
-        const int ci = ci0 + (int)(c - (long long)b * nci);
         constexpr int CPT = SPX_TILE_PX / CPX;            // chunks per kernel-1 tile
         const size_t tile_g = (size_t)b * tiles_per_img + ci / CPT;
         // the chunk's fragments are contiguous: kernel-1 waves NW1 (ci % CPT) ... of the tile
@@ -416,11 +435,11 @@ __global__ __launch_bounds__(SPX_BK_THREADS, 2) void spx_bank_bwd_kernel(const S
         }
     };
     if constexpr (!PIPE) {
-        if (c_begin < c_end) issue(stg[0], c_begin);
+        if (c_begin < c_end) issue(stg[0]);
         for (long long c = c_begin; c < c_end; c += cstep) {
             commit(stg[0]);
             __syncthreads();
-            issue(stg[0], c + cstep < c_end ? c + cstep : c);   // always issue (branch-free); the last chunk is re-read and ignored
+            issue(stg[0]);                               // always issue (branch-free); past the end the last chunk is re-read and ignored
             __builtin_amdgcn_sched_barrier(0);
             compute();
             __syncthreads();
@@ -429,25 +448,47 @@ __global__ __launch_bounds__(SPX_BK_THREADS, 2) void spx_bank_bwd_kernel(const S
         // three-stage software pipeline: chunk c computes from one LDS buffer | chunk c+1 is converted into the other |
         // the loads of chunks c+1 / c+2 are in flight in two register sets; one barrier per chunk.  Indices past the
         // walk's end re-read the last chunk (branch-free, results unused).
-        auto at = [&](long long c) { return c < c_end ? c : c_last; };
-        issue(stg[0], c_begin);
+        //
+        // SPX_BANK_STAGGER: waves w and w + 4 share a SIMD and run the same program.  The upper four ("late") take the two
+        // phases of every barrier interval in the opposite order - conversion first, MFMA phase second - so one partner's
+        // VALU work runs under the other's MFMA chains:
+        //     early:  C0 M1 | C1 M2 | C2 M3 | ...          (C = MFMA phase of a chunk, M = conversion of a chunk, | = barrier)
+        //     late:   M1 C0 | M2 C1 | M3 C2 | ...
+        // In every interval all waves read one buffer and write the other, so both orders are legal.  The late stream is the
+        // SAME rolled body (C, then M) with the barrier between the two instead of after them and the conversions running
+        // one chunk further ahead (one pre-rolled M1); its two load sets are named the other way round, so the body indexes
+        // the register sets statically.  Every wave executes one barrier per interval.
+        const bool late = SPX_BANK_STAGGER && wave >= 4;
+        const int la = late ? 1 : 0;                 // how many chunks further ahead this wave converts
+        issue(stg[0]);
         commit(stg[0]);                              // buffer 0 <- the first chunk
-        issue(stg[0], at(c_begin + cstep));
-        issue(stg[1], at(c_begin + 2 * cstep));
+        if (!late) {
+            issue(stg[0]);                           // chunk 1
+            issue(stg[1]);                           // chunk 2
+        } else {
+            issue(stg[1]);                           // chunk 1
+            issue(stg[0]);                           // chunk 2
+            use_buffer(1);
+            commit(stg[1]);                          // M1, before the first barrier
+            issue(stg[1]);                           // chunk 3
+        }
         __syncthreads();
         for (long long c = c_begin; c < c_end; c += 2 * cstep) {
             use_buffer(0);
             compute();                               // chunk c
-            use_buffer(1);
-            commit(stg[0]);                          // chunk c + 1
-            issue(stg[0], at(c + 3 * cstep));
-            __syncthreads();
+            if (late) __syncthreads();
+            use_buffer(1 - la);
+            commit(stg[0]);                          // chunk c + 1 (late: c + 2)
+            issue(stg[0]);                           // chunk c + 3 (late: c + 4)
+            if (!late) __syncthreads();
             if (c + cstep < c_end) {                 // workgroup-uniform
-                compute();                           // chunk c + 1 (buffer 1)
-                use_buffer(0);
-                commit(stg[1]);                      // chunk c + 2
-                issue(stg[1], at(c + 4 * cstep));
-                __syncthreads();
+                use_buffer(1);
+                compute();                           // chunk c + 1
+                if (late) __syncthreads();
+                use_buffer(la);
+                commit(stg[1]);                      // chunk c + 2 (late: c + 3)
+                issue(stg[1]);                       // chunk c + 4 (late: c + 5)
+                if (!late) __syncthreads();
             }
         }
     }
@@ -587,9 +628,6 @@ __global__ __launch_bounds__(SPX_RED_ELEMS * SPX_RED_PARTS) void spx_bank_reduce
 // writes, every load an L2 hit) 0.32 ms, commit + MFMA phase 0.73 ms, loads + commit without the MFMA phase 0.63 ms - the
 // kernel is bound by its on-chip work (every wave converts, then reads fragments and runs MFMA chains, two waves per
 // SIMD), not by load latency.  Kept as a switch, off.
-#ifndef SPX_BANK_PIPE
-#define SPX_BANK_PIPE 0
-#endif
 template <int NPB, int NCB, bool DO_P, bool DO_W, bool KSPLIT>
 static hipError_t launch_bank_k(const SpxBankBwdArgs& a, int x_dtype, dim3 grid, hipStream_t s) {
     // 32-px double-buffered chunks wherever the k-step split is not in use and two buffers fit the LDS
