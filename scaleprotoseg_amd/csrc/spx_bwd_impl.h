@@ -492,67 +492,112 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
                     for (int reg = 0; reg < 16; ++reg)
                         ga[reg] = __builtin_fmaf(act_c1, sc[r * 33 + (reg & 3) + 8 * (reg >> 2) + 4 * h], ga[reg]);
                 }
-                // straight-line element math, no per-element control flow: d, 1/((d+1)(d+eps)), a / ln 2, then G
-                float dr[16], rpv[16], av[16];
+                // straight-line element math on register PAIRS (packed fp32 / packed converts), no per-element control
+                // flow: d, 1/((d+1)(d+eps)), a / ln 2, then G.  Pair i = registers 2i, 2i+1 = two consecutive prototype rows.
+                f32x2 dr[8], rpv[8], av[8];
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
                     const f32x4 p2v = *(const f32x4*)(p2s + pb * 32 + 8 * g4 + 4 * h);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) dr[4 * g4 + e] = __builtin_fmaf(-2.0f, acc[SLOT][4 * g4 + e], p2v[e]) + x2;
+                    for (int e = 0; e < 4; ++e) dr[2 * g4 + (e >> 1)][e & 1] = __builtin_fmaf(-2.0f, acc[SLOT][4 * g4 + e], p2v[e]) + x2;
                 }
                 if (act_is_log) {
+                    // stage by stage over four pairs at a time: the packed ops of one pair depend on each other back to back,
+                    // four independent pairs fill the issue slots between them
 #pragma unroll
-                    for (int reg = 0; reg < 16; ++reg) {
-                        const float d = fmaxf(dr[reg], 0.0f);
-                        const float t1 = d + 1.0f, t2 = d + a.eps;
-                        const float rp = __builtin_amdgcn_rcpf(t1 * t2);          // 1 / ((d+1)(d+eps))
-                        rpv[reg] = rp;
-                        av[reg] = __builtin_amdgcn_logf(t1 * t1 * rp);            // log2((d+1)/(d+eps)): the blob is a / ln 2
+                    for (int g = 0; g < 2; ++g) {
+                        f32x2 t1[4], m[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            f32x2 d;
+                            d[0] = relu_f32(dr[4 * g + i][0]);
+                            d[1] = relu_f32(dr[4 * g + i][1]);
+                            t1[i] = d + 1.0f;
+                            m[i] = t1[i] * (d + a.eps);
+                        }
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            f32x2 rp;
+                            rp[0] = __builtin_amdgcn_rcpf(m[i][0]);                  // 1 / ((d+1)(d+eps))
+                            rp[1] = __builtin_amdgcn_rcpf(m[i][1]);
+                            rpv[4 * g + i] = rp;
+                            t1[i] = t1[i] * t1[i];
+                        }
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const f32x2 q = t1[i] * rpv[4 * g + i];
+                            av[4 * g + i][0] = __builtin_amdgcn_logf(q[0]);          // log2((d+1)/(d+eps)): the blob is a / ln 2
+                            av[4 * g + i][1] = __builtin_amdgcn_logf(q[1]);
+                        }
                     }
                 } else {
 #pragma unroll
-                    for (int reg = 0; reg < 16; ++reg) {
-                        rpv[reg] = 1.0f;
-                        av[reg] = fmaxf(-1.44269504089f * fmaxf(dr[reg], 0.0f), -65504.0f);   // the blob is fp16: saturate, never inf
+                    for (int i = 0; i < 8; ++i) {
+                        rpv[i] = 1.0f;
+#pragma unroll
+                        for (int e = 0; e < 2; ++e)
+                            av[i][e] = fmaxf(-1.44269504089f * relu_f32(dr[i][e]), -65504.0f);   // the blob is fp16: saturate, never inf
                     }
                 }
-                float gv[16];
+                f32x2 gv[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    f32x2 ga2, dd2;
+                    ga2[0] = ga[2 * i]; ga2[1] = ga[2 * i + 1];
+                    dd2[0] = ddc[2 * i]; dd2[1] = ddc[2 * i + 1];
+                    gv[i] = __builtin_elementwise_fma(ga2, rpv[i], dd2);
+                }
                 if (full && tile_full) {
 #pragma unroll
-                    for (int reg = 0; reg < 16; ++reg) gv[reg] = dr[reg] > 0.0f ? __builtin_fmaf(ga[reg], rpv[reg], ddc[reg]) : 0.0f;
+                    for (int i = 0; i < 8; ++i) {
+                        gv[i][0] = dr[i][0] > 0.0f ? gv[i][0] : 0.0f;
+                        gv[i][1] = dr[i][1] > 0.0f ? gv[i][1] : 0.0f;
+                    }
                 } else {
 #pragma unroll
-                    for (int reg = 0; reg < 16; ++reg) {
-                        const bool valid = px_ok && (pb * 32 + acc_row(reg, h) < np);
-                        gv[reg] = (valid && dr[reg] > 0.0f) ? __builtin_fmaf(ga[reg], rpv[reg], ddc[reg]) : 0.0f;
-                        av[reg] = valid ? av[reg] : 0.0f;
-                    }
+                    for (int i = 0; i < 8; ++i)
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            const bool valid = px_ok && (pb * 32 + acc_row(2 * i + e, h) < np);
+                            gv[i][e] = (valid && dr[i][e] > 0.0f) ? gv[i][e] : 0.0f;
+                            av[i][e] = valid ? av[i][e] : 0.0f;
+                        }
                 }
                 float gmax = 0.0f;
 #pragma unroll
-                for (int reg = 0; reg < 16; ++reg) gmax = fmaxf(gmax, __builtin_fabsf(gv[reg]));
+                for (int i = 0; i < 16; ++i) gmax = fmaxf(gmax, __builtin_fabsf(gv[i >> 1][i & 1]));
                 // gmax = m * 2^ex, m in [0.5, 1): scaled by 2^(15 - ex) the block's values stay below 2^15 (fp16 max 65504)
                 int ex = __builtin_amdgcn_frexp_expf(gmax);
                 ex = ex < -100 ? -100 : (ex > 100 ? 100 : ex);
                 const float gscale_dn = __builtin_amdgcn_ldexpf(1.0f, 15 - ex);
                 gscale_up = __builtin_amdgcn_ldexpf(1.0f, ex - 15);
+                u32x4 ghw[2], glw[2], gbw[2], anw[2];
 #pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    // register reg = 8 s2 + j of the tile -> element j of k-step s2 of the B fragment.  G enters
-                    // dX = 2 (rs x - P^T G) as a bf16 hi + lo pair (~2^-17 relative)
-                    __bf16 gb, gl;
-                    split_bf16(gv[reg], gb, gl);
-                    gout[reg >> 3][reg & 7] = gb;
-                    glo[reg >> 3][reg & 7] = gl;
+                for (int i = 0; i < 8; ++i) {
+                    // pair i = registers 8 s2 + j, j = 2 (i & 3), 2 (i & 3) + 1 of the tile -> elements j, j + 1 of k-step s2 = i >> 2
+                    // of the B fragment.  G enters dX = 2 (rs x - P^T G) as a bf16 hi + lo pair (~2^-17 relative)
+                    uint32_t hi, lo;
+                    split_bf16x2(gv[i], hi, lo);
+                    ghw[i >> 2][i & 3] = hi;
+                    glw[i >> 2][i & 3] = lo;
                     // the row sum uses the SAME rounded G as the P^T.G product: dX = 2 sum_p G_p (x - p) then carries
                     // G's rounding relative to |x - p|, not to |p| (matters where a pixel sits on a prototype)
-                    rs += (float)gb + (float)gl;
-                    gblob[reg >> 3][reg & 7] = (_Float16)(gv[reg] * gscale_dn);
+                    rs = add_bf16x2(lo, add_bf16x2(hi, rs));
+                    gbw[i >> 2][i & 3] = pack_f16x2(gv[i] * gscale_dn);
 #if SPX_ABLOB_USE_E4M12
-                    anew[reg >> 3][reg & 7] = act_is_log ? (unsigned short)ablob_pack(av[reg])
-                                                         : __builtin_bit_cast(unsigned short, (_Float16)av[reg]);
+                    anew[i >> 2][2 * (i & 3)] = act_is_log ? (unsigned short)ablob_pack(av[i][0]) : __builtin_bit_cast(unsigned short, (_Float16)av[i][0]);
+                    anew[i >> 2][2 * (i & 3) + 1] = act_is_log ? (unsigned short)ablob_pack(av[i][1]) : __builtin_bit_cast(unsigned short, (_Float16)av[i][1]);
 #else
-                    anew[reg >> 3][reg & 7] = (_Float16)av[reg];
+                    anw[i >> 2][i & 3] = pack_f16x2(av[i]);
+#endif
+                }
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    gout[s2] = __builtin_bit_cast(bf16x8, ghw[s2]);
+                    glo[s2] = __builtin_bit_cast(bf16x8, glw[s2]);
+                    gblob[s2] = __builtin_bit_cast(f16x8, gbw[s2]);
+#if !SPX_ABLOB_USE_E4M12
+                    anew[s2] = __builtin_bit_cast(f16x8, anw[s2]);
 #endif
                 }
             }

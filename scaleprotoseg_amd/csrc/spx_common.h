@@ -17,6 +17,8 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
 
 #define SPX_TILE_PX 128          // latent pixels per workgroup tile (4 waves x 32)
 #define SPX_XROW 160             // bf16 elements per LDS row of the [k][pixel] X image (128 + 32 pad:
@@ -215,9 +217,51 @@ __device__ __forceinline__ void split_bf16(float x, __bf16& hi, __bf16& lo) {
     lo = (__bf16)(x - (float)hi);
 }
 
+// The same split for TWO values at once, as packed words (element 0 in the low half): one packed convert for the high
+// parts, one packed subtract, one packed convert for the residuals (2.5 VALU per value instead of 4 when every value
+// is converted on its own and paired afterwards).
+__device__ __forceinline__ uint32_t pack_bf16x2(f32x2 v) {
+    bf16x2 p;
+    p[0] = (__bf16)v[0];
+    p[1] = (__bf16)v[1];
+    return __builtin_bit_cast(uint32_t, p);
+}
+__device__ __forceinline__ f32x2 unpack_bf16x2(uint32_t w) {
+    f32x2 v;
+    v[0] = __uint_as_float(w << 16);
+    v[1] = __uint_as_float(w & 0xffff0000u);
+    return v;
+}
+__device__ __forceinline__ void split_bf16x2(f32x2 v, uint32_t& hi, uint32_t& lo) {
+    hi = pack_bf16x2(v);
+    asm("" : "+v"(hi));      // keeps the unpack below on the packed word (otherwise element 0 is converted a second time on its own)
+    lo = pack_bf16x2(v - unpack_bf16x2(hi));
+}
+// sum of the two bf16 halves of a packed word, added to acc (v_dot2_f32_bf16 against ones)
+__device__ __forceinline__ float add_bf16x2(uint32_t w, float acc) {
+    bf16x2 one2;
+    one2[0] = (__bf16)1.0f;
+    one2[1] = (__bf16)1.0f;
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, w), one2, acc, false);
+}
+__device__ __forceinline__ uint32_t pack_f16x2(f32x2 v) {
+    f16x2 p;
+    p[0] = (_Float16)v[0];
+    p[1] = (_Float16)v[1];
+    return __builtin_bit_cast(uint32_t, p);
+}
+
 // Transposed LDS read: 4 k-rows x (this lane's pixel) -> 4 bf16, see cdna guide T10.
 __device__ __forceinline__ s16x4 lds_tr_read(const char* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+}
+
+// relu as ONE instruction.  fmaxf(x, 0) - and the med3 builtin, which the compiler rewrites to it - costs a second one (a
+// canonicalising v_max x, x) wherever x cannot be proven free of signalling NaNs, e.g. after packed fp32 arithmetic.
+__device__ __forceinline__ float relu_f32(float x) {
+    float d;
+    asm("v_max_f32 %0, 0, %1" : "=v"(d) : "v"(x));
+    return d;
 }
 
 __device__ __forceinline__ float act_log(float d, float eps) {
