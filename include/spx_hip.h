@@ -63,7 +63,7 @@ int spx_make_plan(int32_t P, int32_t K, int32_t S, int32_t Cs,
 
 /* Sizes (bytes) of the packed operand buffers for a plan. */
 size_t spx_packed_bank_bytes(const spx_plan* plan);   /* bf16 MFMA A-fragments of the bank          */
-size_t spx_packed_bankT_bytes(const spx_plan* plan);  /* bf16 A-fragments of bank^T (backward dX)   */
+size_t spx_packed_bankT_bytes(const spx_plan* plan);  /* bf16 A-fragments of -2 bank^T (backward dX) */
 size_t spx_packed_p2_bytes(const spx_plan* plan);     /* fp32 |p|^2 per padded prototype            */
 size_t spx_packed_head_bytes(const spx_plan* plan);   /* split-bf16 (hi,lo) fragments of W          */
 size_t spx_packed_headT_bytes(const spx_plan* plan);  /* split-bf16 fragments of W^T (backward)     */

@@ -279,17 +279,32 @@ __global__ __launch_bounds__(SPX_BK_THREADS, 2) void spx_bank_bwd_kernel(const S
                     // and in the blob's own lane order (the split is elementwise), so the waves of the head product
                     // only read fragments
                     const f16x8 hv = __builtin_bit_cast(f16x8, st.ar[i]);
-                    const u16x8 qv = __builtin_bit_cast(u16x8, st.ar[i]);
-                    bf16x8 ahi, alo;
+                    u32x4 ahw, alw;
+                    if (a_fix) {                                  // launch-uniform: the format word kernel 1 wrote
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        __bf16 hi, lo;
-                        split_bf16(a_fix ? ablob_unpack(qv[j]) : (float)hv[j], hi, lo);     // e4m12: hi + lo is exact
-                        ahi[j] = hi;
-                        alo[j] = lo;
+                        for (int j = 0; j < 4; ++j) {
+                            f32x2 v;
+                            v[0] = ablob_unpack(st.ar[i][j] & 0xffffu);             // e4m12: hi + lo is exact
+                            v[1] = ablob_unpack(st.ar[i][j] >> 16);
+                            uint32_t hi, lo;
+                            split_bf16x2(v, hi, lo);
+                            ahw[j] = hi;
+                            alw[j] = lo;
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            f32x2 v;
+                            v[0] = (float)hv[2 * j];
+                            v[1] = (float)hv[2 * j + 1];
+                            uint32_t hi, lo;
+                            split_bf16x2(v, hi, lo);
+                            ahw[j] = hi;
+                            alw[j] = lo;
+                        }
                     }
-                    *(u32x4*)(As + off) = __builtin_bit_cast(u32x4, ahi);
-                    *(u32x4*)(As2 + off) = __builtin_bit_cast(u32x4, alo);
+                    *(u32x4*)(As + off) = ahw;
+                    *(u32x4*)(As2 + off) = alw;
                 }
             }
         }

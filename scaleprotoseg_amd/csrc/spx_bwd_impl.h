@@ -291,28 +291,36 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
         if (BLK && lsrc) block_fetch(lsrc + (size_t)b * a.HW * K, K);
 #pragma unroll
         for (int c = 0; c < NCB * 2; ++c) {
+            u32x4 hw, lw;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int cls = c * 16 + 8 * h + j;
+            for (int j2 = 0; j2 < 4; ++j2) {
+                f32x2 v2;
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int j = 2 * j2 + e;
+                    const int cls = c * 16 + 8 * h + j;
+                    float v;
+                    if (BLK) v = (lsrc && cls < K) ? bsc[r * K + cls] : 0.0f;
+                    else v = buf_load_f32(lr, cls < K ? voff_l : SPX_OOB, (uint32_t)((c * 16 + j) * 4));
+                    if (ce) {
+                        v = cls < K ? ce_c * (ce_exp(v - ce_lse) - (cls == ce_lab ? 1.0f : 0.0f)) : 0.0f;
+                        if (BLK) {
+                            if (cls < K) bsc[r * K + cls] = v;
+                        } else {
+                            buf_store_f32(v, dor, (cls < K && g0) ? voff_l : SPX_OOB, (uint32_t)((c * 16 + j) * 4));
+                        }
+                    }
+                    v2[e] = v;
+                }
                 // pre-scaled by the constant factor of act'(d) (log: -(1-eps) / ((d+1)(d+eps)); linear: -1), so the
                 // element loop multiplies by 1/((d+1)(d+eps)) only
-                float v;
-                if (BLK) v = (lsrc && cls < K) ? bsc[r * K + cls] : 0.0f;
-                else v = buf_load_f32(lr, cls < K ? voff_l : SPX_OOB, (uint32_t)((c * 16 + j) * 4));
-                if (ce) {
-                    v = cls < K ? ce_c * (ce_exp(v - ce_lse) - (cls == ce_lab ? 1.0f : 0.0f)) : 0.0f;
-                    if (BLK) {
-                        if (cls < K) bsc[r * K + cls] = v;
-                    } else {
-                        buf_store_f32(v, dor, (cls < K && g0) ? voff_l : SPX_OOB, (uint32_t)((c * 16 + j) * 4));
-                    }
-                }
-                v *= act_c1;
-                __bf16 hi, lo;
-                split_bf16(v, hi, lo);
-                dlhi[c][j] = hi;
-                dllo[c][j] = lo;
+                uint32_t hi, lo;
+                split_bf16x2(v2 * act_c1, hi, lo);
+                hw[j2] = hi;
+                lw[j2] = lo;
             }
+            dlhi[c] = __builtin_bit_cast(bf16x8, hw);
+            dllo[c] = __builtin_bit_cast(bf16x8, lw);
         }
         if (BLK && ce && a.ce_dlogits_out && g0) block_flush(a.ce_dlogits_out + (size_t)b * a.HW * K, K);
     }
@@ -494,19 +502,25 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
                 }
                 // straight-line element math on register PAIRS (packed fp32 / packed converts), no per-element control
                 // flow: d, 1/((d+1)(d+eps)), a / ln 2, then G.  Pair i = registers 2i, 2i+1 = two consecutive prototype rows.
-                f32x2 dr[8], rpv[8], av[8];
+                f32x2 dr[8], av[8], gv[8];
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
                     const f32x4 p2v = *(const f32x4*)(p2s + pb * 32 + 8 * g4 + 4 * h);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) dr[2 * g4 + (e >> 1)][e & 1] = __builtin_fmaf(-2.0f, acc[SLOT][4 * g4 + e], p2v[e]) + x2;
                 }
+                auto pair_of = [](const auto& v, int i) {
+                    f32x2 p;
+                    p[0] = v[2 * i];
+                    p[1] = v[2 * i + 1];
+                    return p;
+                };
                 if (act_is_log) {
                     // stage by stage over four pairs at a time: the packed ops of one pair depend on each other back to back,
                     // four independent pairs fill the issue slots between them
 #pragma unroll
                     for (int g = 0; g < 2; ++g) {
-                        f32x2 t1[4], m[4];
+                        f32x2 t1[4], m[4], rpv[4];
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
                             f32x2 d;
@@ -520,32 +534,25 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
                             f32x2 rp;
                             rp[0] = __builtin_amdgcn_rcpf(m[i][0]);                  // 1 / ((d+1)(d+eps))
                             rp[1] = __builtin_amdgcn_rcpf(m[i][1]);
-                            rpv[4 * g + i] = rp;
+                            rpv[i] = rp;
                             t1[i] = t1[i] * t1[i];
                         }
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
-                            const f32x2 q = t1[i] * rpv[4 * g + i];
+                            const f32x2 q = t1[i] * rpv[i];
                             av[4 * g + i][0] = __builtin_amdgcn_logf(q[0]);          // log2((d+1)/(d+eps)): the blob is a / ln 2
                             av[4 * g + i][1] = __builtin_amdgcn_logf(q[1]);
+                            gv[4 * g + i] = __builtin_elementwise_fma(pair_of(ga, 4 * g + i), rpv[i], pair_of(ddc, 4 * g + i));
                         }
                     }
                 } else {
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
-                        rpv[i] = 1.0f;
 #pragma unroll
                         for (int e = 0; e < 2; ++e)
                             av[i][e] = fmaxf(-1.44269504089f * relu_f32(dr[i][e]), -65504.0f);   // the blob is fp16: saturate, never inf
+                        gv[i] = pair_of(ga, i) + pair_of(ddc, i);        // act' = -1 (folded into ga)
                     }
-                }
-                f32x2 gv[8];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    f32x2 ga2, dd2;
-                    ga2[0] = ga[2 * i]; ga2[1] = ga[2 * i + 1];
-                    dd2[0] = ddc[2 * i]; dd2[1] = ddc[2 * i + 1];
-                    gv[i] = __builtin_elementwise_fma(ga2, rpv[i], dd2);
                 }
                 if (full && tile_full) {
 #pragma unroll
@@ -654,9 +661,9 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
             clear_acc();
             return;
         }
-        // ---- phase 2: dX^T[ch x px] = 2 (rs * x - P^T . G), one 32-channel block per (rolled) iteration ----
+        // ---- phase 2: dX^T[ch x px] = 2 rs * x + (-2 P)^T . G, one 32-channel block per (rolled) iteration ----
         const float rs_tot = rs + __shfl_xor(rs, 32);
-        if (h == 0) rss[32 * wave + r] = rs_tot;
+        if (h == 0) rss[32 * wave + r] = 2.0f * rs_tot;      // the finish below wants 2 rs (the P^T fragments carry -2 p)
         const bool first_of_scale = (panel == q_begin) || (pl.panel_ch0[panel - 1] != ch0);
         constexpr int BT = spx_bwd_bt_bytes<NPB>();
         char* const bt = smem;                               // 2 x BT  (P^T fragments of one channel block)
@@ -778,7 +785,7 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
                 const f32x4 tv = *(const f32x4*)(T + frow * SPX_T_ROW + fseg * 64 + v * 16);
                 const f32x4 rv = *(const f32x4*)(rss + fseg * 16 + v * 4);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) ov[4 * v + e] = pv[4 * v + e] + 2.0f * (rv[e] * xv[4 * v + e] - tv[e]);
+                for (int e = 0; e < 4; ++e) ov[4 * v + e] = pv[4 * v + e] + __builtin_fmaf(rv[e], xv[4 * v + e], tv[e]);   // 2 rs x - 2 P^T.G in one rounding
             }
             if (use_vec) {
 #pragma unroll

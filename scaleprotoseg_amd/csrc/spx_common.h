@@ -188,18 +188,22 @@ __device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
 // what carried d_W past 1e-3 - and 13 significant bits are an exact bf16 hi + lo pair).  Encoded value v = a / (16 ln 2) in
 // [0, 1): exponents -16 .. -1; anything below 2^-16 is 0.  "linear" activations (-d: signed, unbounded) stay fp16.  The
 // format word sits behind the blobs.
-// Measured on MI355X (same-box A/B, north-star shape): e4m12 costs +0.06 ms in kernel 1 and +0.055 ms in kernel 2 (3.7 % of the
-// step) and takes the d_W peak of a 600-configuration fuzz from 1.11e-3 to 3.9e-4 of max|d_W|; fp16 keeps every
-// configuration of the test suite inside 1e-3 and 597 of those 600.  Default: fp16 (SPX_ABLOB_USE_E4M12 0).
+// Measured on MI355X (same-box A/B, north-star shape, end of round 2): e4m12 costs +0.05 ms in kernel 1 (3 VALU per element
+// against half a packed convert) and nothing measurable in kernel 2 (the decode sits under a launch-uniform branch), i.e. 1.7 %
+// of the step, and takes the d_W peak of a 600-configuration fuzz from 1.11e-3 to 3.9e-4 of max|d_W|; fp16 keeps every
+// configuration of the test suite inside 1e-3 and ~99.3 % of the fuzzed toy configurations (worst seen: 1.7e-3).
+// Default: fp16 (SPX_ABLOB_USE_E4M12 0).
 #ifndef SPX_ABLOB_USE_E4M12
 #define SPX_ABLOB_USE_E4M12 0
 #endif
 #define SPX_ABLOB_FP16 0u
 #define SPX_ABLOB_E4M12 1u
 #define SPX_ABLOB_SCALE 16.0f
-// 4 VALU per element: scale, integer add (rounding + re-bias in one constant), arithmetic shift, clamp
+// 3 VALU per element: integer add (rounding, re-bias and the 1/16 scale - four exponent steps - in one constant),
+// arithmetic shift, clamp
 __device__ __forceinline__ uint32_t ablob_pack(float a_over_ln2) {
-    int t = (int)__float_as_uint(a_over_ln2 * (1.0f / SPX_ABLOB_SCALE)) + (int)(0x400u - (111u << 23));
+    static_assert(SPX_ABLOB_SCALE == 16.0f, "the scale is folded into the exponent re-bias below");
+    int t = (int)__float_as_uint(a_over_ln2) + (int)(0x400u - (115u << 23));
     t >>= 11;                                                       // < 0 for values below 2^-16 (and for 0)
     t = t < 0 ? 0 : t;                                              // the compiler folds the two clamps into v_med3_i32
     return (uint32_t)(t > 65535 ? 65535 : t);

@@ -100,6 +100,15 @@ __global__ __launch_bounds__(256 * SPLIT, (NPB == 2 && NCB == 1 ? 3 : SPX_FWD_WA
     for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
         for (int i = 0; i < 16; ++i) accl[cb][i] = 0.0f;
+    // SPX_FWD_DUAL_HEAD: the one-class-block head keeps a second logits accumulator for k-step 1 of every block, so the six
+    // head MFMAs of a block form two dependent chains of three instead of one of six (summed once, after the last panel)
+#ifndef SPX_FWD_DUAL_HEAD
+#define SPX_FWD_DUAL_HEAD 0
+#endif
+    constexpr bool DUAL = SPX_FWD_DUAL_HEAD && NCB == 1 && SPLIT == 1;
+    f32x16 accl2;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) accl2[i] = 0.0f;
 #pragma unroll
     for (int pb = 0; pb < NH; ++pb)
 #pragma unroll
@@ -274,9 +283,15 @@ __global__ __launch_bounds__(256 * SPLIT, (NPB == 2 && NCB == 1 ? 3 : SPX_FWD_WA
                                 whi = __builtin_bit_cast(bf16x8, buf_load_b128(hr, (uint32_t)lane * 16u, so));
                                 wlo = __builtin_bit_cast(bf16x8, buf_load_b128(hr, (uint32_t)lane * 16u, so + 1024u));
                             }
-                            accl[cb] = mfma_bf16(whi, ahi, accl[cb]);
-                            accl[cb] = mfma_bf16(wlo, ahi, accl[cb]);
-                            accl[cb] = mfma_bf16(whi, alo, accl[cb]);
+                            if (DUAL && s2 == 1) {
+                                accl2 = mfma_bf16(whi, ahi, accl2);
+                                accl2 = mfma_bf16(wlo, ahi, accl2);
+                                accl2 = mfma_bf16(whi, alo, accl2);
+                            } else {
+                                accl[cb] = mfma_bf16(whi, ahi, accl[cb]);
+                                accl[cb] = mfma_bf16(wlo, ahi, accl[cb]);
+                                accl[cb] = mfma_bf16(whi, alo, accl[cb]);
+                            }
                         }
                     }
                 }
@@ -320,6 +335,10 @@ __global__ __launch_bounds__(256 * SPLIT, (NPB == 2 && NCB == 1 ? 3 : SPX_FWD_WA
         }
     }
 
+    if (DUAL) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) accl[0][i] += accl2[i];
+    }
     if (want_head && SPLIT == 2) {
         // the upper prototype half hands its logits partial to the lower one through its own scratch tile
         // (wave-private until here: its last transposed reads were issued before, LDS serves a wave in order)
