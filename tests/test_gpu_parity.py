@@ -1172,6 +1172,31 @@ def test_tiny_and_ragged_grids(H, W, x_dtype):
     _grad_close(w.grad, dw_ref, "dLastLayer")
 
 
+@pytest.mark.parametrize("B,H,W", [(300, 3, 5), (140, 9, 11), (37, 13, 21)])
+def test_many_small_images(B, H, W):
+    """More images than the parameter-side kernel has slabs: its chunk walk then steps over whole images (step > chunks per
+    image; the position advances incrementally, spx_bank.hip) and every slab sums chunks of several images."""
+    from scaleprotoseg_amd.functional import proto_head_forward
+
+    dev = _dev()
+    shape = (B, 2, 16, 12, 3, H, W)
+    _, S, Cs, P, K, _, _ = shape
+    conv, bank, Wl, ident, ranges = _problem(*shape, seed=8)
+    g = torch.Generator().manual_seed(10)
+    g_logits = torch.randn(B, H, W, K, generator=g) * 1e-3
+    g_dist = torch.randn(B, P, H, W, generator=g) * 1e-3
+    rl, rd, _, dx_ref, dp_ref, dw_ref = O.fwd_bwd_reference(conv, bank, ranges, S, Wl, g_logits, g_dist)
+    x = conv.to(dev, torch.bfloat16).requires_grad_(True)
+    pv = bank.to(dev).requires_grad_(True)
+    w = Wl.to(dev).requires_grad_(True)
+    logits, dist, _ = proto_head_forward(x, pv, w, _layout(P, K, S, Cs, ranges))
+    _assert_fwd(logits, dist, None, rl, rd, None)
+    torch.autograd.backward([logits, dist], [g_logits.reshape(-1, K).to(dev), g_dist.to(dev)])
+    _grad_close(x.grad, dx_ref, "dX", tol=_dx_tol(torch.bfloat16, ranges))
+    _grad_close(pv.grad, dp_ref, "dPrototypes")
+    _grad_close(w.grad, dw_ref, "dLastLayer")
+
+
 @pytest.mark.parametrize("x_dtype,offset", [(torch.bfloat16, 1), (torch.bfloat16, 3), (torch.float32, 1)])
 def test_features_at_an_unaligned_address(x_dtype, offset):
     """A feature tensor that starts at an odd element of its storage (2- / 4-byte aligned base): the vector staging path
