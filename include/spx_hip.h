@@ -90,9 +90,9 @@ int spx_dist_fwd(const spx_plan* plan, const void* x, int32_t x_dtype, int32_t B
 
 /* Backward, pixel side: recomputes the distance tile, forms
  *   G = (dDist + (dAct + dLogits.W) * act'(d)) * [d > 0]
- * and writes dX = 2 (rowsum_s(G) x - G.P) in X's dtype, plus 16-bit copies of G (fp16, scaled per lane and block; the
- * inverse scales follow the blobs) and of the activations (a 4-bit-exponent / 12-bit-mantissa float for "log", fp16 for
- * "linear") in MFMA-fragment order for spx_bank_bwd (spx_bwd_scratch_bytes() each; opaque to the caller).  Replaces autograd through
+ * and writes dX = 2 (rowsum_s(G) x - G.P) in X's dtype, plus 16-bit copies of G (fp16) and of the activations (int16), both
+ * scaled per pixel and 32-prototype block by a power of two (the inverse scales follow the blobs), in MFMA-fragment order
+ * for spx_bank_bwd (spx_bwd_scratch_bytes() each; opaque to the caller).  Replaces autograd through
  * model_multiscale.py:255-281,324-330,243-244.  d_dist / d_act / d_logits may be NULL (treated as 0);
  * dx may be NULL (X frozen); g_out / a_out may be NULL when the bank / head are frozen. */
 int spx_dist_bwd(const spx_plan* plan, const void* x, int32_t x_dtype, int32_t B, int32_t HW,

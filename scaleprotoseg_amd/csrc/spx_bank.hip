@@ -158,7 +158,7 @@ __global__ __launch_bounds__(SPX_BK_THREADS, 2) void spx_bank_bwd_kernel(const S
     // staging registers: one set per chunk in flight (the pipelined variant keeps two chunks of loads in flight)
     struct Stage {
         u32x4 gr[FP], ar[FP], xr[XPT][XF32 ? 2 : 1];
-        float gsc[FP];                                // inverse scale of each staged G piece (one lane of one block)
+        uint32_t exw[FP];                             // block exponents of each staged piece (one lane of one block): G | activation << 8, +128 each
         float lr_[(CPX * 32 * NCB + SPX_BK_THREADS - 1) / SPX_BK_THREADS];
         uint32_t rot_bits;                            // this thread's X piece straddles the image end (see SpxXStager::make_ctx)
         bool ragged;                                  // chunk-uniform: some piece of the chunk does
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(SPX_BK_THREADS, 2) void spx_bank_bwd_kernel(const S
     }
     const size_t blob_total = (size_t)pl.npanels * ntiles * 4 * NPB * 2 * 1024;
     // activation blob format (kernel 1 wrote the word behind the blobs)
-    const bool a_fix = SPX_ABLOB_USE_E4M12 && DO_W && a.a_in && *(const uint32_t*)((const char*)a.a_in + blob_total) == SPX_ABLOB_E4M12;
+    const uint32_t a_fmt = (DO_W && a.a_in) ? *(const uint32_t*)((const char*)a.a_in + spx_ablob_fmt_offset(blob_total)) : SPX_ABLOB_FP16;
     constexpr int LPT = (SPX_BK_PX * 32 * NCB + SPX_BK_THREADS - 1) / SPX_BK_THREADS;   // dLogits elements per thread (upper bound)
     const int piece = tid % PPR, prow = tid / PPR;   // X staging: piece of 8 px, row within a pass of RPP rows
 
@@ -206,12 +206,14 @@ __global__ __launch_bounds__(SPX_BK_THREADS, 2) void spx_bank_bwd_kernel(const S
         const size_t blob0 = ((((size_t)q * ntiles + tile_g) * 4 + NW1 * (ci % CPT)) * NPB * 2) * 1024;
         const spx_rsrc grs = make_rsrc_pred(a.g_in ? (const char*)a.g_in + blob0 : nullptr);
         const spx_rsrc ars = make_rsrc_pred(a.a_in ? (const char*)a.a_in + blob0 : nullptr);
-        const spx_rsrc gss = make_rsrc_pred(a.g_in ? (const char*)a.g_in + blob_total + blob0 / 8 : nullptr);
+        // the exponent words sit behind either blob (kernel 1 writes them to both): read the G scratch's when it is there
+        const char* const exsrc = (want_p && a.g_in) ? (const char*)a.g_in : ((want_w && a.a_in) ? (const char*)a.a_in : nullptr);
+        const spx_rsrc exs = make_rsrc_pred(exsrc ? exsrc + blob_total + blob0 / 8 : nullptr);
 #pragma unroll
         for (int i = 0; i < FP; ++i) {
             const uint32_t off = (uint32_t)((i * SPX_BK_THREADS + tid) * 16);
             st.gr[i] = buf_load_b128_p<SPX_AUX_BLOB_LD>(grs, (want_p && off < (uint32_t)FBYTES) ? off : SPX_OOB, 0);
-            st.gsc[i] = buf_load_f32(gss, want_p ? gsc_off[i] : SPX_OOB, 0);
+            st.exw[i] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(exs, exsrc ? gsc_off[i] : SPX_OOB, 0, 0);
             st.ar[i] = buf_load_b128_p<SPX_AUX_BLOB_LD>(ars, (want_w && off < (uint32_t)FBYTES) ? off : SPX_OOB, 0);
         }
         const int px = ci * SPX_BK_PX + piece * 8;
@@ -263,11 +265,12 @@ __global__ __launch_bounds__(SPX_BK_THREADS, 2) void spx_bank_bwd_kernel(const S
             if (off < FBYTES) {
                 if (DO_P) {
                     const f16x8 hv = __builtin_bit_cast(f16x8, st.gr[i]);
+                    const float gsc = __builtin_amdgcn_ldexpf(1.0f, (int)(st.exw[i] & 0xffu) - (128 + 15));   // kernel 1 scaled by 2^(15 - ex)
                     bf16x8 ghi, glo;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         __bf16 hi, lo;
-                        split_bf16((float)hv[j] * st.gsc[i], hi, lo);      // 11-bit mantissa: hi + lo is exact
+                        split_bf16((float)hv[j] * gsc, hi, lo);            // 11-bit mantissa: hi + lo is exact
                         ghi[j] = hi;
                         glo[j] = lo;
                     }
@@ -280,7 +283,20 @@ __global__ __launch_bounds__(SPX_BK_THREADS, 2) void spx_bank_bwd_kernel(const S
                     // only read fragments
                     const f16x8 hv = __builtin_bit_cast(f16x8, st.ar[i]);
                     u32x4 ahw, alw;
-                    if (a_fix) {                                  // launch-uniform: the format word kernel 1 wrote
+                    // launch-uniform branches on the format word kernel 1 wrote
+                    if (SPX_ABLOB_FORMAT == 2 && a_fmt == SPX_ABLOB_I16) {
+                        const float asc = __builtin_amdgcn_ldexpf(1.0f / SPX_ABLOB_I16_ONE, (int)((st.exw[i] >> 8) & 0xffu) - 128);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            f32x2 v;
+                            v[0] = (float)(short)(st.ar[i][j] & 0xffffu);            // 15 bits + sign: hi + lo is exact
+                            v[1] = (float)((int)st.ar[i][j] >> 16);
+                            uint32_t hi, lo;
+                            split_bf16x2(v * asc, hi, lo);
+                            ahw[j] = hi;
+                            alw[j] = lo;
+                        }
+                    } else if (SPX_ABLOB_FORMAT == 1 && a_fmt == SPX_ABLOB_E4M12) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             f32x2 v;
@@ -630,9 +646,9 @@ __global__ __launch_bounds__(SPX_RED_ELEMS * SPX_RED_PARTS) void spx_bank_reduce
     if (is_p) {
         a.d_bank[(size_t)p * Cs + col] = 2.0f * (a.bank[(size_t)p * Cs + col] * ct - st);
     } else {
-        // kernel 1's activation blob holds a / ln 2 (fp16) or a / (16 ln 2) (e4m12, the log activation)
+        // kernel 1's activation blob holds a / ln 2 (scaled int16, fp16) or a / (16 ln 2) (e4m12, the log activation)
         const size_t ntl = (size_t)a.B * ((a.HW + SPX_TILE_PX - 1) / SPX_TILE_PX);
-        const uint32_t fmt = *(const uint32_t*)((const char*)a.a_in + ntl * pl.npanels * 4 * pl.npb * 2 * 1024);
+        const uint32_t fmt = *(const uint32_t*)((const char*)a.a_in + spx_ablob_fmt_offset(ntl * pl.npanels * 4 * pl.npb * 2 * 1024));
         a.d_W[(size_t)(col - Cs) * P + p] = (fmt == SPX_ABLOB_E4M12 ? 0.69314718056f * SPX_ABLOB_SCALE : 0.69314718056f) * st;
     }
 }

@@ -369,11 +369,16 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
         const size_t blob0 = (((size_t)panel * ntiles + tile_g) * 4) * NPB * 2 * 1024;   // bytes
         const spx_rsrc gr = make_rsrc(a.g_out ? (const char*)a.g_out + blob0 : nullptr);
         const spx_rsrc ar = make_rsrc(a.a_out ? (const char*)a.a_out + blob0 : nullptr);
-        // inverse scales of the G blob: one float per (lane, block) behind the blobs, [panel][tile][wave][block][lane]
+        // block exponents of the G blob: one word per (lane, block) behind the blobs, [panel][tile][wave][block][lane]
         const size_t blob_total = (size_t)pl.npanels * ntiles * 4 * NPB * 2 * 1024;
         const spx_rsrc gsr = make_rsrc(a.g_out ? (const char*)a.g_out + blob_total + blob0 / 8 : nullptr);
+        // ... the same words behind the activation blob (SPX_ABLOB_FORMAT 2; the parameter kernel reads whichever scratch it is given);
+        // the format word sits behind them
+        const spx_rsrc asr = make_rsrc(a.a_out ? (const char*)a.a_out + blob_total + blob0 / 8 : nullptr);
+        constexpr uint32_t ABLOB_FMT_LOG = SPX_ABLOB_FORMAT == 2 ? SPX_ABLOB_I16 : (SPX_ABLOB_FORMAT == 1 ? SPX_ABLOB_E4M12 : SPX_ABLOB_FP16);
+        constexpr uint32_t ABLOB_FMT_LIN = SPX_ABLOB_FORMAT == 2 ? SPX_ABLOB_I16 : SPX_ABLOB_FP16;
         if (a.a_out && blockIdx.x == 0 && blockIdx.y == 0 && panel == 0 && tid == 0)
-            *(uint32_t*)((char*)a.a_out + blob_total) = (SPX_ABLOB_USE_E4M12 && act_is_log) ? SPX_ABLOB_E4M12 : SPX_ABLOB_FP16;
+            *(uint32_t*)((char*)a.a_out + spx_ablob_fmt_offset(blob_total)) = act_is_log ? ABLOB_FMT_LOG : ABLOB_FMT_LIN;
 
         // ---- phase 1: G, a — a ROLLED loop over the panel's 32-prototype blocks.  The block being processed is
         // always acc[0]; acc is rotated after each block and the packed G fragments enter a register queue, so
@@ -434,29 +439,26 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
         // gout = its packed G fragments (k-steps 0 / 1)
         auto block = [&](int pb, auto slot_c, float (&ddc)[16], float (&ddnext)[16], bf16x8 (&gout)[2], bf16x8 (&glo)[2]) {
             constexpr int SLOT = decltype(slot_c)::value;
-#if SPX_ABLOB_USE_E4M12
-            u16x8 anew[2];     // the activation blob: e4m12 (log) or fp16 bits (linear), see spx_common.h
-#else
-            f16x8 anew[2];     // the activation blob is fp16 (a / ln 2 <= 13.3; 11-bit mantissa): the bank side splits it into bf16 hi + lo
-#endif
+            u32x4 anew[2];     // the activation blob: 16-bit codes of a / ln 2 (scaled int16 / e4m12 / fp16, see spx_common.h), packed in pairs
             // the G blob is fp16 too, scaled per (lane, block) by a power of two so that the lane's largest |G| of the
             // block sits just under 2^15 (a gradient has no fixed range: bf16's exponent with fp16's mantissa); the
             // inverse scale goes to a side array and the bank side rebuilds G = fp16 * scale as an exact bf16 hi + lo pair
             f16x8 gblob[2];
-            float gscale_up = 1.0f;
+            // the two block exponents of this lane travel as ONE word per (lane, block) in the side array behind each blob:
+            // bits 0-7 = exponent of the G scale + 128, bits 8-15 = exponent of the activation scale + 128
+            int ex_g = 0, ex_a = 0;
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     gout[s2][j] = (__bf16)0.0f;
                     glo[s2][j] = (__bf16)0.0f;
-#if SPX_ABLOB_USE_E4M12
-                    anew[s2][j] = 0;
-#else
-                    anew[s2][j] = (_Float16)0.0f;
-#endif
                     gblob[s2][j] = (_Float16)0.0f;
                 }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) anew[s2][j] = 0u;
             if (pb < nv) {
                 if (have_dd && pb + 1 < nv) load_ddist(pb + 1, ddnext);
                 const bool full = pb * 32 + 32 <= np;
@@ -577,8 +579,19 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
                 int ex = __builtin_amdgcn_frexp_expf(gmax);
                 ex = ex < -100 ? -100 : (ex > 100 ? 100 : ex);
                 const float gscale_dn = __builtin_amdgcn_ldexpf(1.0f, 15 - ex);
-                gscale_up = __builtin_amdgcn_ldexpf(1.0f, ex - 15);
-                u32x4 ghw[2], glw[2], gbw[2], anw[2];
+                ex_g = ex;
+                // activation blob, SPX_ABLOB_FORMAT 2: amax = m * 2^ea, m in [0.5, 1): codes round(a * 2^-ea * 32767), |code| <= 32767
+                float ascale_dn = 1.0f;
+                if (SPX_ABLOB_FORMAT == 2) {
+                    float amax = 0.0f;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) amax = fmaxf(amax, __builtin_fabsf(av[i >> 1][i & 1]));
+                    int ea = __builtin_amdgcn_frexp_expf(amax);
+                    ea = ea < -100 ? -100 : (ea > 100 ? 100 : ea);
+                    ascale_dn = __builtin_amdgcn_ldexpf(1.0f, -ea);
+                    ex_a = ea;
+                }
+                u32x4 ghw[2], glw[2], gbw[2];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     // pair i = registers 8 s2 + j, j = 2 (i & 3), 2 (i & 3) + 1 of the tile -> elements j, j + 1 of k-step s2 = i >> 2
@@ -591,21 +604,20 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
                     // G's rounding relative to |x - p|, not to |p| (matters where a pixel sits on a prototype)
                     rs = add_bf16x2(lo, add_bf16x2(hi, rs));
                     gbw[i >> 2][i & 3] = pack_f16x2(gv[i] * gscale_dn);
-#if SPX_ABLOB_USE_E4M12
-                    anew[i >> 2][2 * (i & 3)] = act_is_log ? (unsigned short)ablob_pack(av[i][0]) : __builtin_bit_cast(unsigned short, (_Float16)av[i][0]);
-                    anew[i >> 2][2 * (i & 3) + 1] = act_is_log ? (unsigned short)ablob_pack(av[i][1]) : __builtin_bit_cast(unsigned short, (_Float16)av[i][1]);
-#else
-                    anw[i >> 2][i & 3] = pack_f16x2(av[i]);
-#endif
+                    if (SPX_ABLOB_FORMAT == 2) {
+                        const f32x2 an = av[i] * ascale_dn;                       // in [-1, 1]
+                        anew[i >> 2][i & 3] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pknorm_i16(an[0], an[1]));
+                    } else if (SPX_ABLOB_FORMAT == 1 && act_is_log) {
+                        anew[i >> 2][i & 3] = ablob_pack(av[i][0]) | (ablob_pack(av[i][1]) << 16);
+                    } else {
+                        anew[i >> 2][i & 3] = pack_f16x2(av[i]);
+                    }
                 }
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
                     gout[s2] = __builtin_bit_cast(bf16x8, ghw[s2]);
                     glo[s2] = __builtin_bit_cast(bf16x8, glw[s2]);
                     gblob[s2] = __builtin_bit_cast(f16x8, gbw[s2]);
-#if !SPX_ABLOB_USE_E4M12
-                    anew[s2] = __builtin_bit_cast(f16x8, anw[s2]);
-#endif
                 }
             }
             // fragment dump for kernel 2 (wholly padded blocks are written as zeros: kernel 2 reads them)
@@ -614,9 +626,11 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
                 const uint32_t so = (uint32_t)(((wave * NPB + pb) * 2 + s2) * 1024);
                 const uint32_t vo = spx_blob_slot(r, h, s2) * 16u;
                 if (a.g_out) buf_store_b128_p<SPX_AUX_BLOB_ST>(__builtin_bit_cast(u32x4, gblob[s2]), gr, vo, so);
-                if (a.a_out) buf_store_b128_p<SPX_AUX_BLOB_ST>(__builtin_bit_cast(u32x4, anew[s2]), ar, vo, so);
+                if (a.a_out) buf_store_b128_p<SPX_AUX_BLOB_ST>(anew[s2], ar, vo, so);
             }
-            if (a.g_out) buf_store_f32(gscale_up, gsr, (uint32_t)lane * 4u, (uint32_t)((wave * NPB + pb) * 256));
+            const float exw = __uint_as_float((uint32_t)(ex_g + 128) | ((uint32_t)(ex_a + 128) << 8));
+            if (a.g_out) buf_store_f32(exw, gsr, (uint32_t)lane * 4u, (uint32_t)((wave * NPB + pb) * 256));
+            if (SPX_ABLOB_FORMAT == 2 && a.a_out) buf_store_f32(exw, asr, (uint32_t)lane * 4u, (uint32_t)((wave * NPB + pb) * 256));
         };
         auto put_g = [&](f32x16& dst, const bf16x8 (&g)[2], const bf16x8 (&gl)[2]) {
             const u32x4 g0 = __builtin_bit_cast(u32x4, g[0]), g1 = __builtin_bit_cast(u32x4, g[1]);

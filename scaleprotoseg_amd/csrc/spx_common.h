@@ -182,23 +182,31 @@ __device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
-// Activation blob of the backward (kernel 1 -> kernel 2).  "log" activations a / ln 2 = log2((d+1)/(d+eps)) lie in
-// [0, 13.3) and are small wherever distances are large (a ~ 1/d), so they need RELATIVE precision over ~16 binades and no
-// sign: a 16-bit float with a 4-bit exponent and a 12-bit mantissa (half-ulp 2^-13, four times finer than fp16's 2^-11 -
-// what carried d_W past 1e-3 - and 13 significant bits are an exact bf16 hi + lo pair).  Encoded value v = a / (16 ln 2) in
-// [0, 1): exponents -16 .. -1; anything below 2^-16 is 0.  "linear" activations (-d: signed, unbounded) stay fp16.  The
-// format word sits behind the blobs.
-// Measured on MI355X (same-box A/B, north-star shape, end of round 2): e4m12 costs +0.05 ms in kernel 1 (3 VALU per element
-// against half a packed convert) and nothing measurable in kernel 2 (the decode sits under a launch-uniform branch), i.e. 1.7 %
-// of the step, and takes the d_W peak of a 600-configuration fuzz from 1.11e-3 to 3.9e-4 of max|d_W|; fp16 keeps every
-// configuration of the test suite inside 1e-3 and ~99.3 % of the fuzzed toy configurations (worst seen: 1.7e-3).
-// Default: fp16 (SPX_ABLOB_USE_E4M12 0).
-#ifndef SPX_ABLOB_USE_E4M12
-#define SPX_ABLOB_USE_E4M12 0
+// Activation blob of the backward (kernel 1 -> kernel 2): 16 bits per (pixel, prototype), read by the d_W product only,
+// where what counts is the ABSOLUTE error of each entry (d_W = sum_px dLogits * a).  Three formats (SPX_ABLOB_FORMAT):
+//   0  fp16 of a / ln 2: 11 significant bits PER ELEMENT; d_W peaks at 1.1e-3 .. 1.7e-3 of max|d_W| in a handful of toy
+//      configurations of the fuzz (few pixels, large activations).
+//   1  "log" activations as a 16-bit float with a 4-bit exponent and a 12-bit mantissa (a / (16 ln 2) in [0, 1); 13
+//      significant bits; "linear" activations stay fp16): d_W peak 3.9e-4; +3 VALU per element in kernel 1 (+0.05 ms).
+//   2  (default) int16 codes scaled per (pixel, 32-prototype block) by a power of two - the same device the G blob uses: the
+//      block's largest |a| keeps 15 bits, every entry an absolute error of 2^-16 of that maximum; works for both
+//      activations (signed).  +1 VALU per element in kernel 1 (one v_max3 per pair, one packed multiply, one
+//      v_cvt_pknorm_i16_f32 per pair), one more float per (lane, block) in the side array behind the blob.
+// The format word sits behind the scales (last 16 bytes of the scratch); kernels 2 and 3 read it.
+#ifndef SPX_ABLOB_FORMAT
+#ifdef SPX_ABLOB_USE_E4M12
+#define SPX_ABLOB_FORMAT (SPX_ABLOB_USE_E4M12 ? 1 : 0)
+#else
+#define SPX_ABLOB_FORMAT 2
+#endif
 #endif
 #define SPX_ABLOB_FP16 0u
 #define SPX_ABLOB_E4M12 1u
+#define SPX_ABLOB_I16 2u
 #define SPX_ABLOB_SCALE 16.0f
+#define SPX_ABLOB_I16_ONE 32767.0f
+// bytes from the start of a blob scratch to its format word: [blobs | scales (blobs / 8) | format word]
+__host__ __device__ inline size_t spx_ablob_fmt_offset(size_t blob_total) { return blob_total + blob_total / 8; }
 // 3 VALU per element: integer add (rounding, re-bias and the 1/16 scale - four exponent steps - in one constant),
 // arithmetic shift, clamp
 __device__ __forceinline__ uint32_t ablob_pack(float a_over_ln2) {
