@@ -19,11 +19,13 @@
 // converted into the other and chunk c+2's loads are in flight, one barrier per chunk (the loads then have a whole
 // iteration to land instead of the MFMA phase only, and the conversion VALU of one wave runs under the other's MFMAs).
 #define SPX_BK_THREADS 512
+// Default since the end of round 2 (with the int16 activation blob the commit phase got heavier): the pipelined + staggered
+// variant for the 6-block panels without the k-step split (the north-star bank), 0.783 -> 0.740 ms on one box.
 #ifndef SPX_BANK_PIPE
-#define SPX_BANK_PIPE 0
+#define SPX_BANK_PIPE 1
 #endif
 #ifndef SPX_BANK_STAGGER
-#define SPX_BANK_STAGGER 0
+#define SPX_BANK_STAGGER 1
 #endif
 // LDS row stride of the [channel][px] images: 2 CPX + 16 bytes (144 / 80: conflict-free ds_read_b128)
 __host__ __device__ constexpr int spx_bk_row(int cpx) { return 2 * cpx + 16; }
@@ -653,16 +655,17 @@ __global__ __launch_bounds__(SPX_RED_ELEMS * SPX_RED_PARTS) void spx_bank_reduce
     }
 }
 
-// 32-px chunks with two LDS buffers and two register load sets (CPX = 32: a three-stage pipeline, one barrier per chunk):
-// measured EQUAL to the 64-px single-buffered loop on MI355X (0.865 vs 0.865 ms at the north-star shape, A/B on one box,
-// with and without the second load set).  Timing-only builds (SPX_DIAG_BANK_*) say why: commit alone (conversions + LDS
-// writes, every load an L2 hit) 0.32 ms, commit + MFMA phase 0.73 ms, loads + commit without the MFMA phase 0.63 ms - the
-// kernel is bound by its on-chip work (every wave converts, then reads fragments and runs MFMA chains, two waves per
-// SIMD), not by load latency.  Kept as a switch, off.
+// 32-px chunks with two LDS buffers and two register load sets (CPX = 32: a three-stage pipeline, one barrier per chunk).
+// History of the measurements on MI355X (north-star shape, A/B on one box each): on its own the pipeline equals or loses to the
+// 64-px single-buffered loop (0.865 vs 0.865 ms early in round 2, 0.832 vs 0.742 later: more barriers and shorter MFMA chains per
+// chunk); WITH the wave stagger (partners on a SIMD take the two phases in opposite order) it hides the conversion VALU of the
+// commit phase under the MFMA chains: 0.721-0.730 vs 0.742 with the fp16 activation blob, 0.737-0.742 vs 0.783 with the int16
+// one - so both are on for the 6-block panels that do not use the k-step split.
 template <int NPB, int NCB, bool DO_P, bool DO_W, bool KSPLIT>
 static hipError_t launch_bank_k(const SpxBankBwdArgs& a, int x_dtype, dim3 grid, hipStream_t s) {
     // 32-px double-buffered chunks wherever the k-step split is not in use and two buffers fit the LDS
-    constexpr int CPX = (SPX_BANK_PIPE && !KSPLIT && 2 * spx_bk_buf_bytes<NPB, NCB, DO_P, DO_W, 32>() <= SPX_LDS_LIMIT) ? 32 : 64;
+    // (one-class-block heads only: with 32 more d_W accumulators the pipelined instance spills)
+    constexpr int CPX = (SPX_BANK_PIPE && !KSPLIT && NPB == 6 && NCB == 1 && 2 * spx_bk_buf_bytes<NPB, NCB, DO_P, DO_W, 32>() <= SPX_LDS_LIMIT) ? 32 : 64;
     constexpr size_t lds = (size_t)spx_bk_lds_bytes<NPB, NCB, DO_P, DO_W, CPX>();
     static_assert(lds <= SPX_LDS_LIMIT, "bank kernel LDS");
     if (x_dtype == 1) {
