@@ -660,7 +660,10 @@ __global__ __launch_bounds__(SPX_RED_ELEMS * SPX_RED_PARTS) void spx_bank_reduce
 // 64-px single-buffered loop (0.865 vs 0.865 ms early in round 2, 0.832 vs 0.742 later: more barriers and shorter MFMA chains per
 // chunk); WITH the wave stagger (partners on a SIMD take the two phases in opposite order) it hides the conversion VALU of the
 // commit phase under the MFMA chains: 0.721-0.730 vs 0.742 with the fp16 activation blob, 0.737-0.742 vs 0.783 with the int16
-// one - so both are on for the 6-block panels that do not use the k-step split.
+// one - so both are on for the 6-block panels that do not use the k-step split.  (The PMC fetch count of the pipelined kernel is
+// 1.07 GB higher: the two 64-B halves of every 128-B line of an X row go to two workgroups, i.e. two L2s.  Giving both halves to ONE
+// workgroup - walk units of two consecutive 32-px chunks - was tried: 0.74 -> 0.94 ms, the workgroups running at one time then touch
+// only every other 64 B of a twice as long stretch.  The second fetch of a line is served by the memory-side cache.)
 template <int NPB, int NCB, bool DO_P, bool DO_W, bool KSPLIT>
 static hipError_t launch_bank_k(const SpxBankBwdArgs& a, int x_dtype, dim3 grid, hipStream_t s) {
     // 32-px double-buffered chunks wherever the k-step split is not in use and two buffers fit the LDS
