@@ -98,7 +98,15 @@ __global__ __launch_bounds__(SPX_BK_THREADS, 2) void spx_bank_bwd_kernel(const S
     // one contiguous stretch of every X row (16-32 KB) and of the blobs, instead of 128-B pieces 16 KB apart
     // (DRAM page locality).  Every slab still sums a fixed chunk set in a fixed order: results stay deterministic.
     const long long cstep = a.nslabs;
-    const long long c_begin = split;
+    // Pipelined variant (32-px chunks = 64-B halves of the 128-B lines of an X row): chunks 2j and 2j + 1 go to two workgroups
+    // of the SAME XCD (workgroup w runs on XCD w mod 8), so the second half of a line hits that XCD's L2 instead of being
+    // fetched into another one.  A bijection of [0, nslabs) whenever nslabs is a multiple of 16; the slab index stays `split`.
+    int phase = split;
+    if (CPX == 32 && (a.nslabs & 15) == 0) {
+        const int xcd = split & 7, slot = split >> 3;
+        phase = 2 * ((slot >> 1) * 8 + xcd) + (slot & 1);
+    }
+    const long long c_begin = phase;
     const long long c_end = total;                     // exclusive bound of this workgroup's walk c_begin, c_begin + cstep, ...
     const bool want_w = DO_W && a.d_W != nullptr;
     const bool want_p = DO_P && a.d_bank != nullptr;
