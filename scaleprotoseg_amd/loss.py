@@ -266,7 +266,6 @@ class KLDLoss(nn.Module):
         K, J = table.shape
         B = vals.shape[0]
         lab = labels0.to(dev)
-        ok = ((lab >= 0) & (lab < K)).reshape(-1)
         nseg = B * K
         if planes is None and _kld_kernels_usable(vals, K, J):
             planes = vals.permute(0, 2, 1).contiguous()      # full map given: its gathered entries as [B, J, H*W] planes
@@ -281,6 +280,7 @@ class KLDLoss(nn.Module):
                 "domain (fp32 on the GPU, J <= 16, K*J*J*8 + K*J*8 <= 60 KiB); pass torch_formulation=True to the "
                 "constructor to allow the torch form - there is no silent fallback"
             )
+        ok = ((lab >= 0) & (lab < K)).reshape(-1)
         if not bool(ok.any()):
             return torch.tensor(0.0)
         # (image, class) segment of every pixel; pixels without a class go to a dummy segment that is dropped below
