@@ -35,7 +35,7 @@ extern "C" {
 #endif
 
 #define SPX_MAX_PANELS 64   /* (scale, <=192-prototype block) work units per pixel tile */
-#define SPX_ABI_VERSION 9
+#define SPX_ABI_VERSION 10
 
 /* How the prototype bank is cut into MFMA panels.  Filled by spx_make_plan(). */
 typedef struct spx_plan {
@@ -247,6 +247,31 @@ size_t spx_bank_bwd_workspace_bytes(const spx_plan* plan, int32_t B, int32_t HW)
 int spx_bank_bwd(const spx_plan* plan, const void* x, int32_t x_dtype, int32_t B, int32_t HW,
                  const float* bank, const void* g_in, const void* a_in, const float* d_logits,
                  float* d_bank, float* d_W, void* workspace, void* stream);
+
+/* Fused backward (one persistent kernel, one workgroup per compute unit, for banks of a single panel: one scale of at most
+ * 192 prototypes and 256 channels, a head of at most 32 rows - spx_bwd_fused_supported() says whether a plan qualifies):
+ * dX AND d_bank from one pass over the pixel tiles.  G never leaves the chip (fp16 with one power-of-two scale per tile, in
+ * LDS), X is fetched from HBM once per tile, and the d_bank partial sums stay in registers for the whole launch (one fp32
+ * slab per workgroup, summed in a fixed order: run-to-run identical).  Replaces spx_dist_bwd + the d_bank half of
+ * spx_bank_bwd, i.e. autograd through model_multiscale.py:255-281, :324-330, :243-244.
+ *   packed_bankT16  spx_pack_bankT16(): fp16 fragments of -2 bank^T (spx_packed_bankT16_bytes())
+ *   bank            fp32 [P, Cs] (the p * colsum(G) term of d_bank)
+ *   d_dist / d_logits may be NULL; labels_cls / proto_key / J / d_class_distances: the class-gathered distance gradient of
+ *                   spx_dist_bwd_cls instead of d_dist (labels_cls NULL = off)
+ *   dx              X's dtype, NULL = X frozen;   d_bank [P, Cs] fp32, NULL = bank frozen (workspace then unused)
+ *   a_out           the activation blob for spx_bank_bwd(d_W) (spx_bwd_scratch_bytes()), NULL = head frozen
+ *   workspace       spx_bwd_fused_workspace_bytes() */
+int32_t spx_bwd_fused_supported(const spx_plan* plan);
+size_t spx_packed_bankT16_bytes(const spx_plan* plan);
+int spx_pack_bankT16(const spx_plan* plan, const float* bank, void* packed_bankT16, void* stream);
+size_t spx_bwd_fused_workspace_bytes(const spx_plan* plan, int32_t B, int32_t HW);
+int spx_dist_bwd_fused(const spx_plan* plan, const void* x, int32_t x_dtype, int32_t B, int32_t HW,
+                       const void* packed_bank, const void* packed_bankT16, const float* packed_p2,
+                       const void* packed_headT, const float* bank,
+                       const float* d_dist, const int32_t* labels_cls, const uint32_t* proto_key, int32_t J,
+                       const float* d_class_distances, const float* d_logits,
+                       void* dx, void* a_out, float* d_bank, void* workspace,
+                       float epsilon, int32_t act_fn, void* stream);
 
 /* Class-masked per-prototype argmin over the latent grid (prototype push).
  * Replaces the one_hot / matmul / masked add / two min() reductions of

@@ -15,7 +15,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libspx_hip.so")
 SPX_MAX_PANELS = 64
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 class SpxError(RuntimeError):
@@ -82,6 +82,11 @@ SIGNATURES = {
     "spx_bwd_scratch_bytes": (C.c_size_t, [_PP, _I, _I]),
     "spx_bank_bwd_workspace_bytes": (C.c_size_t, [_PP, _I, _I]),
     "spx_bank_bwd": (C.c_int, [_PP, _V, _I, _I, _I, _V, _V, _V, _V, _V, _V, _V, _V]),
+    "spx_bwd_fused_supported": (_I, [_PP]),
+    "spx_packed_bankT16_bytes": (C.c_size_t, [_PP]),
+    "spx_pack_bankT16": (C.c_int, [_PP, _V, _V, _V]),
+    "spx_bwd_fused_workspace_bytes": (C.c_size_t, [_PP, _I, _I]),
+    "spx_dist_bwd_fused": (C.c_int, [_PP, _V, _I, _I, _I, _V, _V, _V, _V, _V, _V, _V, _V, _I, _V, _V, _V, _V, _V, _V, _F, _I, _V]),
     "spx_push_argmin": (C.c_int, [_V, _V, _V, _I, _I, _I, _I, _I, _F, _V, _V, _V, _V]),
     "spx_argmin_images": (C.c_int, [_V, _I, _I, _V, _V]),
     "spx_kld_segment_max": (C.c_int, [_V, _V, _I, _I, _I, _I, _I, _V, _V, _V]),

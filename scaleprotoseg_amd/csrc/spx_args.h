@@ -98,6 +98,7 @@ __host__ __device__ inline uint32_t spx_blob_slot(int r, int h, int s2) {
 hipError_t spx_launch_fwd(const SpxFwdArgs& a, int x_dtype, hipStream_t s);        // a.labels != NULL: class-gathered variant
 hipError_t spx_launch_bwd(const SpxBwdArgs& a, int x_dtype, hipStream_t s);
 hipError_t spx_launch_bank_bwd(const SpxBankBwdArgs& a, int x_dtype, hipStream_t s);
+hipError_t spx_launch_bank_reduce(const SpxBankBwdArgs& a, hipStream_t s);
 int spx_bank_bwd_nsplit(const spx_plan& pl, int B, int HW);
 size_t spx_bwd_scratch_elems(const spx_plan& pl, int B, int HW);
 size_t spx_bank_bwd_ws_floats(const spx_plan& pl, int nsplit);

@@ -699,6 +699,8 @@ static hipError_t launch_bank_pw(const SpxBankBwdArgs& a, int x_dtype, dim3 grid
 template <int NPB, int NCB>
 static hipError_t launch_bank_x(const SpxBankBwdArgs& a, int x_dtype, dim3 grid, hipStream_t s) {
     if constexpr (NCB < 5) {
+        // d_W alone (the fused backward of spx_bwdf_impl.h has already produced d_bank): its own instance, no G / X staging
+        if (!a.d_bank) return launch_bank_pw<NPB, NCB, false, true>(a, x_dtype, grid, s);
         return launch_bank_pw<NPB, NCB, true, true>(a, x_dtype, grid, s);
     } else {
         hipError_t e = hipSuccess;
@@ -716,6 +718,15 @@ static hipError_t spx_launch_bank_part(const SpxBankBwdArgs& a, int x_dtype, hip
     if (pl.ncb == 2)
         return pl.npb == 2 ? launch_bank_x<2, 2>(a, x_dtype, grid, s) : pl.npb == 4 ? launch_bank_x<4, 2>(a, x_dtype, grid, s) : launch_bank_x<6, 2>(a, x_dtype, grid, s);
     return pl.npb == 2 ? launch_bank_x<2, 5>(a, x_dtype, grid, s) : pl.npb == 4 ? launch_bank_x<4, 5>(a, x_dtype, grid, s) : launch_bank_x<6, 5>(a, x_dtype, grid, s);
+}
+
+// the fixed-order slab sum alone (the fused backward of spx_bwdf_impl.h writes its own slabs: a.nsplit of them)
+hipError_t spx_launch_bank_reduce(const SpxBankBwdArgs& a, hipStream_t s) {
+    const spx_plan& pl = a.plan;
+    const long long n = (long long)pl.npanels * pl.npb * 32 * (pl.channels_per_scale + pl.num_classes);
+    hipLaunchKernelGGL(spx_bank_reduce_kernel, dim3((unsigned)((n + SPX_RED_ELEMS - 1) / SPX_RED_ELEMS)),
+                       dim3(SPX_RED_ELEMS * SPX_RED_PARTS), 0, s, a);
+    return hipGetLastError();
 }
 
 hipError_t spx_launch_bank_bwd(const SpxBankBwdArgs& a0, int x_dtype, hipStream_t s) {

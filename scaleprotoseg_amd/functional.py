@@ -253,6 +253,13 @@ def wide_linear(a: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
     return _WideLinearFn.apply(a, w)
 
 
+# The fused persistent backward (spx_dist_bwd_fused) for the banks it carries; SPX_FUSED_BWD=0 keeps the two-kernel
+# backward everywhere (A/B timing, and the parity tests run both).
+import os as _os
+
+FUSED_BACKWARD = _os.environ.get("SPX_FUSED_BWD", "1") != "0"
+
+
 class _Packs:
     """Device buffers holding the MFMA-ordered operands of one forward."""
 
@@ -267,6 +274,11 @@ class _Packs:
         self.p2 = torch.empty(lib.spx_packed_p2_bytes(pp) // 4, dtype=torch.float32, device=dev)
         s = _lib.stream_ptr()
         _lib.check(lib.spx_pack_bank(pp, _lib.ptr(bank2d), _lib.ptr(self.bank), _lib.ptr(self.bankT), _lib.ptr(self.p2), s))
+        # the fused backward (one panel banks) takes -2 bank^T as fp16 fragments
+        self.bankT16 = None
+        if need_bwd and FUSED_BACKWARD and lib.spx_bwd_fused_supported(pp):
+            self.bankT16 = torch.empty(lib.spx_packed_bankT16_bytes(pp), **u8)
+            _lib.check(lib.spx_pack_bankT16(pp, _lib.ptr(bank2d), _lib.ptr(self.bankT16), s))
         self.head = self.headT = None
         if head is not None:
             self.head = torch.empty(lib.spx_packed_head_bytes(pp), **u8)
@@ -451,11 +463,42 @@ class _ProtoHeadFn(torch.autograd.Function):
                 ce = _lib.SpxCe(labels=_lib.ptr(ce_labels), lse=_lib.ptr(lse), logits=_lib.ptr(ce_logits),
                                 coef=_lib.ptr(coef), d_logits_out=_lib.ptr(d_logits_ce))
         dx = torch.empty_like(x) if need_x else None
-        g_scr = torch.empty(scr, dtype=torch.uint8, device=dev) if need_bank else None
+        g_scr = torch.empty(scr, dtype=torch.uint8, device=dev) if (need_bank and not (
+            packs.bankT16 is not None and ctx.tail2d is None and ce is None and ga is None)) else None
         a_scr = torch.empty(scr, dtype=torch.uint8, device=dev) if need_head else None
         tail2d, d_units, d_tail = ctx.tail2d, None, None
         if tail2d is not None and gl is None and ce is None:
             raise SpxError("backward through the fused group tail without a logits gradient")
+        fused = (packs.bankT16 is not None and tail2d is None and ce is None and ga is None)
+        d_bank = d_head = None
+        if fused:
+            # one persistent kernel: dX and d_bank; the activation blob feeds spx_bank_bwd for d_LastLayer
+            g = ctx.gather
+            if need_bank:
+                d_bank = torch.empty((P, Cs), dtype=torch.float32, device=dev)
+                ws_f = torch.empty(lib.spx_bwd_fused_workspace_bytes(pp, B, HW) // 4, dtype=torch.float32, device=dev)
+            with _timed("spx_dist_bwd"):
+                _lib.check(
+                    lib.spx_dist_bwd_fused(
+                        pp, _lib.ptr(x), xd, B, HW, _lib.ptr(packs.bank), _lib.ptr(packs.bankT16), _lib.ptr(packs.p2),
+                        _lib.ptr(packs.headT) if gl is not None else None, _lib.ptr(bank2d),
+                        _lib.ptr(gd) if g is None else None, _lib.ptr(g.labels) if g is not None else None,
+                        _lib.ptr(g.keys) if g is not None else None, g.width if g is not None else 0,
+                        _lib.ptr(gd) if g is not None else None, _lib.ptr(gl), _lib.ptr(dx), _lib.ptr(a_scr),
+                        _lib.ptr(d_bank), _lib.ptr(ws_f) if need_bank else None, ctx.epsilon, ACT_FN[ctx.act_fn], s,
+                    )
+                )
+            if need_head:
+                ws = torch.empty(lib.spx_bank_bwd_workspace_bytes(pp, B, HW) // 4, dtype=torch.float32, device=dev)
+                d_head = torch.empty((K, P), dtype=torch.float32, device=dev)
+                with _timed("spx_bank_bwd"):
+                    _lib.check(lib.spx_bank_bwd(pp, _lib.ptr(x), xd, B, HW, _lib.ptr(bank2d), None, _lib.ptr(a_scr),
+                                                _lib.ptr(gl), None, _lib.ptr(d_head), _lib.ptr(ws), s))
+            if d_bank is not None:
+                d_bank = d_bank.reshape(ctx.bank_shape)
+            if ctx.needs_input_grad[2] and d_head is None and head2d is not None:
+                d_head = torch.zeros_like(head2d)
+            return dx, d_bank, d_head, None, None, None, None, None, None, None, None
         with _timed("spx_dist_bwd"):
             if tail2d is not None and ce is not None:
                 d_units = torch.empty((B * HW, K), dtype=torch.float32, device=dev)
@@ -512,7 +555,6 @@ class _ProtoHeadFn(torch.autograd.Function):
             if ctx.needs_input_grad[9]:
                 d_tail = _pixel_outer(gl, ctx.gact)   # d W_g [K2, U]: one small product over the pixels
             gl = d_units                              # the parameter kernel's d_logits operand
-        d_bank = d_head = None
         if need_bank or need_head:
             ws = torch.empty(lib.spx_bank_bwd_workspace_bytes(pp, B, HW) // 4, dtype=torch.float32, device=dev)
             d_bank = torch.empty((P, Cs), dtype=torch.float32, device=dev) if need_bank else None
