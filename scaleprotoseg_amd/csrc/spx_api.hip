@@ -78,7 +78,7 @@ hipError_t spx_launch_pack_bankT16(const spx_plan& pl, const float* bank, void* 
 int spx_bwdf_run(const spx_plan& pl, const void* x, int x_dtype, int B, int HW, const void* packed_bank, const void* packed_bankT16,
                  const float* p2, const void* packed_headT, const float* d_dist, const int32_t* labels, const uint32_t* proto_key,
                  int J, const float* d_cls, const float* d_logits, void* dx, void* a_out, float* workspace, float eps, int act_fn,
-                 int grid, hipStream_t s);
+                 int grid, hipStream_t s, unsigned long long* dbg);
 
 extern "C" {
 
@@ -549,7 +549,7 @@ int spx_dist_bwd_fused(const spx_plan* pl, const void* x, int32_t x_dtype, int32
     const bool gather = labels_cls && d_class_distances;
     if (spx_bwdf_run(*pl, x, x_dtype, B, HW, packed_bank, packed_bankT16, packed_p2, packed_headT, d_dist, gather ? labels_cls : nullptr,
                      proto_key, J, gather ? d_class_distances : nullptr, d_logits, dx, a_out, d_bank ? (float*)workspace : nullptr,
-                     epsilon, act_fn, grid, (hipStream_t)stream))
+                     epsilon, act_fn, grid, (hipStream_t)stream, g_dbg))
         return fail("spx_dist_bwd_fused: launch failed: %s", hipGetErrorString(hipGetLastError()));
     if (!d_bank) return 0;
     SpxBankBwdArgs r;

@@ -60,8 +60,9 @@ hipError_t spx_launch_bwdf(const SpxBwdFArgs& a, int x_dtype, int grid, hipStrea
 int spx_bwdf_run(const spx_plan& pl, const void* x, int x_dtype, int B, int HW, const void* packed_bank, const void* packed_bankT16,
                  const float* p2, const void* packed_headT, const float* d_dist, const int32_t* labels, const uint32_t* proto_key,
                  int J, const float* d_cls, const float* d_logits, void* dx, void* a_out, float* workspace, float eps, int act_fn,
-                 int grid, hipStream_t s) {
+                 int grid, hipStream_t s, unsigned long long* dbg) {
     SpxBwdFArgs a;
+    a.dbg = dbg;
     a.plan = pl;
     a.x = x;
     a.packed_bank = (const char*)packed_bank;

@@ -68,6 +68,44 @@ __device__ __forceinline__ void spx_compute_chunk(f32x16 (&acc)[NH], float& x2pa
     }
 }
 
+// The same chunk with EVERY fragment read issued before the first MFMA (28 more registers for NH = 3): for a workgroup that
+// is alone on its CU (the fused persistent backward).  Under register pressure hipcc otherwise emits read -> wait -> MFMA
+// per fragment, i.e. one exposed LDS round trip per MFMA; with two co-resident workgroups the other one fills those gaps
+// (measured there: no gain), a lone workgroup stalls on every one of them.
+template <int NPB, int NH>
+__device__ __forceinline__ void spx_compute_chunk_batched(f32x16 (&acc)[NH], float& x2part, const char* xs, const char* as,
+                                                          int lane, int pg, int pb0) {
+    constexpr int NKS = SPX_KC / 16;
+    const int g = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
+    const char* xb = xs + ((8 * (g >> 1) + q) * SPX_XROW + 32 * pg + 16 * (g & 1) + 4 * pp) * 2;
+    const char* ab = as + lane * 16 + pb0 * (NKS * 1024);
+    s16x4 t[NKS][2];
+    bf16x8 af[NKS][NH];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+        t[ks][0] = lds_tr_read(xb + ks * (16 * SPX_XROW * 2));
+        t[ks][1] = lds_tr_read(xb + ks * (16 * SPX_XROW * 2) + 4 * SPX_XROW * 2);
+#pragma unroll
+        for (int pb = 0; pb < NH; ++pb) af[ks][pb] = *(const bf16x8*)(ab + (pb * NKS + ks) * 1024);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+        const bf16x4 b0 = __builtin_bit_cast(bf16x4, t[ks][0]);
+        const bf16x4 b1 = __builtin_bit_cast(bf16x4, t[ks][1]);
+        const bf16x8 bfrag = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            bf16x2 p2v;
+            p2v[0] = bfrag[2 * e];
+            p2v[1] = bfrag[2 * e + 1];
+            x2part = __builtin_amdgcn_fdot2_f32_bf16(p2v, p2v, x2part, false);
+        }
+#pragma unroll
+        for (int pb = 0; pb < NH; ++pb) acc[pb] = mfma_bf16(af[ks][pb], bfrag, acc[pb]);
+    }
+}
+
 // X stager: the registers of one 32-channel chunk of the tile (XPASS passes of NT/16 rows x 8 px per thread;
 // NT = threads of the workgroup, 256 or 512)
 // VM: 0 = element-wise loads, 1 = 16-B vector loads (every piece wholly inside or outside the image), 2 = vector loads
@@ -201,7 +239,7 @@ struct SpxAStager {
 // indices past the panel's last real chunk load and stage zeros.
 // NT threads per workgroup; each wave accumulates NH of the panel's NPB blocks (NT = 256: NH = NPB, one wave per
 // 32-pixel group; NT = 512: NH = NPB / 2, two waves per pixel group, each with half of the prototype blocks).
-template <int NPB, bool XF32, int VM, int XR, int NT = 256, int NH = NPB>
+template <int NPB, bool XF32, int VM, int XR, int NT = 256, int NH = NPB, bool BATCH = false>
 struct SpxPipeline {
     SpxXStager<XF32, VM, NT> xs[XR];
     SpxAStager<NPB, NT> as_[2];
@@ -224,7 +262,8 @@ struct SpxPipeline {
         dg_issue += s0b - s0;
 #endif
         char* cur = smem + (I % 2) * STAGE;
-        spx_compute_chunk<NPB, NH>(acc, x2part, cur, cur + SPX_STAGE_X_BYTES, lane, wave & 3, (wave >> 2) * NH);
+        if constexpr (BATCH) spx_compute_chunk_batched<NPB, NH>(acc, x2part, cur, cur + SPX_STAGE_X_BYTES, lane, wave & 3, (wave >> 2) * NH);
+        else spx_compute_chunk<NPB, NH>(acc, x2part, cur, cur + SPX_STAGE_X_BYTES, lane, wave & 3, (wave >> 2) * NH);
 #ifdef SPX_DIAG_STAMPS
         __builtin_amdgcn_sched_barrier(0);
         const unsigned long long s1 = __builtin_amdgcn_s_memtime();
