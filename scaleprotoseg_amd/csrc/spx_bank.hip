@@ -53,17 +53,17 @@ int spx_bank_bwd_nsplit(const spx_plan& pl, int B, int HW) {
 size_t spx_bank_bwd_ws_floats(const spx_plan& pl, int nsplit) {
     return (size_t)nsplit * pl.npanels * pl.npb * 32 * spx_bk_wstride(pl);
 }
-// LDS carve: [G hi | G lo | X] (d_bank instances) then [a hi | a lo | dLogits^T hi | dLogits^T lo] (d_W instances)
+// LDS carve: [G16 | X] (d_bank instances: both fp16) then [a hi | a lo | dLogits^T hi | dLogits^T lo] (d_W instances)
 template <int NPB, int NCB, bool DO_P, bool DO_W, int CPX>
 __host__ __device__ constexpr int spx_bk_buf_bytes() {
     constexpr int fb = (CPX / 32) * NPB * 2 * 1024;
-    return (DO_P ? 2 * fb + 256 * spx_bk_row(CPX) : 0) + (DO_W ? 2 * fb + 2 * NCB * 32 * spx_bk_row(CPX) : 0);
+    return (DO_P ? fb + 256 * spx_bk_row(CPX) : 0) + (DO_W ? 2 * fb + 2 * NCB * 32 * spx_bk_row(CPX) : 0);
 }
 template <int NPB, int NCB, bool DO_P, bool DO_W, int CPX>
 __host__ __device__ constexpr int spx_bk_lds_bytes() {
     constexpr int red = (2 * 3 * 2 * 1024 + 2 * 3 * 64) * 4;          // the k-step-split reduction re-uses the staging area
     constexpr int n = (CPX == 32 ? 2 : 1) * spx_bk_buf_bytes<NPB, NCB, DO_P, DO_W, CPX>();
-    return n > red ? n : red;
+    return (n > red ? n : red) + 16;        // + the fp16 exponent of the chunk in each buffer
 }
 
 // DO_P / DO_W: which of the two products this instance carries.  One launch does both for small heads; for the
@@ -114,14 +114,18 @@ __global__ __launch_bounds__(SPX_BK_THREADS, 2) void spx_bank_bwd_kernel(const S
     constexpr int NFRAG = NW1 * NPB * 2;              // fragments per chunk and image: kernel-1 waves x NPB x 2 k-steps
     constexpr int FBYTES = NFRAG * 1024;
 
-    // both blobs are fp16 (G scaled per (lane, block), see kernel 1); each is split into an exact bf16 hi + lo pair
-    // while it is committed to LDS, in the blob's own lane order (the split is elementwise)
+    // The G blob is ONE fp16 plane with a power-of-two scale per kernel-1 tile (exponent in the side array behind the blobs):
+    // it is copied verbatim and enters the d_bank product as it is (fp16 MFMA against X, which is bf16-representable, i.e.
+    // exact in fp16).  The activation blob (int16 / fp16 codes) is split into an exact bf16 hi + lo pair while it is committed
+    // to LDS, in the blob's own lane order (the split is elementwise).
     constexpr int BUF = spx_bk_buf_bytes<NPB, NCB, DO_P, DO_W, CPX>();
-    char *Gs, *Gs2, *Xs, *As, *As2, *Ls, *Ls2;
+    int32_t* const ebuf = (int32_t*)(smem + spx_bk_lds_bytes<NPB, NCB, DO_P, DO_W, CPX>() - 16);     // [2]
+    char *Gs, *Xs, *As, *As2, *Ls, *Ls2;
+    int cur_buf = 0;
     auto use_buffer = [&](int buf) {
-        Gs = smem + buf * BUF;                        // G fragments: bf16 high part of scale * fp16
-        Gs2 = Gs + (DO_P ? FBYTES : 0);               // ... and the bf16 residual (G = hi + lo exactly)
-        Xs = Gs2 + (DO_P ? FBYTES : 0);               // [256][row]  X rows (rows >= Cs are zero)
+        cur_buf = buf;
+        Gs = smem + buf * BUF;                        // G16 fragments
+        Xs = Gs + (DO_P ? FBYTES : 0);                // [256][row]  X rows as fp16 (rows >= Cs are zero)
         As = Xs + (DO_P ? 256 * SPX_BK_ROW : 0);      // a fragments: bf16 high part of the fp16 blob
         As2 = As + FBYTES;                            // ... and the bf16 residual (a = hi + lo exactly)
         Ls = As2 + FBYTES;                            // [NCB*32][row] dLogits^T, bf16 high part
@@ -147,6 +151,10 @@ __global__ __launch_bounds__(SPX_BK_THREADS, 2) void spx_bank_bwd_kernel(const S
     f32x16 accp[PH][2];
     f32x16 accw[NCB];
     float csum[PH];
+    // the d_bank accumulators (and colsum) live in the units of the chunk added last (2^e_acc); a chunk of a tile with another
+    // fp16 exponent first multiplies them by the power-of-two ratio (see chunk_scale)
+    int e_acc = 0;
+    bool have_e = false;
 #pragma unroll
     for (int i = 0; i < PH; ++i) {
         csum[i] = 0.0f;
@@ -170,6 +178,7 @@ __global__ __launch_bounds__(SPX_BK_THREADS, 2) void spx_bank_bwd_kernel(const S
         u32x4 gr[FP], ar[FP], xr[XPT][XF32 ? 2 : 1];
         uint32_t exw[FP];                             // block exponents of each staged piece (one lane of one block): G | activation << 8, +128 each
         float lr_[(CPX * 32 * NCB + SPX_BK_THREADS - 1) / SPX_BK_THREADS];
+        int32_t gexp;                                 // fp16 exponent of the chunk's G16 (kernel-1 tile uniform)
         uint32_t rot_bits;                            // this thread's X piece straddles the image end (see SpxXStager::make_ctx)
         bool ragged;                                  // chunk-uniform: some piece of the chunk does
     };
@@ -216,9 +225,10 @@ __global__ __launch_bounds__(SPX_BK_THREADS, 2) void spx_bank_bwd_kernel(const S
         const size_t blob0 = ((((size_t)q * ntiles + tile_g) * 4 + NW1 * (ci % CPT)) * NPB * 2) * 1024;
         const spx_rsrc grs = make_rsrc_pred(a.g_in ? (const char*)a.g_in + blob0 : nullptr);
         const spx_rsrc ars = make_rsrc_pred(a.a_in ? (const char*)a.a_in + blob0 : nullptr);
-        // the exponent words sit behind either blob (kernel 1 writes them to both): read the G scratch's when it is there
-        const char* const exsrc = (want_p && a.g_in) ? (const char*)a.g_in : ((want_w && a.a_in) ? (const char*)a.a_in : nullptr);
+        // the block exponents of the activation blob sit behind it
+        const char* const exsrc = (want_w && a.a_in) ? (const char*)a.a_in : nullptr;
         const spx_rsrc exs = make_rsrc_pred(exsrc ? exsrc + blob_total + blob0 / 8 : nullptr);
+        st.gexp = (want_p && a.g_in) ? *(const int32_t*)((const char*)a.g_in + spx_gexp_offset(blob_total) + ((size_t)q * ntiles + tile_g) * 4) : 0;
 #pragma unroll
         for (int i = 0; i < FP; ++i) {
             const uint32_t off = (uint32_t)((i * SPX_BK_THREADS + tid) * 16);
@@ -273,20 +283,7 @@ __global__ __launch_bounds__(SPX_BK_THREADS, 2) void spx_bank_bwd_kernel(const S
         for (int i = 0; i < FP; ++i) {
             const int off = (i * SPX_BK_THREADS + tid) * 16;
             if (off < FBYTES) {
-                if (DO_P) {
-                    const f16x8 hv = __builtin_bit_cast(f16x8, st.gr[i]);
-                    const float gsc = __builtin_amdgcn_ldexpf(1.0f, (int)(st.exw[i] & 0xffu) - (128 + 15));   // kernel 1 scaled by 2^(15 - ex)
-                    bf16x8 ghi, glo;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        __bf16 hi, lo;
-                        split_bf16((float)hv[j] * gsc, hi, lo);            // 11-bit mantissa: hi + lo is exact
-                        ghi[j] = hi;
-                        glo[j] = lo;
-                    }
-                    *(u32x4*)(Gs + off) = __builtin_bit_cast(u32x4, ghi);
-                    *(u32x4*)(Gs2 + off) = __builtin_bit_cast(u32x4, glo);
-                }
+                if (DO_P) *(u32x4*)(Gs + off) = st.gr[i];
                 if (DO_W) {
                     // the activation blob is fp16: split every element into bf16 hi + lo HERE, with the whole workgroup
                     // and in the blob's own lane order (the split is elementwise), so the waves of the head product
@@ -334,6 +331,7 @@ __global__ __launch_bounds__(SPX_BK_THREADS, 2) void spx_bank_bwd_kernel(const S
                 }
             }
         }
+        if (DO_P && tid == 0) ebuf[cur_buf] = st.gexp;
         if (RAG && st.ragged) {                              // chunk-uniform: shift the moved-back window into place
 #pragma unroll
             for (int i = 0; i < XPT; ++i) {
@@ -347,13 +345,14 @@ __global__ __launch_bounds__(SPX_BK_THREADS, 2) void spx_bank_bwd_kernel(const S
             if (XF32) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    bf16x2 p;
-                    p[0] = (__bf16)__uint_as_float(st.xr[i][e >> 1][(2 * e) & 3]);
-                    p[1] = (__bf16)__uint_as_float(st.xr[i][e >> 1][(2 * e + 1) & 3]);
-                    v[e] = __builtin_bit_cast(uint32_t, p);
+                    f32x2 p;                        // the forward's bf16 rounding first, then fp16 (exact)
+                    p[0] = (float)(__bf16)__uint_as_float(st.xr[i][e >> 1][(2 * e) & 3]);
+                    p[1] = (float)(__bf16)__uint_as_float(st.xr[i][e >> 1][(2 * e + 1) & 3]);
+                    v[e] = pack_f16x2(p);
                 }
             } else {
-                v = st.xr[i][0];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = pack_f16x2(unpack_bf16x2(st.xr[i][0][e]));
             }
             if (DO_P) *(u32x4*)(Xs + (prow + RPP * i) * SPX_BK_ROW + piece * 16) = v;
         }
@@ -389,6 +388,25 @@ __global__ __launch_bounds__(SPX_BK_THREADS, 2) void spx_bank_bwd_kernel(const S
     const int ts2 = tg & 1, tkh = tg >> 1;
 
     // d_bank part of one pixel k-step: this wave's prototype blocks x channel blocks 2 cp, 2 cp + 1
+    // bring the accumulators to the units of the chunk about to be added (a power-of-two multiply, exact); returns false for
+    // a chunk whose gradients are more than 2^80 below what the accumulators are scaled for: it could not change them
+    auto chunk_scale = [&]() -> bool {
+        const int e_c = __builtin_amdgcn_readfirstlane(ebuf[cur_buf]);
+        if (have_e && e_c == e_acc) return true;
+        if (have_e && e_c - e_acc > 80) return false;
+        const float ratio = have_e ? __builtin_amdgcn_ldexpf(1.0f, e_c - e_acc) : 1.0f;
+#pragma unroll
+        for (int i = 0; i < PH; ++i) {
+            csum[i] *= ratio;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) accp[i][t][e] *= ratio;
+        }
+        e_acc = e_c;
+        have_e = true;
+        return true;
+    };
     auto bank_part = [&](int ks, int cp) {
         const int koff = (ks * 16 + 8 * h) * 2;
         // this lane's pixel rows of the k-step: px = 16 ks + 8 tkh + tqq (+4): kernel-1 wave px >> 5, lane px & 31
@@ -396,40 +414,31 @@ __global__ __launch_bounds__(SPX_BK_THREADS, 2) void spx_bank_bwd_kernel(const S
         const int wsel = pxa >> 5, ra = pxa & 31;
         const int fo0 = spx_blob_slot(ra, tpp & 1, ts2) * 16 + 8 * (tpp >> 1);
         const int fo1 = spx_blob_slot(ra + 4, tpp & 1, ts2) * 16 + 8 * (tpp >> 1);
-        bf16x8 xb[2];
+        f16x8 xb[2];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) xb[t] = *(const bf16x8*)(Xs + ((2 * cp + t) * 32 + r) * SPX_BK_ROW + koff);
+        for (int t = 0; t < 2; ++t) xb[t] = *(const f16x8*)(Xs + ((2 * cp + t) * 32 + r) * SPX_BK_ROW + koff);
 #pragma unroll
         for (int i = 0; i < PH; ++i) {
             const int fb = ((wsel * NPB + pb0 + i) * 2 + ts2) * 1024;
-            const bf16x4 g0 = __builtin_bit_cast(bf16x4, lds_tr_read(Gs + fb + fo0));
-            const bf16x4 g1 = __builtin_bit_cast(bf16x4, lds_tr_read(Gs + fb + fo1));
-            const bf16x4 l0 = __builtin_bit_cast(bf16x4, lds_tr_read(Gs2 + fb + fo0));
-            const bf16x4 l1 = __builtin_bit_cast(bf16x4, lds_tr_read(Gs2 + fb + fo1));
-            const bf16x8 gf = __builtin_shufflevector(g0, g1, 0, 1, 2, 3, 4, 5, 6, 7);
-            const bf16x8 gf2 = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+            const s16x4 g0 = lds_tr_read(Gs + fb + fo0);
+            const s16x4 g1 = lds_tr_read(Gs + fb + fo1);
+            const f16x8 gf = __builtin_bit_cast(f16x8, __builtin_shufflevector(g0, g1, 0, 1, 2, 3, 4, 5, 6, 7));
             if (ksplit || cpair == cs_owner(i)) {   // colsum(G): every lane holds 8 px of its prototype row; lanes r, r+32 cover the k-step
-                // 8 bf16 of the hi and of the lo fragment against ones: four 2-element dot products each (v_dot2_f32_bf16)
-                // instead of 16 unpack + add pairs
-                bf16x2 one2;
-                one2[0] = (__bf16)1.0f;
-                one2[1] = (__bf16)1.0f;
+                f16x2 one2;
+                one2[0] = (_Float16)1.0f;
+                one2[1] = (_Float16)1.0f;
                 float s8 = csum[i];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    bf16x2 ph, pl;
-                    ph[0] = gf[2 * e]; ph[1] = gf[2 * e + 1];
-                    pl[0] = gf2[2 * e]; pl[1] = gf2[2 * e + 1];
-                    s8 = __builtin_amdgcn_fdot2_f32_bf16(ph, one2, s8, false);
-                    s8 = __builtin_amdgcn_fdot2_f32_bf16(pl, one2, s8, false);
+                    f16x2 pr;                   // (element by element: a dword taken from the transposed read's result through a
+                    pr[0] = gf[2 * e];          // vector bit-cast came out as dword 0 / 2 twice - hipcc 7.2)
+                    pr[1] = gf[2 * e + 1];
+                    s8 = __builtin_amdgcn_fdot2(pr, one2, s8, false);
                 }
                 csum[i] = s8;
             }
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                accp[i][t] = mfma_bf16(gf, xb[t], accp[i][t]);
-                accp[i][t] = mfma_bf16(gf2, xb[t], accp[i][t]);
-            }
+            for (int t = 0; t < 2; ++t) accp[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gf, xb[t], accp[i][t], 0, 0, 0);
         }
     };
     // d_W part of one pixel k-step (waves 0 .. NPB-1: prototype block `wave`, every class block)
@@ -461,8 +470,9 @@ __global__ __launch_bounds__(SPX_BK_THREADS, 2) void spx_bank_bwd_kernel(const S
 #ifdef SPX_DIAG_BANK_NOCOMPUTE
         return;                                       // timing-only build: data movement + commit alone
 #endif
+        const bool add_p = DO_P && chunk_scale();
         if constexpr (KSPLIT) {
-            if (DO_P) bank_part(cpair, 0);
+            if (add_p) bank_part(cpair, 0);
             if (DO_W && w_role) {
 #pragma unroll
                 for (int ks = 0; ks < SPX_BK_PX / 16; ++ks) head_part(ks);
@@ -470,7 +480,7 @@ __global__ __launch_bounds__(SPX_BK_THREADS, 2) void spx_bank_bwd_kernel(const S
         } else {
 #pragma unroll
             for (int ks = 0; ks < SPX_BK_PX / 16; ++ks) {
-                if (DO_P) bank_part(ks, cpair);
+                if (add_p) bank_part(ks, cpair);
                 if (DO_W && w_role) head_part(ks);
             }
         }
@@ -568,6 +578,7 @@ __global__ __launch_bounds__(SPX_BK_THREADS, 2) void spx_bank_bwd_kernel(const S
     // ---- write this workgroup's partial slab ----
     const int ws = spx_bk_wstride(pl);
     float* slab = a.workspace + ((size_t)(a.slab_first + split) * pl.npanels + q) * rows * ws;
+    const float sinv_acc = have_e ? __builtin_amdgcn_ldexpf(1.0f, -e_acc) : 0.0f;      // accumulator units -> true values
     if (want_p && (!ksplit || cpair == 0)) {
 #pragma unroll
         for (int i = 0; i < PH; ++i) {
@@ -578,12 +589,12 @@ __global__ __launch_bounds__(SPX_BK_THREADS, 2) void spx_bank_bwd_kernel(const S
                 if (chb < nchb) {
 #pragma unroll
                     for (int reg = 0; reg < 16; ++reg)
-                        slab[(size_t)(pb * 32 + acc_row(reg, h)) * ws + chb * 32 + r] = accp[i][t][reg];
+                        slab[(size_t)(pb * 32 + acc_row(reg, h)) * ws + chb * 32 + r] = accp[i][t][reg] * sinv_acc;
                 }
             }
             if (ksplit ? cpair == 0 : cpair == cs_owner(i)) {
                 const float s = csum[i] + __shfl_xor(csum[i], 32);
-                if (h == 0) slab[(size_t)(pb * 32 + r) * ws + nchb * 32 + NCB * 32] = s;
+                if (h == 0) slab[(size_t)(pb * 32 + r) * ws + nchb * 32 + NCB * 32] = s * sinv_acc;
             }
         }
     }

@@ -56,7 +56,7 @@ __host__ __device__ constexpr int spx_bwd_region1_bytes() {
 }
 template <int NPB, int NCB>
 __host__ __device__ constexpr int spx_bwd_lds_bytes() {
-    return spx_bwd_region0_bytes<NPB>() + spx_bwd_region1_bytes<NPB, NCB>() + 3 * NPB * 32 * 4 + SPX_TILE_PX * 4;   // + |p|^2, class keys, slot plane offsets, rowsum(G)
+    return spx_bwd_region0_bytes<NPB>() + spx_bwd_region1_bytes<NPB, NCB>() + 3 * NPB * 32 * 4 + SPX_TILE_PX * 4 + 32;   // + |p|^2, class keys, slot plane offsets, rowsum(G)
 }
 static_assert(spx_bwd_lds_bytes<6, 1>() <= 80 * 1024, "pixel kernel must fit two workgroups per CU");
 // bf16 elements of one G (or a) scratch: [panel][tile][wave][pb][s2] fragments of 512 elements
@@ -106,6 +106,7 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
     uint32_t* const keys = (uint32_t*)(p2s + NPB * 32);    // GATHER: (class << 16) | slot per padded prototype row
     uint32_t* const koff = keys + NPB * 32;                // GATHER: byte offset of the row's slot plane (slot * HW * 4)
     float* const rss = p2s + 3 * NPB * 32;
+    float* const gmaxs = rss + SPX_TILE_PX;                // [4] wave maxima of |G| (the tile's fp16 scale)
 
     const int px = px0 + 32 * wave + r;
     const bool px_ok = px < a.HW;
@@ -371,7 +372,6 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
         const spx_rsrc ar = make_rsrc(a.a_out ? (const char*)a.a_out + blob0 : nullptr);
         // block exponents of the G blob: one word per (lane, block) behind the blobs, [panel][tile][wave][block][lane]
         const size_t blob_total = (size_t)pl.npanels * ntiles * 4 * NPB * 2 * 1024;
-        const spx_rsrc gsr = make_rsrc(a.g_out ? (const char*)a.g_out + blob_total + blob0 / 8 : nullptr);
         // ... the same words behind the activation blob (SPX_ABLOB_FORMAT 2; the parameter kernel reads whichever scratch it is given);
         // the format word sits behind them
         const spx_rsrc asr = make_rsrc(a.a_out ? (const char*)a.a_out + blob_total + blob0 / 8 : nullptr);
@@ -381,13 +381,11 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
             *(uint32_t*)((char*)a.a_out + spx_ablob_fmt_offset(blob_total)) = act_is_log ? ABLOB_FMT_LOG : ABLOB_FMT_LIN;
 
         // ---- phase 1: G, a — a ROLLED loop over the panel's 32-prototype blocks.  The block being processed is
-        // always acc[0]; acc is rotated after each block and the packed G fragments enter a register queue, so
-        // the body is compiled once with a fixed register footprint (an unrolled version spilled hundreds of
-        // registers).  Exactly NPB iterations, so the queue ends aligned: gpk[i] = block i.
-        // The packed G fragments (8 registers per block) are stored in the accumulator slot that the rotation
-        // frees (16 registers), so after NPB iterations acc[i] holds block i's fragments and no second register
-        // array is needed.
-        float rs = 0.0f;
+        // always acc[0]; acc is rotated after each block and the block's G enters a register queue, so the body is
+        // compiled once with a fixed register footprint (an unrolled version spilled hundreds of registers).  Exactly NPB
+        // iterations, so the queue ends aligned.  G (fp32, 16 registers per block) is stored in the accumulator slot that
+        // the rotation frees, so after NPB iterations acc[i] holds block i's G and no second register array is needed.
+        float rs = 0.0f, gmax = 0.0f;
         float ddA[16], ddB[16];     // dDist of the current / next block (double-buffered: the loop is unrolled by 2)
         auto load_ddist = [&](int pb, float (&dst)[16]) {
             if (GATHER) {
@@ -436,25 +434,16 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
         const bool tile_full = px0 + SPX_TILE_PX <= a.HW;      // wave-uniform: every pixel of the tile is real
 
         // one prototype block, read from accumulator slot SLOT (static); ddc = its dDist, ddnext = prefetch target;
-        // gout = its packed G fragments (k-steps 0 / 1)
-        auto block = [&](int pb, auto slot_c, float (&ddc)[16], float (&ddnext)[16], bf16x8 (&gout)[2], bf16x8 (&glo)[2]) {
+        // gout = its G (fp32, accumulator layout)
+        auto block = [&](int pb, auto slot_c, float (&ddc)[16], float (&ddnext)[16], f32x16& gout) {
             constexpr int SLOT = decltype(slot_c)::value;
             u32x4 anew[2];     // the activation blob: 16-bit codes of a / ln 2 (scaled int16 / e4m12 / fp16, see spx_common.h), packed in pairs
-            // the G blob is fp16 too, scaled per (lane, block) by a power of two so that the lane's largest |G| of the
-            // block sits just under 2^15 (a gradient has no fixed range: bf16's exponent with fp16's mantissa); the
-            // inverse scale goes to a side array and the bank side rebuilds G = fp16 * scale as an exact bf16 hi + lo pair
-            f16x8 gblob[2];
-            // the two block exponents of this lane travel as ONE word per (lane, block) in the side array behind each blob:
-            // bits 0-7 = exponent of the G scale + 128, bits 8-15 = exponent of the activation scale + 128
-            int ex_g = 0, ex_a = 0;
+            // G leaves the block as fp32 (it is packed to fp16 with ONE power-of-two scale per tile once the tile's largest |G|
+            // is known, see below); the activation blob's block exponent travels in one word per (lane, block) behind the blob:
+            // bits 8-15 = exponent of the activation scale + 128 (bits 0-7: unused since the G scale became per tile, 128)
+            int ex_a = 0;
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    gout[s2][j] = (__bf16)0.0f;
-                    glo[s2][j] = (__bf16)0.0f;
-                    gblob[s2][j] = (_Float16)0.0f;
-                }
+            for (int j = 0; j < 16; ++j) gout[j] = 0.0f;
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
@@ -572,14 +561,8 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
                             av[i][e] = valid ? av[i][e] : 0.0f;
                         }
                 }
-                float gmax = 0.0f;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) gmax = fmaxf(gmax, __builtin_fabsf(gv[i >> 1][i & 1]));
-                // gmax = m * 2^ex, m in [0.5, 1): scaled by 2^(15 - ex) the block's values stay below 2^15 (fp16 max 65504)
-                int ex = __builtin_amdgcn_frexp_expf(gmax);
-                ex = ex < -100 ? -100 : (ex > 100 ? 100 : ex);
-                const float gscale_dn = __builtin_amdgcn_ldexpf(1.0f, 15 - ex);
-                ex_g = ex;
                 // activation blob, SPX_ABLOB_FORMAT 2: amax = m * 2^ea, m in [0.5, 1): codes round(a * 2^-ea * 32767), |code| <= 32767
                 float ascale_dn = 1.0f;
                 if (SPX_ABLOB_FORMAT == 2) {
@@ -591,19 +574,10 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
                     ascale_dn = __builtin_amdgcn_ldexpf(1.0f, -ea);
                     ex_a = ea;
                 }
-                u32x4 ghw[2], glw[2], gbw[2];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    // pair i = registers 8 s2 + j, j = 2 (i & 3), 2 (i & 3) + 1 of the tile -> elements j, j + 1 of k-step s2 = i >> 2
-                    // of the B fragment.  G enters dX = 2 (rs x - P^T G) as a bf16 hi + lo pair (~2^-17 relative)
-                    uint32_t hi, lo;
-                    split_bf16x2(gv[i], hi, lo);
-                    ghw[i >> 2][i & 3] = hi;
-                    glw[i >> 2][i & 3] = lo;
-                    // the row sum uses the SAME rounded G as the P^T.G product: dX = 2 sum_p G_p (x - p) then carries
-                    // G's rounding relative to |x - p|, not to |p| (matters where a pixel sits on a prototype)
-                    rs = add_bf16x2(lo, add_bf16x2(hi, rs));
-                    gbw[i >> 2][i & 3] = pack_f16x2(gv[i] * gscale_dn);
+                    gout[2 * i] = gv[i][0];
+                    gout[2 * i + 1] = gv[i][1];
                     if (SPX_ABLOB_FORMAT == 2) {
                         const f32x2 an = av[i] * ascale_dn;                       // in [-1, 1]
                         anew[i >> 2][i & 3] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pknorm_i16(an[0], an[1]));
@@ -613,57 +587,79 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
                         anew[i >> 2][i & 3] = pack_f16x2(av[i]);
                     }
                 }
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
-                    gout[s2] = __builtin_bit_cast(bf16x8, ghw[s2]);
-                    glo[s2] = __builtin_bit_cast(bf16x8, glw[s2]);
-                    gblob[s2] = __builtin_bit_cast(f16x8, gbw[s2]);
-                }
             }
-            // fragment dump for kernel 2 (wholly padded blocks are written as zeros: kernel 2 reads them)
+            // activation fragment dump for kernel 2 (wholly padded blocks are written as zeros: kernel 2 reads them)
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 const uint32_t so = (uint32_t)(((wave * NPB + pb) * 2 + s2) * 1024);
                 const uint32_t vo = spx_blob_slot(r, h, s2) * 16u;
-                if (a.g_out) buf_store_b128_p<SPX_AUX_BLOB_ST>(__builtin_bit_cast(u32x4, gblob[s2]), gr, vo, so);
                 if (a.a_out) buf_store_b128_p<SPX_AUX_BLOB_ST>(anew[s2], ar, vo, so);
             }
-            const float exw = __uint_as_float((uint32_t)(ex_g + 128) | ((uint32_t)(ex_a + 128) << 8));
-            if (a.g_out) buf_store_f32(exw, gsr, (uint32_t)lane * 4u, (uint32_t)((wave * NPB + pb) * 256));
+            const float exw = __uint_as_float(128u | ((uint32_t)(ex_a + 128) << 8));
             if (SPX_ABLOB_FORMAT == 2 && a.a_out) buf_store_f32(exw, asr, (uint32_t)lane * 4u, (uint32_t)((wave * NPB + pb) * 256));
         };
-        auto put_g = [&](f32x16& dst, const bf16x8 (&g)[2], const bf16x8 (&gl)[2]) {
-            const u32x4 g0 = __builtin_bit_cast(u32x4, g[0]), g1 = __builtin_bit_cast(u32x4, g[1]);
-            const u32x4 l0 = __builtin_bit_cast(u32x4, gl[0]), l1 = __builtin_bit_cast(u32x4, gl[1]);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                dst[i] = __uint_as_float(g0[i]);
-                dst[4 + i] = __uint_as_float(g1[i]);
-                dst[8 + i] = __uint_as_float(l0[i]);
-                dst[12 + i] = __uint_as_float(l1[i]);
-            }
-        };
         // ROLLED loop, two blocks per iteration from the static slots 0 and 1 (static dDist buffers too), then one
-        // rotation by two: the next pair moves to the front, the pair's packed G fragments enter the two vacated
-        // slots.  NPB / 2 iterations, so the rotation ends aligned: acc[i] = block i's G fragments.
+        // rotation by two: the next pair moves to the front, the pair's G (fp32) enters the two vacated slots.  NPB / 2
+        // iterations, so the rotation ends aligned: acc[i] = block i's G.
 #pragma unroll 1
         for (int pb = 0; pb < NPB; pb += 2) {
-            bf16x8 gA[2], gB[2], lA[2], lB[2];
-            block(pb, std::integral_constant<int, 0>{}, ddA, ddB, gA, lA);
-            block(pb + 1, std::integral_constant<int, 1>{}, ddB, ddA, gB, lB);
+            f32x16 gA, gB;
+            block(pb, std::integral_constant<int, 0>{}, ddA, ddB, gA);
+            block(pb + 1, std::integral_constant<int, 1>{}, ddB, ddA, gB);
 #pragma unroll
             for (int i = 0; i + 2 < NPB; ++i) acc[i] = acc[i + 2];
-            put_g(acc[NPB - 2], gA, lA);
-            put_g(acc[NPB - 1], gB, lB);
+            acc[NPB - 2] = gA;
+            acc[NPB - 1] = gB;
+        }
+        // ---- ONE power-of-two scale per tile puts G into fp16 (11 significant bits; a gradient has no fixed range): the largest
+        // |G| of the tile sits just under 2^15.  G enters dX = 2 (rs x - P^T G) and crosses to kernel 2 as that single fp16
+        // plane (both products are fp16 MFMAs; the bank and X are bf16-representable, i.e. exact in fp16); the exponent goes
+        // to the side array behind the blobs, one word per (panel, tile).
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) gmax = fmaxf(gmax, __shfl_xor(gmax, m));
+        if (lane == 0) gmaxs[wave] = gmax;
+        __syncthreads();
+        int ex_t = __builtin_amdgcn_frexp_expf(fmaxf(fmaxf(gmaxs[0], gmaxs[1]), fmaxf(gmaxs[2], gmaxs[3])));
+        ex_t = ex_t < -100 ? -100 : (ex_t > 100 ? 100 : ex_t);
+        const int e_t = __builtin_amdgcn_readfirstlane(15 - ex_t);       // |G| 2^e_t < 2^15
+        const float gscale = __builtin_amdgcn_ldexpf(1.0f, e_t), sinv = __builtin_amdgcn_ldexpf(1.0f, -e_t);
+        if (a.g_out && tid == 0) *(int32_t*)((char*)a.g_out + spx_gexp_offset(blob_total) + ((size_t)panel * ntiles + tile_g) * 4) = e_t;
+        {
+            const int lane = spx_opaque((int)threadIdx.x) & 63, r = lane & 31, h = lane >> 5;     // (see spx_opaque)
+            f16x2 one2;
+            one2[0] = (_Float16)1.0f;
+            one2[1] = (_Float16)1.0f;
+#pragma unroll
+            for (int pb = 0; pb < NPB; ++pb) {
+                u32x4 gw[2];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    f32x2 v;
+                    v[0] = acc[pb][2 * k] * gscale;
+                    v[1] = acc[pb][2 * k + 1] * gscale;
+                    const uint32_t w = pack_f16x2(v);
+                    gw[k >> 2][k & 3] = w;
+                    // the row sum uses the SAME rounded G as the P^T.G product: dX = 2 sum_p G_p (x - p) then carries
+                    // G's rounding relative to |x - p|, not to |p| (matters where a pixel sits on a prototype)
+                    rs = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, w), one2, rs, false);
+                }
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[pb][4 * s2 + i] = __uint_as_float(gw[s2][i]);
+                    if (a.g_out)
+                        buf_store_b128_p<SPX_AUX_BLOB_ST>(gw[s2], gr, spx_blob_slot(r, h, s2) * 16u, (uint32_t)(((wave * NPB + pb) * 2 + s2) * 1024));
+                }
+            }
         }
 #ifdef SPX_DIAG_STAMPS
         dg_t2 = __builtin_amdgcn_s_memtime();
 #endif
-        auto g_frag = [&](int pb, int s2) -> bf16x8 {       // s2 = 0, 1: bf16 high parts of k-steps 0, 1; 2, 3: the residuals
+        auto g_frag = [&](int pb, int s2) -> f16x8 {       // the fp16 B fragment of k-step s2
             u32x4 w;
 #pragma unroll
             for (int i = 0; i < 4; ++i) w[i] = __float_as_uint(acc[pb][4 * s2 + i]);
-            return __builtin_bit_cast(bf16x8, w);
+            return __builtin_bit_cast(f16x8, w);
         };
         auto clear_acc = [&]() {
 #pragma unroll
@@ -683,6 +679,9 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
         char* const bt = smem;                               // 2 x BT  (P^T fragments of one channel block)
         char* const tt0 = smem + 2 * BT;                     // fp32 transpose tile 0
         char* const tt1 = hlds;                              // fp32 transpose tile 1 (the head^T image is dead in phase 2)
+        // (phase 2's own copies of the thread / lane index: addresses derived from them are recomputed here instead of being
+        // hoisted to kernel entry and spilled around the panel loop, see spx_opaque)
+        const int tid = spx_opaque((int)threadIdx.x), lane = tid & 63, r = lane & 31, h = lane >> 5;
         const int frow = tid >> 3, fseg = tid & 7;           // finish mapping: channel row, 16-px segment
         const int fpx = px0 + fseg * 16;
         // this thread's segment inside a 32-channel block (resources are re-based per block: offsets < 2 GiB)
@@ -781,9 +780,8 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
                 if (pb < nv) {
 #pragma unroll
                     for (int s2 = 0; s2 < 2; ++s2) {
-                        const bf16x8 pt = *(const bf16x8*)(cur + (pb * 2 + s2) * 1024);
-                        accx = mfma_bf16(pt, g_frag(pb, s2), accx);
-                        accx = mfma_bf16(pt, g_frag(pb, 2 + s2), accx);
+                        const f16x8 pt = *(const f16x8*)(cur + (pb * 2 + s2) * 1024);
+                        accx = __builtin_amdgcn_mfma_f32_32x32x16_f16(pt, g_frag(pb, s2), accx, 0, 0, 0);
                     }
                 }
             }
@@ -799,7 +797,7 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
                 const f32x4 tv = *(const f32x4*)(T + frow * SPX_T_ROW + fseg * 64 + v * 16);
                 const f32x4 rv = *(const f32x4*)(rss + fseg * 16 + v * 4);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) ov[4 * v + e] = pv[4 * v + e] + __builtin_fmaf(rv[e], xv[4 * v + e], tv[e]);   // 2 rs x - 2 P^T.G in one rounding
+                for (int e = 0; e < 4; ++e) ov[4 * v + e] = __builtin_fmaf(sinv, __builtin_fmaf(rv[e], xv[4 * v + e], tv[e]), pv[4 * v + e]);   // (2 rs x - 2 P^T.G16) / scale
             }
             if (use_vec) {
 #pragma unroll

@@ -8,5 +8,5 @@ size_t spx_bwd_scratch_elems(const spx_plan& pl, int B, int HW) {
     // 16-bit elements: the fragment blobs + one float per (lane, block) of inverse scales (= blobs / 8) + 16 bytes for the
     // activation blob's format word
     const size_t blobs = (size_t)pl.npanels * tiles * 4 * pl.npb * 2 * 512;
-    return blobs + blobs / 8 + 8;
+    return blobs + blobs / 8 + 8 + 2 * (size_t)pl.npanels * tiles + 8;       // + the G blob's exponent per (panel, tile)
 }

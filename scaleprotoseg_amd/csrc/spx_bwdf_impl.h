@@ -61,14 +61,6 @@ struct SpxBwdFArgs {
 
 typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
 
-// A value the optimiser must treat as new at this point: lane-constant addresses and predicates derived from it are
-// recomputed where they are used instead of being hoisted out of the tile loop (where hipcc then spills them around the
-// whole loop and reloads them behind a full vmcnt wait: cdna guide, persistent-kernel pitfalls).
-__device__ __forceinline__ int spx_opaque(int v) {
-    asm volatile("" : "+v"(v));
-    return v;
-}
-
 __device__ __forceinline__ f32x16 mfma_f16(f16x8 a, f16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }

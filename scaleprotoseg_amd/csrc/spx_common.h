@@ -148,6 +148,14 @@ __device__ __forceinline__ void spx_shr256(u32x4& lo, u32x4& hi, uint32_t bits) 
     }
 }
 
+// A value the optimiser must treat as new at this point: lane-constant addresses and predicates derived from it are
+// recomputed where they are used instead of being hoisted out of the tile loop (where hipcc then spills them around the
+// whole loop and reloads them behind a full vmcnt wait: cdna guide, persistent-kernel pitfalls).
+__device__ __forceinline__ int spx_opaque(int v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
 // Row of a 32x32 MFMA accumulator held in register `reg` of lane half `h`
 // (cdna guide §3: row = (reg&3) + 8*(reg>>2) + 4*(lane>>5), col = lane&31).
 __device__ __forceinline__ int acc_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
@@ -207,6 +215,8 @@ __device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
 #define SPX_ABLOB_I16_ONE 32767.0f
 // bytes from the start of a blob scratch to its format word: [blobs | scales (blobs / 8) | format word]
 __host__ __device__ inline size_t spx_ablob_fmt_offset(size_t blob_total) { return blob_total + blob_total / 8; }
+// ... and behind the format word (16 bytes) the exponents of the G blob: one int32 per (panel, tile), G16 = G * 2^e
+__host__ __device__ inline size_t spx_gexp_offset(size_t blob_total) { return blob_total + blob_total / 8 + 16; }
 // 3 VALU per element: integer add (rounding, re-bias and the 1/16 scale - four exponent steps - in one constant),
 // arithmetic shift, clamp
 __device__ __forceinline__ uint32_t ablob_pack(float a_over_ln2) {

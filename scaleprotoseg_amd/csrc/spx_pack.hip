@@ -7,7 +7,7 @@
 // 16*s2 + 8*(j>>2) + 4*h + (j&3)  (cdna guide §3 'An accumulator tile as the next MFMA's operand').
 __device__ __forceinline__ int perm_row(int s2, int h, int j) { return 16 * s2 + 8 * (j >> 2) + 4 * h + (j & 3); }
 
-// packed_bank [panel][chunk][pb][ks][lane][8], p2 [panel][npb*32], packed_bankT [panel][pb][s2][chb][lane][8] (holds -2 p)
+// packed_bank [panel][chunk][pb][ks][lane][8], p2 [panel][npb*32], packed_bankT [panel][pb][s2][chb][lane][8] (fp16, holds -2 p)
 __global__ void spx_pack_bank_kernel(const spx_plan pl, const float* __restrict__ bank, __bf16* __restrict__ pb_out,
                                      __bf16* __restrict__ pbT_out, float* __restrict__ p2_out) {
     const int Cs = pl.channels_per_scale;
@@ -43,17 +43,21 @@ __global__ void spx_pack_bank_kernel(const spx_plan pl, const float* __restrict_
         const int pb = t % pl.npb; t /= pl.npb;
         const int panel = t;
         const int ch = chb * 32 + (lane & 31);
-        bf16x8 v;
+        // fp16: the dX product is an fp16 MFMA (G is a single fp16 plane); the bf16-rounded bank value is exact in fp16 within
+        // |p| < 32768 (anything below 2^-24 flushes, larger values saturate)
+        f16x8 v;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int row = pb * 32 + perm_row(s2, lane >> 5, j);
             float f = 0.0f;
-            if (row < pl.panel_np[panel] && ch < Cs) f = bank[(size_t)(pl.panel_p0[panel] + row) * Cs + ch];
+            if (row < pl.panel_np[panel] && ch < Cs) f = (float)(__bf16)bank[(size_t)(pl.panel_p0[panel] + row) * Cs + ch];
             // the transposed image carries -2 p (exact: a power of two): the dX kernel then forms
             // dX = 2 rs x + (-2 P)^T.G with one packed fma per pixel pair instead of multiply, subtract and doubling
-            v[j] = (__bf16)(-2.0f * f);
+            f = -2.0f * f;
+            f = f > 65504.0f ? 65504.0f : (f < -65504.0f ? -65504.0f : f);
+            v[j] = (_Float16)f;
         }
-        *(bf16x8*)(pbT_out + (size_t)gid * 8) = v;
+        *(f16x8*)((_Float16*)pbT_out + (size_t)gid * 8) = v;
     }
     // |p|^2: one wave per padded prototype row (lane-strided channels, fixed-order butterfly sum)
     const int wid = gid >> 6, lane = gid & 63;
