@@ -78,6 +78,103 @@ def cpu_baseline(C, P, S, K, sample_hw, reps=6):
     }
 
 
+def secondary_modes(dev, spx, F_, steps=5, warmup=2):
+    """The driver-visible secondary measurements: each entry is timed in this same process run, after the
+    headline, on synthetic inputs of the named shape: ms per forward or per fwd+bwd step, and the algorithmic GB/s and
+    TFLOP/s that time corresponds to (SURVEY.md 8d byte / flop counts for the mode's own outputs)."""
+    from scaleprotoseg_amd.graphs import capture_step
+
+    out = {}
+
+    def problem(C, P, S, K, H, W, B, seed=1):
+        g = torch.Generator(device=dev).manual_seed(20220227 + seed)
+        Cs = C // S
+        x = torch.sigmoid(torch.randn(B, C, H, W, device=dev, generator=g)).to(torch.bfloat16).requires_grad_(True)
+        per_scale = P // S
+        layout = spx.BankLayout(P, K, S, Cs, tuple((s_ * per_scale, (s_ + 1) * per_scale) for s_ in range(S)))
+        bank = torch.rand(P, Cs, 1, 1, device=dev, generator=g).to(torch.bfloat16).float().requires_grad_(True)
+        ident = torch.zeros(P, K, device=dev)
+        per_cs = max(1, P // K // S)
+        for s_ in range(S):
+            for k in range(K):
+                ident[s_ * per_scale + k * per_cs: s_ * per_scale + (k + 1) * per_cs, k] = 1
+        head = (ident.t() - 0.5 * (1 - ident.t())).contiguous().requires_grad_(True)
+        return g, x, layout, bank, ident, head
+
+    def timed(fn, n=steps, w=warmup):
+        for _ in range(w):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e3
+
+    def entry(ms, M, nbytes_px, flop_px, **extra):
+        return {"ms": round(ms, 4), "Mpix_s": round(M / (ms * 1e-3) / 1e6, 1), "algorithmic_GBs": round(nbytes_px * M / (ms * 1e-3) / 1e9, 1),
+                "algorithmic_TFLOPs": round(flop_px * M / (ms * 1e-3) / 1e12, 1), **extra}
+
+    # (1) logits-only forward at the north-star shape (no fp32 distance map: eval_test.py:96-97 deletes it)
+    C, P, S, K, H, W = WORKLOADS["cityscapes_1024x2048_c256_p190_s1"]
+    M = H * W
+    g, x, layout, bank, ident, head = problem(C, P, S, K, H, W, 1)
+
+    def fwd_logits():
+        with torch.no_grad():
+            spx.proto_head_forward(x, bank, head, layout, want_distances=False)
+    ms = timed(fwd_logits)
+    out["logits_only_forward_1024x2048_p190_s1"] = entry(ms, M, 2 * C + 4 * K, 2 * P * (C // S), mfma_frac=round(2 * P * C * M / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4))
+
+    # (2) / (3) class-gathered distances (SURVEY 8f-1): fwd+bwd with a random gradient on the gathered planes, then with the
+    # KLD loss (HIP kernels) producing it
+    keys, J, table = spx.class_gather_table(layout, ident, dev)
+    patches = torch.randint(0, K, (1, (H + 63) // 64, (W + 63) // 64), device=dev, generator=g, dtype=torch.int32)
+    labels0 = patches.repeat_interleave(64, 1).repeat_interleave(64, 2)[:, :H, :W].reshape(1, H * W).contiguous()
+    gather = spx.ClassGather(labels=labels0, keys=keys, width=J, table=table)
+    g_logits = torch.randn(M, K, device=dev, generator=g) * 1e-3
+    g_cls = torch.randn(1, J, M, device=dev, generator=g) * 1e-3
+    kld_fn = spx.KLDLoss(ident, S, {s_: layout.scale_ranges[s_] for s_ in range(S)})
+    target1 = (labels0 + 1).reshape(1, H, W)
+    fwd_b = 2 * C + 4 * K + 4 * J + 4
+    bwd_b = 4 * K + 2 * C + 2 * C + 4 * J + 4
+
+    def gathered(kld):
+        def f():
+            x.grad = bank.grad = head.grad = None
+            logits, dmap, _ = spx.proto_head_forward(x, bank, head, layout, want_distances=False, class_gather=gather)
+            if kld:
+                loss = kld_fn(spx.ClassDistances(dmap, gather.labels, gather.table, (H, W)), target1)
+                torch.autograd.backward([logits, loss], [g_logits, None])
+            else:
+                torch.autograd.backward([logits, dmap], [g_logits, g_cls])
+        return f
+    out["class_gathered_step_1024x2048_p190_s1"] = entry(timed(gathered(False)), M, fwd_b + bwd_b, 6 * P * (C // S))
+    out["class_gathered_kld_step_1024x2048_p190_s1"] = entry(timed(gathered(True)), M, fwd_b + bwd_b, 6 * P * (C // S))
+    del x, bank, head, g_logits, g_cls, gather, labels0, patches, target1
+    torch.cuda.empty_cache()
+
+    # (4) / (5) the reference's own shapes as HIP-graph replays of one fwd+bwd (eager is host-bound at these sizes)
+    for name, (C, P, S, K, H, W, B) in (("native_129x257_p228_s4_graph_step", (256, 228, 4, 19, 129, 257, 1)),
+                                        ("ade_2x65x65_p1800_s4_graph_step", (256, 1800, 4, 150, 65, 65, 2))):
+        M = B * H * W
+        g, x, layout, bank, ident, head = problem(C, P, S, K, H, W, B, seed=2)
+        gl = torch.randn(M, K, device=dev, generator=g) * 1e-3
+        gd = torch.randn(B, P, H, W, device=dev, generator=g) * 1e-3
+
+        def f():
+            x.grad = bank.grad = head.grad = None
+            logits, dmap, _ = spx.proto_head_forward(x, bank, head, layout, want_distances=True)
+            torch.autograd.backward([logits, dmap], [gl, gd])
+        graph, _ = capture_step(f, warmup=2)
+        ms = timed(graph.replay, n=20, w=3)
+        fb, bb = algorithmic_bytes_per_px(C, P, K)
+        out[name] = entry(ms, M, fb + bb, 6 * P * (C // S))
+        del graph, x, bank, head, gl, gd
+        torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -86,6 +183,8 @@ def main():
     ap.add_argument("--workload", default="cityscapes_1024x2048_c256_p190_s1", choices=sorted(WORKLOADS))
     ap.add_argument("--x-dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-modes", action="store_true", help="skip the secondary `modes` measurements (logits-only forward, class-gathered "
+                    "steps, the reference's own shapes as graph replays)")
     ap.add_argument("--grads", default="logits,dist", help="diagnostic only: which output gradients flow back")
     ap.add_argument("--outputs", default="logits,dist", help="diagnostic only: 'logits' = logits-only forward (no fp32 distance map); "
                     "'logits,class_dist' = class-gathered distances (SURVEY 8f-1: what the fused KLD consumes) instead of the P-wide map")
@@ -336,6 +435,15 @@ def main():
                 "algorithmic_bytes_per_px": fwd_b + bwd_b,
                 "algorithmic_flop_per_px": 6 * nb,
             }
+        default_run = (args.workload == "cityscapes_1024x2048_c256_p190_s1" and args.x_dtype == "bf16" and args.outputs == "logits,dist"
+                       and args.grads == "logits,dist" and not args.freeze and not args.group_tail)
+        if world == 1 and default_run and not args.no_modes:
+            del x, g_logits, g_dist
+            torch.cuda.empty_cache()
+            try:
+                out["modes"] = secondary_modes(dev, spx, F_)
+            except Exception as exc:                     # a secondary measurement must never cost the headline line
+                out["modes"] = {"error": f"{type(exc).__name__}: {exc}"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(C, P, S, K, (128, W) if H >= 128 else (H, W))
         print(json.dumps(out), flush=True)

@@ -49,9 +49,14 @@ def shard_range(n_items: int, rank: int, world_size: int) -> range:
 
 
 class FlatGradBucket:
-    """One flat fp32 buffer holding the gradients of a fixed parameter list."""
+    """One flat fp32 buffer holding the gradients of a fixed parameter list.
 
-    def __init__(self, params: Sequence[torch.nn.Parameter]):
+    ``attach()`` makes every parameter's ``.grad`` a VIEW of the flat buffer: autograd then accumulates straight into the
+    bucket and ``all_reduce`` is the collective alone - no gather / scatter copy kernels around it (2 x n_params launches
+    per step otherwise).  A parameter whose ``.grad`` was re-assigned or set to None since (``zero_grad(set_to_none=True)``,
+    ``p.grad = None``) is copied in and re-attached; use ``zero()`` to clear gradients while keeping the views."""
+
+    def __init__(self, params: Sequence[torch.nn.Parameter], attach: bool = False):
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("FlatGradBucket needs at least one trainable parameter")
@@ -63,9 +68,32 @@ class FlatGradBucket:
         for p, n in zip(self.params, self.sizes):
             self.views.append(self.flat[off : off + n].view_as(p))
             off += n
+        if attach:
+            self.attach()
+
+    def _is_view(self, p: torch.nn.Parameter, v: torch.Tensor) -> bool:
+        g = p.grad
+        return g is not None and g.data_ptr() == v.data_ptr() and g.shape == v.shape and g.dtype == v.dtype and g.is_contiguous()
+
+    def attach(self):
+        """Point every parameter's ``.grad`` at its slice of the flat buffer (existing gradient values are kept)."""
+        for p, v in zip(self.params, self.views):
+            if self._is_view(p, v):
+                continue
+            if p.grad is None:
+                v.zero_()
+            else:
+                v.copy_(p.grad)
+            p.grad = v
+
+    def zero(self):
+        """Clear all gradients in one fill, keeping the views attached."""
+        self.flat.zero_()
 
     def gather(self):
         for p, v in zip(self.params, self.views):
+            if self._is_view(p, v):
+                continue                     # autograd accumulated into the bucket already
             if p.grad is None:
                 v.zero_()
             else:
@@ -73,13 +101,11 @@ class FlatGradBucket:
 
     def scatter(self):
         for p, v in zip(self.params, self.views):
-            if p.grad is None:
-                p.grad = v.clone()
-            else:
-                p.grad.copy_(v)
+            if not self._is_view(p, v):
+                p.grad = v                   # from now on the gradient lives in the bucket
 
     def all_reduce(self, group=None, average: bool = False):
-        """Sum (or mean) the bucket over the ranks with one collective and write the grads back."""
+        """Sum (or mean) the bucket over the ranks with ONE collective; afterwards every ``.grad`` is a view of it."""
         self.gather()
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
             _all_reduce_sum(self.flat, group)
@@ -148,14 +174,21 @@ class DataParallelStep:
     Gradient semantics: the mean over ranks of per-rank gradients, i.e. the gradient of the mean of the per-rank losses
     (equal to the single-process loss over the union batch when each rank's loss is a mean over equally many terms)."""
 
-    def __init__(self, net: torch.nn.Module, optimizer: torch.optim.Optimizer, iter_size: int = 1, group=None):
+    def __init__(self, net: torch.nn.Module, optimizer: torch.optim.Optimizer, iter_size: int = 1, group=None,
+                 grad_hook=None, scheduler=None):
+        """``grad_hook`` (optional, no arguments) runs on every rank AFTER the all-reduce and BEFORE ``optimizer.step()`` - the
+        place of the reference's gradient edits, e.g. ``last_layer_group.weight.grad *= group_class_identity.T`` when
+        ``incorrect_strength == 0`` (module_multiscale_group_train.py:327-328); ``scheduler.step()`` (optional) follows the
+        optimizer step and precedes the simplex re-projection, as upstream (:333-338)."""
         self.net = net
         self.optimizer = optimizer
         self.iter_size = int(iter_size)
         self.group = group
+        self.grad_hook = grad_hook
+        self.scheduler = scheduler
         self.iter_steps = 0
         params = [p for g in optimizer.param_groups for p in g["params"]]
-        self.bucket = FlatGradBucket(params)
+        self.bucket = FlatGradBucket(params, attach=True)
 
     def backward(self, loss: torch.Tensor) -> bool:
         """Accumulate ``loss / iter_size``; at the end of the window all-reduce, step and re-project.  Returns True when
@@ -166,12 +199,16 @@ class DataParallelStep:
             return False
         self.iter_steps = 0
         self.bucket.all_reduce(group=self.group, average=True)
+        if self.grad_hook is not None:
+            self.grad_hook()
         self.optimizer.step()
+        if self.scheduler is not None:
+            self.scheduler.step()
         projections = getattr(self.net, "group_projection", None)
         if projections is not None:
             from .utils import projection_simplex_sort
 
             for gp in projections:
                 gp.weight.data = projection_simplex_sort(gp.weight.data)
-        self.optimizer.zero_grad(set_to_none=True)
+        self.bucket.zero()                   # (not zero_grad(set_to_none=True): the .grad views stay attached)
         return True

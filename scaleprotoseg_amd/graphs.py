@@ -41,14 +41,26 @@ def capture_step(step: Callable[[], Any], warmup: int = 3, stream: Optional[torc
         raise SpxError("capture_step needs an AMD GPU")
     s = stream or torch.cuda.Stream()
     s.wait_stream(torch.cuda.current_stream())
+    # torch reports the stream mismatch through TORCH_WARN_ONCE: once per process unless "warn always" is on, so a second
+    # refused capture (or any earlier eager side-stream step) would otherwise go unseen and the capture would crash.  Both
+    # global switches are restored afterwards, and warnings that are not ours are re-emitted to the caller.
+    prev_always = torch.is_warn_always_enabled()
+    torch.set_warn_always(True)
     torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(True)
-    with warnings.catch_warnings(record=True) as caught:
-        warnings.simplefilter("always")
-        with torch.cuda.stream(s):
-            for _ in range(max(1, int(warmup))):
-                step()
+    try:
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            with torch.cuda.stream(s):
+                for _ in range(max(1, int(warmup))):
+                    step()
+    finally:
+        torch.set_warn_always(prev_always)
     torch.cuda.current_stream().wait_stream(s)
-    if any(_STALE in str(w.message) for w in caught):
+    stale = [w for w in caught if _STALE in str(w.message)]
+    for w in caught:
+        if w not in stale:
+            warnings.warn_explicit(w.message, w.category, w.filename, w.lineno)
+    if stale:
         raise SpxError(
             "capture_step: an autograd graph created on another stream (an eager step's outputs or loss) is still alive; "
             "its AccumulateGrad nodes would pull the legacy default stream into the capture and crash "

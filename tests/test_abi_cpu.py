@@ -73,7 +73,9 @@ def test_make_plan(lib, P, K, S, Cs, npanels, npb, ncb):
     assert lib.spx_packed_p2_bytes(pp) == npanels * npb * 32 * 4
     assert lib.spx_packed_head_bytes(pp) == ncb * npanels * npb * 4096
     blobs = npanels * 2 * (-(-129 * 257 // 128)) * 4 * npb * 2 * 1024
-    assert lib.spx_bwd_scratch_bytes(pp, 2, 129 * 257) == blobs + blobs // 8 + 16  # + the per-(lane, block) scale exponents + the format word
+    tiles = 2 * (-(-129 * 257 // 128))
+    # + the per-(lane, block) exponents of the activation blob + the format word + the G blob's exponent per (panel, tile)
+    assert lib.spx_bwd_scratch_bytes(pp, 2, 129 * 257) == blobs + blobs // 8 + 16 + 4 * npanels * tiles + 16
     assert lib.spx_bank_bwd_workspace_bytes(pp, 1, 65 * 65) > 0
 
 

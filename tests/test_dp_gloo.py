@@ -259,3 +259,57 @@ def test_data_parallel_step_keeps_replicas_bit_identical(tmp_path):
         assert torch.allclose(a, b.detach(), rtol=1e-5, atol=1e-7)
     for gp_w in p0[1:4]:
         assert (gp_w >= 0).all() and torch.allclose(gp_w.sum(1), torch.ones(3), atol=1e-5)    # rows on the simplex
+
+
+def _dp_hook_case(rank, world):
+    """The reference's phase-1 group training masks last_layer_group's gradient before the optimizer step when
+    incorrect_strength == 0 (module_multiscale_group_train.py:327-328) and steps the LR scheduler before the re-projection."""
+    from scaleprotoseg_amd.dp import DataParallelStep
+
+    m = _TinyGroupModel()
+    mask = torch.zeros(3, 9)
+    for k in range(3):
+        mask[k, 3 * k:3 * k + 3] = 1.0                      # group_class_identity.T: own-class connections only
+    opt = torch.optim.Adam(m.parameters(), lr=1e-2)
+    sched = torch.optim.lr_scheduler.StepLR(opt, step_size=1, gamma=0.5)
+
+    def hook():
+        m.last_layer_group.weight.grad *= mask
+
+    stepper = DataParallelStep(m, opt, iter_size=1, grad_hook=hook, scheduler=sched)
+    w0 = m.last_layer_group.weight.detach().clone()
+    g = torch.Generator().manual_seed(70 + rank)
+    for it in range(3):
+        stepper.backward(m.loss(torch.rand(5, 8, generator=g)))
+    grads_are_views = all(p.grad is not None and p.grad.data_ptr() == v.data_ptr() for p, v in zip(stepper.bucket.params, stepper.bucket.views))
+    return m.last_layer_group.weight.detach().clone(), w0, opt.param_groups[0]["lr"], grads_are_views
+
+
+def test_data_parallel_step_grad_hook_and_scheduler(tmp_path):
+    res = _run(_dp_hook_case, tmp_path)
+    (w_a, w0, lr_a, views_a), (w_b, _, lr_b, views_b) = res
+    assert torch.equal(w_a, w_b) and lr_a == lr_b == 1e-2 * 0.5 ** 3
+    mask = torch.zeros(3, 9)
+    for k in range(3):
+        mask[k, 3 * k:3 * k + 3] = 1.0
+    assert torch.equal(w_a[mask == 0], w0[mask == 0])       # the masked ("incorrect") connections never moved
+    assert not torch.equal(w_a[mask == 1], w0[mask == 1])
+    assert views_a and views_b                               # gradients live in the flat bucket: no gather / scatter copies
+
+
+def test_flat_bucket_views_survive_backward_and_zero():
+    from scaleprotoseg_amd.dp import FlatGradBucket
+
+    a = torch.nn.Parameter(torch.rand(4, 3))
+    b = torch.nn.Parameter(torch.rand(5))
+    bucket = FlatGradBucket([a, b], attach=True)
+    ((a ** 2).sum() + (3 * b).sum()).backward()
+    assert a.grad.data_ptr() == bucket.views[0].data_ptr() and b.grad.data_ptr() == bucket.views[1].data_ptr()
+    assert torch.allclose(bucket.flat[:12].view(4, 3), 2 * a.detach()) and torch.allclose(bucket.flat[12:], torch.full((5,), 3.0))
+    bucket.zero()
+    ((a ** 2).sum()).backward()                              # accumulates into the zeroed views
+    assert torch.allclose(a.grad, 2 * a.detach()) and float(b.grad.abs().sum()) == 0.0
+    b.grad = None                                            # a caller that resets a gradient: copied in and re-attached
+    (b.sum()).backward()
+    bucket.all_reduce()
+    assert b.grad.data_ptr() == bucket.views[1].data_ptr() and torch.allclose(b.grad, torch.ones(5))

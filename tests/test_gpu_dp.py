@@ -107,3 +107,21 @@ def test_data_parallel_step_on_the_kernels(tmp_path):
     assert all(torch.equal(a, b) for a, b in zip(p0, p1))                  # replicas bit-identical after 3 steps
     for w in p0[1:-1]:                                                     # projections re-projected onto the simplex
         assert (w >= 0).all() and torch.allclose(w.sum(1), torch.ones(w.shape[0]), atol=1e-5)
+
+
+def test_rccl_one_rank_allreduce():
+    """RCCL itself on the one-GPU box: ONE fresh child process runs the "nccl" backend at world_size 1 (library load, communicator
+    init, one all-reduce of the flat gradient bucket, barrier, destroy).  The 1 -> 8 GPU curve stays unmeasured until a
+    multi-GPU node exists; this at least executes the collective path bench.py and dp.py take under WORLD_SIZE > 1."""
+    import socket
+    import subprocess
+    import sys
+
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "nccl_one_rank.py")
+    r = subprocess.run([sys.executable, script, str(port)], capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0 and "rccl one-rank ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
