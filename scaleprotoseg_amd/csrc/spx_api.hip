@@ -9,6 +9,18 @@
 static thread_local char g_err[512] = "";
 static unsigned long long* g_dbg = nullptr;   // diagnostic builds: see spx_set_debug_buffer
 
+// Block -> tile permutation of the pixel kernels: tile = (block * mul) mod tiles with mul coprime to the tile count, so that
+// the workgroups running at one time are spread over the whole pixel range instead of covering one contiguous stretch of every
+// feature plane (plane strides).  g_tile_mul_req <= 1: identity.
+static int g_tile_mul_req = 1;
+static int gcd_i(int a, int b) { while (b) { const int t = a % b; a = b; b = t; } return a; }
+int spx_tile_mul(int tiles_launch) {
+    if (g_tile_mul_req <= 1 || tiles_launch < 4 * g_tile_mul_req) return 1;
+    int m = g_tile_mul_req;
+    while (gcd_i(m, tiles_launch) != 1) ++m;
+    return m;
+}
+
 static int fail(const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
@@ -85,6 +97,8 @@ extern "C" {
 int spx_version(void) { return SPX_ABI_VERSION; }
 /* Not part of the product ABI (absent from spx_hip.h): profiling hook of SPX_DIAG_STAMPS builds. */
 void spx_diag_set_debug_buffer(void* p) { g_dbg = (unsigned long long*)p; }
+/* Not part of the product ABI either: experiment switch for the block -> tile permutation (1 = identity). */
+void spx_diag_set_tile_mul(int m) { g_tile_mul_req = m; }
 const char* spx_last_error(void) { return g_err; }
 
 int spx_make_plan(int32_t P, int32_t K, int32_t S, int32_t Cs, const int32_t* lo, const int32_t* hi, spx_plan* out) {

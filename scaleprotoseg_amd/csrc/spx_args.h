@@ -13,6 +13,7 @@ struct SpxFwdArgs {
     float* logits;
     int B, HW, vec_ok;
     int tile_first, tiles_launch;   // this launch covers tiles [tile_first, tile_first + tiles_launch) of every image
+    int tile_mul;                   // block -> tile permutation: tile = (block * tile_mul) mod tiles_launch (1 = identity), see spx_tile_mul
     int dist_vec;              // distances 16-B aligned and HW % 4 == 0: 16-B stores of 4 pixels of a row
     // class-gathered distances (spx_dist_fwd_cls): every pixel keeps only the distances to its own class's prototypes
     const int32_t* labels;     // [B, HW] class per pixel (anything outside 0..0xFFFD = none)
@@ -69,6 +70,7 @@ struct SpxBwdArgs {
     uint16_t* a_out;
     int B, HW, vec_ok;
     int tile_first, tiles_launch;   // this launch covers tiles [tile_first, tile_first + tiles_launch) of every image
+    int tile_mul;                   // see SpxFwdArgs
     float eps;
     int act_fn;
     unsigned long long* dbg;
@@ -95,6 +97,7 @@ __host__ __device__ inline uint32_t spx_blob_slot(int r, int h, int s2) {
     return (uint32_t)(((r >> 2) * 8 + (r & 3) + 4 * h + 8 * s2) & 63);
 }
 
+int spx_tile_mul(int tiles_launch);
 hipError_t spx_launch_fwd(const SpxFwdArgs& a, int x_dtype, hipStream_t s);        // a.labels != NULL: class-gathered variant
 hipError_t spx_launch_bwd(const SpxBwdArgs& a, int x_dtype, hipStream_t s);
 hipError_t spx_launch_bank_bwd(const SpxBankBwdArgs& a, int x_dtype, hipStream_t s);

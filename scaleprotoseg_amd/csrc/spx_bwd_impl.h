@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
     const int tile_i = blockIdx.x % tiles_per_img;
 #else
     const int b = blockIdx.x / a.tiles_launch;
-    const int tile_i = a.tile_first + blockIdx.x % a.tiles_launch;
+    const int tile_i = a.tile_first + (int)(((long long)(blockIdx.x % a.tiles_launch) * a.tile_mul) % a.tiles_launch);
 #endif
     const int px0 = tile_i * SPX_TILE_PX;
     const size_t ntiles = (size_t)a.B * tiles_per_img;
@@ -904,5 +904,6 @@ static hipError_t spx_launch_bwd_npb(const SpxBwdArgs& a0, int x_dtype, hipStrea
     a.vec_ok = a.HW < 8 ? 0 : (a.HW % 8 == 0 ? 1 : 2);      // the element-wise path only for images of fewer than 8 pixels
     a.tile_first = 0;
     a.tiles_launch = (a.HW + SPX_TILE_PX - 1) / SPX_TILE_PX;
+    a.tile_mul = spx_tile_mul(a.tiles_launch);
     return spx_launch_bwd_tiles<NPB>(a, x_dtype, s);
 }

@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256 * SPLIT, (NPB == 2 && NCB == 1 ? 3 : SPX_FWD_WA
     const int r = lane & 31, h = lane >> 5;
     const int tiles_per_img = (a.HW + SPX_TILE_PX - 1) / SPX_TILE_PX;
     const int b = blockIdx.x / a.tiles_launch;
-    const int tile_i = a.tile_first + blockIdx.x % a.tiles_launch;
+    const int tile_i = a.tile_first + (int)(((long long)(blockIdx.x % a.tiles_launch) * a.tile_mul) % a.tiles_launch);
     const int px0 = tile_i * SPX_TILE_PX;
     const int Cs = pl.channels_per_scale;
     const int C = pl.num_scales * Cs;
@@ -544,5 +544,6 @@ static hipError_t spx_launch_fwd_npb(const SpxFwdArgs& a0, int x_dtype, hipStrea
     a.vec_ok = a.HW < 8 ? 0 : (a.HW % 8 == 0 ? 1 : 2);      // the element-wise path only for images of fewer than 8 pixels
     a.tile_first = 0;
     a.tiles_launch = (a.HW + SPX_TILE_PX - 1) / SPX_TILE_PX;
+    a.tile_mul = spx_tile_mul(a.tiles_launch);
     return spx_launch_fwd_tiles<NPB>(a, x_dtype, s);
 }

@@ -296,6 +296,54 @@ class _Packs:
                 _lib.check(lib.spx_pack_headT_units(pp, _lib.ptr(head), _lib.ptr(self.headT), s))
 
 
+# ---- pack cache: the MFMA-ordered operands depend on the parameters only, so an unchanged bank / head /
+# tail (inference, evaluation, several forwards per optimizer step) reuses them instead of re-running the pack kernels and
+# their five allocations per forward.  Key: (object, ``_version``, ``data_ptr``) of each parameter + the plan + what was packed.
+# ``_version`` follows every in-place edit made THROUGH the parameter (optimizer steps, ``copy_``, ``add_``); a new Parameter
+# object (``prune_prototypes``) or new storage (``weight.data = ...``: the simplex projection) changes the key too.  The one
+# edit none of them sees is an in-place write through ``.data`` (``p.data.copy_(...)``: ``.data`` has its own version counter):
+# the package's own such sites (the push commit, the ``_initialize_weights`` fills) call ``invalidate_pack_cache()``, and so must
+# foreign code that edits a parameter that way.
+import collections as _collections
+import weakref as _weakref
+
+_PACK_CACHE: "_collections.OrderedDict[tuple, tuple]" = _collections.OrderedDict()
+_PACK_CACHE_MAX = 8
+PACK_CACHE_STATS = {"hits": 0, "misses": 0}
+
+
+def invalidate_pack_cache() -> None:
+    """Drop every cached pack (call after editing a parameter in place through ``.data``)."""
+    _PACK_CACHE.clear()
+
+
+def _tensor_key(t: Optional[torch.Tensor]):
+    return None if t is None else (id(t), int(t._version), int(t.data_ptr()), tuple(t.shape), t.dtype)
+
+
+def _cached_packs(plan_key, plan, bank, head, tail, bank2d, head2d, tail2d, need_bwd):
+    if torch.cuda.is_current_stream_capturing():
+        # a captured step is replayed after its parameters have been edited in place (the static-buffer protocol of HIP graphs):
+        # the pack kernels must be part of the graph
+        return _Packs(plan, bank2d, head2d, need_bwd, tail2d)
+    key = (plan_key, _tensor_key(bank), _tensor_key(head), _tensor_key(tail), bool(need_bwd), FUSED_BACKWARD)
+    hit = _PACK_CACHE.get(key)
+    if hit is not None:
+        refs, packs = hit
+        if all((r is None and t is None) or (r is not None and r() is t) for r, t in zip(refs, (bank, head, tail))):
+            _PACK_CACHE.move_to_end(key)
+            PACK_CACHE_STATS["hits"] += 1
+            return packs
+        del _PACK_CACHE[key]
+    PACK_CACHE_STATS["misses"] += 1
+    packs = _Packs(plan, bank2d, head2d, need_bwd, tail2d)
+    refs = tuple(None if t is None else _weakref.ref(t) for t in (bank, head, tail))
+    _PACK_CACHE[key] = (refs, packs)
+    while len(_PACK_CACHE) > _PACK_CACHE_MAX:
+        _PACK_CACHE.popitem(last=False)
+    return packs
+
+
 class _ProtoHeadFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, bank, head, layout, want_dist, want_act, epsilon, act_fn, gather=None, tail=None, ce_labels=None):
@@ -321,7 +369,9 @@ class _ProtoHeadFn(torch.autograd.Function):
                 raise SpxError("the fused group tail needs the dense head and no class gather")
             if tail2d.dim() != 2 or tail2d.shape[1] != K or tail2d.shape[0] > 32:
                 raise SpxError(f"group tail must be [K2 <= 32, {K}], got {tuple(tail2d.shape)}")
-        packs = _Packs(plan, bank2d, head2d, need_bwd, tail2d)
+        plan_key = (layout.num_prototypes, layout.num_classes, layout.num_scales, layout.channels_per_scale,
+                    tuple(tuple(int(v) for v in r_) for r_ in layout.scale_ranges))
+        packs = _cached_packs(plan_key, plan, bank, head, tail, bank2d, head2d, tail2d, need_bwd)
         f32 = dict(dtype=torch.float32, device=x.device)
         act = torch.empty((B * HW, P), **f32) if want_act else None
         logits = torch.empty((B * HW, K), **f32) if head is not None else None

@@ -299,6 +299,9 @@ class PPNetMultiScale(_PrototypeBankMixin, nn.Module):
         """+1 own class / incorrect_strength elsewhere (model_multiscale.py:449-464)."""
         pos = torch.t(self.prototype_class_identity).to(self.last_layer.weight.device)
         self.last_layer.weight.data.copy_(1 * pos + incorrect_strength * (1 - pos))
+        from .functional import invalidate_pack_cache
+
+        invalidate_pack_cache()
 
     def _initialize_weights(self):
         for m in self.add_on_layers.modules():  # :466-476

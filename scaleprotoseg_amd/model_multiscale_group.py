@@ -203,6 +203,9 @@ class PPNetMultiScale(_PrototypeBankMixin, nn.Module):
     def set_last_layer_incorrect_connection(self):
         pos = torch.t(self.group_class_identity).to(self.last_layer_group.weight.device)  # :480-491
         self.last_layer_group.weight.data.copy_(1 * pos + self.incorrect_strength * (1 - pos))
+        from .functional import invalidate_pack_cache
+
+        invalidate_pack_cache()
 
     def _initialize_weights(self, equiv_path=None, equiv_scale_weight: float = 0.25):
         for m in self.add_on_layers.modules():  # :493-519

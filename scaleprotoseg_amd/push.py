@@ -125,6 +125,9 @@ def commit_push(ppnet, patches: Sequence[np.ndarray], root_dir: Optional[os.Path
     shape = tuple(ppnet.prototype_shape)
     update = np.reshape(patches, shape)
     ppnet.prototype_vectors.data.copy_(torch.tensor(update, dtype=torch.float32).to(ppnet.prototype_vectors.device))
+    from .functional import invalidate_pack_cache
+
+    invalidate_pack_cache()                  # (an in-place write through .data is invisible to the parameter's version counter)
     _, unique_index = np.unique(update, axis=0, return_index=True)
     keep = set(int(i) for i in unique_index)
     dup = [i for i in range(ppnet.num_prototypes) if i not in keep]

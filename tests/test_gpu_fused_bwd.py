@@ -144,3 +144,47 @@ def test_fused_backward_is_run_to_run_identical():
     b = _run(conv, bank, Wl, layout, g_logits, g_dist, torch.bfloat16, dev, fused=True)
     for u, v in zip(a, b):
         assert torch.equal(u, v)
+
+
+def test_pack_cache_follows_every_parameter_edit():
+    """The packed operands are reused while the parameters are unchanged and rebuilt after each kind of edit the reference makes
+    (optimizer step, push commit, prune / re-assignment, simplex projection's ``weight.data = ...``)."""
+    from scaleprotoseg_amd import functional as F_
+
+    dev = _dev()
+    shape = (1, 4, 64, 228, 19, 9, 13)
+    B, S, Cs, P, K, H, W = shape
+    conv, bank, Wl, ident, ranges = _problem(*shape, seed=21)
+    layout = _layout(P, K, S, Cs, ranges)
+    x = conv.to(dev)
+    pv = torch.nn.Parameter(bank.to(dev))
+    w = torch.nn.Parameter(Wl.to(dev))
+    F_.invalidate_pack_cache()
+    st = F_.PACK_CACHE_STATS
+
+    def fwd():
+        with torch.no_grad():
+            return F_.proto_head_forward(x, pv, w, layout, want_distances=True)[1].clone()
+
+    h0, m0 = st["hits"], st["misses"]
+    d0 = fwd()
+    d1 = fwd()
+    assert (st["hits"], st["misses"]) == (h0 + 1, m0 + 1) and torch.equal(d0, d1)
+    # an optimizer step (in place through the parameter: its version counter moves)
+    opt = torch.optim.SGD([pv, w], lr=0.1)
+    pv.grad = torch.ones_like(pv)
+    w.grad = torch.zeros_like(w)
+    opt.step()
+    d2 = fwd()
+    assert st["misses"] == m0 + 2 and not torch.equal(d2, d0)
+    ref = O.forward_from_conv_features(conv, pv.detach().cpu(), ranges, S, w.detach().cpu())[1]
+    assert ((d2.cpu() - ref).abs() <= 2e-2 * (1 + ref)).all()          # (the stepped bank is no longer bf16-representable)
+    # new storage (the simplex projection's ``weight.data = ...``)
+    w.data = w.data.clone() * 0.5
+    fwd()
+    assert st["misses"] == m0 + 3
+    # an in-place write through .data is invisible to the version counter: the package's own sites invalidate explicitly
+    pv.data.copy_(bank.to(dev))
+    F_.invalidate_pack_cache()
+    d3 = fwd()
+    assert st["misses"] == m0 + 4 and torch.equal(d3, d0)

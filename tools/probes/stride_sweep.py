@@ -8,6 +8,10 @@ from scaleprotoseg_amd import functional as F_
 from scaleprotoseg_amd.functional import proto_head_forward
 
 dev = torch.device("cuda:0")
+from scaleprotoseg_amd import _lib
+MUL = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+_lib.load().spx_diag_set_tile_mul(MUL)
+print('tile multiplier', MUL)
 C_, P, K = 256, 190, 19
 lay = spx.BankLayout(P, K, 1, C_, ((0, P),))
 bank = torch.rand(P, C_, 1, 1, device=dev).requires_grad_(True)
