@@ -12,11 +12,16 @@ static unsigned long long* g_dbg = nullptr;   // diagnostic builds: see spx_set_
 // Block -> tile permutation of the pixel kernels: tile = (block * mul) mod tiles with mul coprime to the tile count, so that
 // the workgroups running at one time are spread over the whole pixel range instead of covering one contiguous stretch of every
 // feature plane (plane strides).  g_tile_mul_req <= 1: identity.
-static int g_tile_mul_req = 1;
+static int g_tile_mul_req = 0;                 // 0 = automatic (below), 1 = identity, > 1 = that multiplier (experiments)
 static int gcd_i(int a, int b) { while (b) { const int t = a % b; a = b; b = t; } return a; }
-int spx_tile_mul(int tiles_launch) {
-    if (g_tile_mul_req <= 1 || tiles_launch < 4 * g_tile_mul_req) return 1;
+int spx_tile_mul(int tiles_launch, long long plane_bytes) {
+    // Automatic: only where the feature planes are a multiple of 1 MiB apart (power-of-two grids such as 1024 x 2048: plane
+    // stride 4 MiB).  There neighbouring tiles of all channels fall on the same few DRAM banks at the same time and spreading
+    // the co-running tiles 64 KiB apart measured -3.5 % (forward) / -1.6 % (pixel backward); on every other stride tried it
+    // changed nothing or cost up to 15 % (1016 x 2048), so it stays off there (tools/probes/stride_sweep.py).
     int m = g_tile_mul_req;
+    if (m == 0) m = (plane_bytes > 0 && plane_bytes % (1ll << 20) == 0) ? 257 : 1;
+    if (m <= 1 || tiles_launch < 4 * m) return 1;
     while (gcd_i(m, tiles_launch) != 1) ++m;
     return m;
 }

@@ -97,7 +97,7 @@ __host__ __device__ inline uint32_t spx_blob_slot(int r, int h, int s2) {
     return (uint32_t)(((r >> 2) * 8 + (r & 3) + 4 * h + 8 * s2) & 63);
 }
 
-int spx_tile_mul(int tiles_launch);
+int spx_tile_mul(int tiles_launch, long long plane_bytes);
 hipError_t spx_launch_fwd(const SpxFwdArgs& a, int x_dtype, hipStream_t s);        // a.labels != NULL: class-gathered variant
 hipError_t spx_launch_bwd(const SpxBwdArgs& a, int x_dtype, hipStream_t s);
 hipError_t spx_launch_bank_bwd(const SpxBankBwdArgs& a, int x_dtype, hipStream_t s);

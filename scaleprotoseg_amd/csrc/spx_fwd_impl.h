@@ -544,6 +544,6 @@ static hipError_t spx_launch_fwd_npb(const SpxFwdArgs& a0, int x_dtype, hipStrea
     a.vec_ok = a.HW < 8 ? 0 : (a.HW % 8 == 0 ? 1 : 2);      // the element-wise path only for images of fewer than 8 pixels
     a.tile_first = 0;
     a.tiles_launch = (a.HW + SPX_TILE_PX - 1) / SPX_TILE_PX;
-    a.tile_mul = spx_tile_mul(a.tiles_launch);
+    a.tile_mul = spx_tile_mul(a.tiles_launch, (long long)a.HW * (x_dtype == 1 ? 4 : 2));
     return spx_launch_fwd_tiles<NPB>(a, x_dtype, s);
 }

@@ -9,7 +9,7 @@ from scaleprotoseg_amd.functional import proto_head_forward
 
 dev = torch.device("cuda:0")
 from scaleprotoseg_amd import _lib
-MUL = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+MUL = int(sys.argv[1]) if len(sys.argv) > 1 else 0      # 0 = the library's automatic choice, 1 = identity
 _lib.load().spx_diag_set_tile_mul(MUL)
 print('tile multiplier', MUL)
 C_, P, K = 256, 190, 19
