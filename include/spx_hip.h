@@ -35,7 +35,7 @@ extern "C" {
 #endif
 
 #define SPX_MAX_PANELS 64   /* (scale, <=192-prototype block) work units per pixel tile */
-#define SPX_ABI_VERSION 10
+#define SPX_ABI_VERSION 11
 
 /* How the prototype bank is cut into MFMA panels.  Filled by spx_make_plan(). */
 typedef struct spx_plan {
@@ -191,6 +191,21 @@ int spx_ce_bwd(const float* logits, const float* lse, const int32_t* labels, con
  * Deterministic (per-workgroup partials summed in workgroup order).  workspace: spx_pixel_outer_workspace_bytes(). */
 size_t spx_pixel_outer_workspace_bytes(int64_t M, int32_t n1, int32_t n2);
 int spx_pixel_outer(const float* a, const float* b, int64_t M, int32_t n1, int32_t n2, float* out, void* workspace, void* stream);
+
+/* Heads wider than the distance kernels carry (more than 160 rows: scaleproto_coco.gin's 182 classes, the 450 / 546 grouping
+ * units of group_scaleproto_ade.gin / _coco.gin; a grouping tail over more than 32 classes) and the head behind a user-supplied
+ * similarity: the three products of the reference's nn.Linear (segmentation/model/model_multiscale.py:243-244,
+ * model_multiscale_group.py:283-308, and their autograd) as ONE fp32 MFMA kernel family on row-major device tensors,
+ *     C[i][j] = sum_k A(i, k) * B(j, k),   A(i, k) = A[i * a_row_stride + k * a_k_stride]  (B alike),
+ * for i < M, j < N, k < K; per operand one of the two strides must be 1.  y = a . w^T: (a, P, 1), (w, P, 1); d_a = g . w:
+ * (g, N, 1), (w, 1, P); d_w = g^T . a: (g, 1, N), (a, 1, P).  flags: 1 = A elements enter as exp(A) and 2 = B elements as exp(B)
+ * (the grouping tail's exp(units)), 4 = C[i][j] is multiplied by exp(E[i * lde + j]) (its backward d_units).  fp32 operands and
+ * accumulation (v_mfma_f32_32x32x2_f32); long contractions over few output tiles are split into workspace slabs summed in a fixed
+ * order (deterministic).  workspace: spx_rows_gemm_workspace_bytes() (may be 0 -> NULL accepted). */
+size_t spx_rows_gemm_workspace_bytes(int32_t M, int32_t N, int32_t K, int32_t flags);
+int spx_rows_gemm(const float* A, int64_t a_row_stride, int64_t a_k_stride, const float* B, int64_t b_row_stride,
+                  int64_t b_k_stride, float* C, int64_t ldc, int32_t M, int32_t N, int32_t K, int32_t flags, const float* E,
+                  int64_t lde, void* workspace, void* stream);
 
 /* Grouping head with the tail as its own kernel: the unit product runs in the distance kernel, then a small fp32 kernel
  * forms g = exp(units), logits = W_g . g and - when `ce` is given - the cross-entropy statistics of the logits it has just

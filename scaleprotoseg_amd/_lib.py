@@ -15,7 +15,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libspx_hip.so")
 SPX_MAX_PANELS = 64
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 
 class SpxError(RuntimeError):
@@ -103,6 +103,8 @@ SIGNATURES = {
     "spx_dist_bwd_group_ce": (C.c_int, [_PP, _V, _I, _I, _I, _V, _V, _V, _V, _V, _I, _V, _V, _V, _PCE, _V, _V, _V, _V, _F, _I, _V]),
     "spx_pixel_outer_workspace_bytes": (C.c_size_t, [C.c_int64, _I, _I]),
     "spx_pixel_outer": (C.c_int, [_V, _V, C.c_int64, _I, _I, _V, _V, _V]),
+    "spx_rows_gemm_workspace_bytes": (C.c_size_t, [_I, _I, _I, _I]),
+    "spx_rows_gemm": (C.c_int, [_V, C.c_int64, C.c_int64, _V, C.c_int64, C.c_int64, _V, C.c_int64, _I, _I, _I, _I, _V, C.c_int64, _V, _V]),
     "spx_ce_partials": (C.c_size_t, [_I, _I]),
     "spx_ce_partials_flat": (C.c_size_t, [C.c_int64]),
     "spx_dist_fwd_ce": (C.c_int, [_PP, _V, _I, _I, _I, _V, _V, _V, _V, _V, _I, _V, _V, _V, _V, _PCE, _F, _I, _V]),

@@ -489,6 +489,25 @@ int spx_pixel_outer(const float* a, const float* b, int64_t M, int32_t n1, int32
     return hip_status(spx_launch_pixel_outer(a, b, M, n1, n2, out, (float*)workspace, (hipStream_t)stream), "spx_pixel_outer");
 }
 
+size_t spx_rows_gemm_workspace_bytes(int32_t M, int32_t N, int32_t K, int32_t flags) {
+    if (M < 1 || N < 1 || K < 1) return 0;
+    return spx_gemm_workspace(M, N, K, flags);
+}
+int spx_rows_gemm(const float* A, int64_t ras, int64_t kas, const float* B, int64_t rbs, int64_t kbs, float* C, int64_t ldc,
+                  int32_t M, int32_t N, int32_t K, int32_t flags, const float* E, int64_t lde, void* workspace, void* stream) {
+    if (!A || !B || !C) return fail("spx_rows_gemm: NULL operand");
+    if (M < 1 || N < 1 || K < 1) return fail("spx_rows_gemm: bad sizes (M=%d N=%d K=%d)", M, N, K);
+    if ((ras != 1 && kas != 1) || (rbs != 1 && kbs != 1) || ras < 1 || kas < 1 || rbs < 1 || kbs < 1)
+        return fail("spx_rows_gemm: each operand needs one unit stride (A: %lld, %lld; B: %lld, %lld)", (long long)ras, (long long)kas,
+                    (long long)rbs, (long long)kbs);
+    if (ldc < N) return fail("spx_rows_gemm: ldc (%lld) < N (%d)", (long long)ldc, N);
+    if (flags & ~7) return fail("spx_rows_gemm: unknown flags 0x%x", flags);
+    if ((flags & 4) && (!E || lde < N)) return fail("spx_rows_gemm: flag 4 needs E with lde >= N");
+    if (spx_gemm_workspace(M, N, K, flags) && !workspace) return fail("spx_rows_gemm: workspace needed (spx_rows_gemm_workspace_bytes)");
+    return hip_status(spx_launch_gemm(A, ras, kas, B, rbs, kbs, C, ldc, M, N, K, flags, E, lde, (float*)workspace, (hipStream_t)stream),
+                      "spx_rows_gemm");
+}
+
 int spx_ce_fwd(const float* logits, const int32_t* labels, int64_t M, int32_t K, float* lse, int32_t* pred, float* partials,
                void* stream) {
     if (!logits || !labels || !lse || !partials) return fail("spx_ce_fwd: NULL buffer");

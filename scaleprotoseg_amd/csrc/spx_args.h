@@ -119,6 +119,10 @@ hipError_t spx_launch_sum_groups(const float* parts, size_t n, int groups, float
 int spx_split_groups(const spx_plan& pl, int B, int HW, int32_t* group_first);
 hipError_t spx_launch_group_tail(const float* parts, int groups, long long M, int U, const float* Wg, int K2, float* gact,
                                  float* logits, const int32_t* labels, float* lse, int32_t* pred, float* partials, hipStream_t s);
+size_t spx_gemm_workspace(int M, int N, int K, int flags);
+hipError_t spx_launch_gemm(const float* A, long long ras, long long kas, const float* B, long long rbs, long long kbs,
+                           float* C, long long ldc, int M, int N, int K, int flags, const float* E, long long lde,
+                           float* ws, hipStream_t s);
 int spx_pixel_outer_blocks(long long M);
 hipError_t spx_launch_pixel_outer(const float* a, const float* b, long long M, int n1, int n2, float* out, float* parts, hipStream_t s);
 hipError_t spx_launch_ce_fwd(const float* logits, const int32_t* labels, long long M, int K, float* lse, int32_t* pred,

@@ -199,26 +199,39 @@ def _check_x(x: torch.Tensor, layout: BankLayout) -> Tuple[int, int]:
     return B, H * W
 
 
-def _pixel_outer(a: torch.Tensor, b: torch.Tensor, chunk: int = 4096) -> torch.Tensor:
+def _rows_gemm(A: torch.Tensor, a_strides, B: torch.Tensor, b_strides, M: int, N: int, K: int, flags: int = 0,
+               E: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """C[i][j] = sum_k A(i, k) B(j, k) on row-major fp32 device tensors through the fp32 MFMA kernels of csrc/spx_gemm.hip
+    (include/spx_hip.h: spx_rows_gemm); ``*_strides`` = (row stride, k stride) in elements."""
+    if not (A.is_cuda and B.is_cuda):
+        raise SpxError("scaleprotoseg_amd runs on an AMD GPU only; there is no CPU fallback")
+    if A.dtype != torch.float32 or B.dtype != torch.float32 or not A.is_contiguous() or not B.is_contiguous():
+        raise SpxError("spx_rows_gemm takes contiguous float32 operands")
+    lib = _lib.load()
+    out = torch.empty((M, N), dtype=torch.float32, device=A.device)
+    nws = lib.spx_rows_gemm_workspace_bytes(M, N, K, flags)
+    ws = torch.empty(nws, dtype=torch.uint8, device=A.device) if nws else None
+    _lib.check(lib.spx_rows_gemm(_lib.ptr(A), a_strides[0], a_strides[1], _lib.ptr(B), b_strides[0], b_strides[1], _lib.ptr(out), N,
+                                 M, N, K, flags, _lib.ptr(E), (int(E.shape[1]) if E is not None else 0), _lib.ptr(ws),
+                                 _lib.stream_ptr()))
+    return out
+
+
+def _pixel_outer(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     """a^T . b for tall-skinny [M, n] operands (M = pixels).  Up to 8192 output elements (d W_g of the grouping tail:
-    19 x 57) in the HIP kernel spx_pixel_outer; larger ones (the heads wider than the fused kernels: 450 x 1800) as a
-    chunked batched library product + one sum (the plain ``a.t() @ b`` is a single-workgroup-shaped GEMM: 2.9 ms for
-    2 Mpx x 19 x 57 on MI355X)."""
+    19 x 57) in the fp32 FMA kernel spx_pixel_outer; larger ones (the heads wider than the fused kernels: 450 x 1800) in the
+    MFMA product kernel with the pixels as the contraction index (split over workgroups, slabs summed in a fixed order)."""
     M, n1, n2 = a.shape[0], a.shape[1], b.shape[1]
-    if a.is_cuda and n1 * n2 <= 8192 and a.dtype == torch.float32 and b.dtype == torch.float32:
+    if not a.is_cuda:
+        raise SpxError("scaleprotoseg_amd runs on an AMD GPU only; there is no CPU fallback")
+    a, b = a.contiguous().float(), b.contiguous().float()
+    if n1 * n2 <= 8192:
         lib = _lib.load()
-        a, b = a.contiguous(), b.contiguous()
         out = torch.empty((n1, n2), dtype=torch.float32, device=a.device)
         ws = torch.empty(lib.spx_pixel_outer_workspace_bytes(M, n1, n2), dtype=torch.uint8, device=a.device)
         _lib.check(lib.spx_pixel_outer(_lib.ptr(a), _lib.ptr(b), M, n1, n2, _lib.ptr(out), _lib.ptr(ws), _lib.stream_ptr()))
         return out
-    n = M // chunk
-    out = torch.zeros((n1, n2), dtype=torch.float32, device=a.device)
-    if n:
-        out = out + torch.bmm(a[: n * chunk].view(n, chunk, -1).transpose(1, 2), b[: n * chunk].view(n, chunk, -1)).sum(0)
-    if M % chunk:
-        out = out + a[n * chunk :].t() @ b[n * chunk :]
-    return out
+    return _rows_gemm(a, (1, n1), b, (1, n2), n1, n2, M)
 
 
 # Limits of the head product fused into the distance kernels (class blocks of 32 rows: 1, 2 or 5 per instance)
@@ -228,23 +241,57 @@ MAX_FUSED_TAIL_CLASSES = 32
 
 class _WideLinearFn(torch.autograd.Function):
     """y = a . w^T for heads wider than the fused kernels carry (more than 160 rows: scaleproto_coco.gin's 182 classes,
-    the dense grouping heads of group_scaleproto_ade.gin / _coco.gin with 450 / 546 rows, or a grouping tail over more
-    than 32 classes).  The [pixel][P] activations come out of the distance kernel once; this product is a PLAIN library
-    GEMM (rocBLAS through torch.mm) - the one case the hardware rules reserve for a library.  Backward: d_a = g . w, and
-    d_w = g^T . a as a chunked tall-skinny product (the plain form is a single-workgroup-shaped GEMM)."""
+    the dense grouping heads of group_scaleproto_ade.gin / _coco.gin with 450 / 546 rows) and for the head behind a
+    user-supplied similarity.  The [pixel][P] activations come out of the distance kernel once; the three products of the
+    layer (y, d_a = g . w, d_w = g^T . a) are the hand-written fp32 MFMA kernels of csrc/spx_gemm.hip - fp32 operands, so
+    these heads carry the reference's fp32 arithmetic (segmentation/model/model_multiscale.py:243-244)."""
 
     @staticmethod
     def forward(ctx, a, w):
+        a, w = a.contiguous().float(), w.contiguous().float()
         ctx.save_for_backward(a, w)
-        return a @ w.t()
+        M, P = a.shape
+        return _rows_gemm(a, (P, 1), w, (P, 1), M, int(w.shape[0]), P)
 
     @staticmethod
     def backward(ctx, g):
         a, w = ctx.saved_tensors
-        g = g.contiguous()
-        da = g @ w if ctx.needs_input_grad[0] else None
-        dw = _pixel_outer(g, a).to(w.dtype) if ctx.needs_input_grad[1] else None
+        g = g.contiguous().float()
+        M, P = a.shape
+        N = int(w.shape[0])
+        da = _rows_gemm(g, (N, 1), w, (1, P), M, P, N) if ctx.needs_input_grad[0] else None
+        dw = _pixel_outer(g, a) if ctx.needs_input_grad[1] else None
         return da, dw
+
+
+class _WideGroupTailFn(torch.autograd.Function):
+    """logits = exp(units) . W_g^T for a grouping tail over more than 32 classes (group_scaleproto_ade.gin: 150,
+    _coco.gin: 182; segmentation/model/model_multiscale_group.py:303-308): the exponential is applied while the operand is
+    staged, the backward's d_units = (g . W_g) * exp(units) in the product's epilogue, d_W_g = g^T . exp(units) with the
+    pixels as the contraction index - no [pixel][units] temporary besides the saved units."""
+
+    @staticmethod
+    def forward(ctx, units, wg):
+        units, wg = units.contiguous().float(), wg.contiguous().float()
+        ctx.save_for_backward(units, wg)
+        M, U = units.shape
+        return _rows_gemm(units, (U, 1), wg, (U, 1), M, int(wg.shape[0]), U, flags=1)
+
+    @staticmethod
+    def backward(ctx, g):
+        units, wg = ctx.saved_tensors
+        g = g.contiguous().float()
+        M, U = units.shape
+        K2 = int(wg.shape[0])
+        du = _rows_gemm(g, (K2, 1), wg, (1, U), M, U, K2, flags=4, E=units) if ctx.needs_input_grad[0] else None
+        dwg = _rows_gemm(g, (1, K2), units, (1, U), K2, U, M, flags=2) if ctx.needs_input_grad[1] else None
+        return du, dwg
+
+
+def wide_group_tail(units: torch.Tensor, wg: torch.Tensor) -> torch.Tensor:
+    if not units.is_cuda:
+        raise SpxError("scaleprotoseg_amd runs on an AMD GPU only; there is no CPU fallback")
+    return _WideGroupTailFn.apply(units, wg)
 
 
 def wide_linear(a: torch.Tensor, w: torch.Tensor) -> torch.Tensor:

@@ -247,9 +247,9 @@ class PPNetMultiScale(_PrototypeBankMixin, nn.Module):
         if not (hasattr(self, "patch_classification") and self.patch_classification):
             raise Exception("Original Prototype Network Implementation")
         self._check_fusable()
-        if callable(self.prototype_activation_function):
-            raise SpxError("callable prototype_activation_function has no fused kernel")
         B, _, H, W = conv_features.shape
+        if callable(self.prototype_activation_function):
+            return self._forward_callable_similarity(conv_features, return_activations, return_distances, target_labels, ce_target)
         want_dist = return_distances or not return_activations
         wide = self.num_classes > MAX_FUSED_HEAD_ROWS          # e.g. scaleproto_coco.gin: 182 classes
         layout = self._layout(1 if wide else self.num_classes)
@@ -270,7 +270,7 @@ class PPNetMultiScale(_PrototypeBankMixin, nn.Module):
             ce_labels=None if wide else ce_labels,
         )
         logits, dist, act = out[:3]
-        if wide:      # the kernel hands out the activations once; the 182-row head is a plain library GEMM on them
+        if wide:      # the kernel hands out the activations once; the 182-row head is the fp32 MFMA product kernel (csrc/spx_gemm.hip) on them
             logits = wide_linear(act, self.last_layer.weight)
             if ce_labels is not None:
                 fused_ce = cross_entropy_from_logits(logits, ce_labels)
@@ -282,6 +282,24 @@ class PPNetMultiScale(_PrototypeBankMixin, nn.Module):
         if fused_ce is not None:
             fused_ce.target = ce_target
             logits.spx_ce = fused_ce
+        if return_activations and not return_distances:
+            return logits, act
+        if return_activations and return_distances:
+            return logits, dist, act
+        return logits, dist
+
+    def _forward_callable_similarity(self, conv_features, return_activations, return_distances, target_labels, ce_target):
+        """A user-supplied ``prototype_activation_function`` (model_multiscale.py:329-330: any callable on the [B, P, H, W]
+        distance map): the distance kernel writes the map, the user's function runs on it as ordinary torch code (autograd
+        included), and the head is the fp32 MFMA product kernel on its NHWC view - the reference's op order with its two
+        GEMM-shaped pieces on this package's kernels."""
+        if target_labels is not None or ce_target is not None:
+            raise SpxError("target_labels / ce_target need a built-in similarity ('log' or 'linear')")
+        B, _, H, W = conv_features.shape
+        _, dist, _ = proto_head_forward(conv_features, self.prototype_vectors, None, self._layout(1), want_distances=True,
+                                        epsilon=self.epsilon, activation="log")
+        act = self.prototype_activation_function(dist).permute(0, 2, 3, 1).reshape(B * H * W, -1)
+        logits = wide_linear(act, self.last_layer.weight).reshape(B, H, W, -1)
         if return_activations and not return_distances:
             return logits, act
         if return_activations and return_distances:

@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 
 from .functional import (MAX_FUSED_HEAD_ROWS, MAX_FUSED_TAIL_CLASSES, SpxError, cross_entropy_from_logits,
-                         proto_head_forward, wide_linear)
+                         proto_head_forward, wide_group_tail, wide_linear)
 from .model_multiscale import _PrototypeBankMixin, _build_add_on, _first_add_on_channels
 from .utils import projection_simplex_sort
 
@@ -143,10 +143,22 @@ class PPNetMultiScale(_PrototypeBankMixin, nn.Module):
         if not (hasattr(self, "patch_classification") and self.patch_classification):
             raise Exception("Original Prototype Network Implementation")
         self._check_fusable()
-        if callable(self.prototype_activation_function):
-            raise SpxError("callable prototype_activation_function has no fused kernel")
         B, _, H, W = conv_features.shape
         wd = self._dense_group_matrix()
+        if callable(self.prototype_activation_function):
+            # model_multiscale_group.py:393-394: the user's function on the distance map as ordinary torch code; both head
+            # products on the fp32 MFMA product kernels
+            if ce_target is not None:
+                raise SpxError("ce_target needs a built-in similarity ('log' or 'linear')")
+            _, dist, _ = proto_head_forward(conv_features, self.prototype_vectors, None, self._layout(1), want_distances=True,
+                                            epsilon=self.epsilon, activation="log")
+            act = self.prototype_activation_function(dist).permute(0, 2, 3, 1).reshape(B * H * W, -1)
+            logits = wide_group_tail(wide_linear(act, wd), self.last_layer_group.weight).reshape(B, H, W, -1)
+            if return_activations and not return_distances:
+                return logits, act
+            if return_activations and return_distances:
+                return logits, dist, act
+            return logits, dist
         want_dist = return_distances or not return_activations
         wg = self.last_layer_group.weight
         rows, k2 = int(wd.shape[0]), int(wg.shape[0])
@@ -166,18 +178,18 @@ class PPNetMultiScale(_PrototypeBankMixin, nn.Module):
             if ce_labels is not None:
                 fused_ce = out[3]
         elif rows <= MAX_FUSED_HEAD_ROWS:
-            # up to 160 units but more than 32 classes: the unit product stays in the kernel, the tail is a library GEMM
+            # up to 160 units but more than 32 classes: the unit product stays in the kernel, the tail is the fp32 MFMA product kernel (exp fused into its operand staging)
             units, dist, act = proto_head_forward(
                 conv_features, self.prototype_vectors, wd, self._layout(rows), want_activations=return_activations, **kw,
             )
-            logits = wide_linear(torch.exp(units), wg)
+            logits = wide_group_tail(units, wg)
         else:
             # group_scaleproto_ade.gin (150 classes x 3 groups = 450 units) / _coco.gin (546): the kernel hands out the
-            # [pixel][P] activations once, both products are plain library GEMMs on them
+            # [pixel][P] activations once, both products are the fp32 MFMA product kernels (csrc/spx_gemm.hip) on them
             _, dist, act = proto_head_forward(
                 conv_features, self.prototype_vectors, None, self._layout(1), want_activations=True, **kw,
             )
-            logits = wide_linear(torch.exp(wide_linear(act, wd)), wg)
+            logits = wide_group_tail(wide_linear(act, wd), wg)
         if ce_labels is not None and fused_ce is None:
             fused_ce = cross_entropy_from_logits(logits, ce_labels)       # heads the fused kernels do not carry
         logits = logits.reshape(B, H, W, -1)

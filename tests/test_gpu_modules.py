@@ -498,7 +498,7 @@ def test_push_prototypes_multiscale_end_to_end(tmp_path):
 # ------------------------------------------------------------------------------------------------------------------
 # heads wider than the fused kernels carry (group_scaleproto_ade.gin: 150 classes x 3 groups = 450 units over a
 # 1800-prototype bank in 4 scales; scaleproto_coco.gin: 182 classes): distances / activations from the kernel, the head
-# as library GEMMs on the activations (functional.wide_linear)
+# through the fp32 MFMA product kernels on the activations (functional.wide_linear / wide_group_tail, csrc/spx_gemm.hip)
 # ------------------------------------------------------------------------------------------------------------------
 def test_ade_group_phase_wide_head_forward_backward():
     from scaleprotoseg_amd.model_multiscale_group import PPNetMultiScale as GroupNet
@@ -548,7 +548,7 @@ def test_ade_group_phase_wide_head_forward_backward():
 @pytest.mark.parametrize("K,G", [(182, None), (50, 3)])
 def test_wide_class_heads(K, G):
     """182 classes (scaleproto_coco.gin) on the prototype-phase module; 50 classes x 3 groups = 150 units with a 50-class
-    tail (unit product in the kernel, tail as a library GEMM) on the group-phase module."""
+    tail (unit product in the kernel, tail in the fp32 MFMA product kernel) on the group-phase module."""
     import scaleprotoseg_amd as spx
     from scaleprotoseg_amd.model_multiscale_group import PPNetMultiScale as GroupNet
 
@@ -590,6 +590,44 @@ def test_wide_class_heads(K, G):
     _grad_close(net.prototype_vectors.grad, p0.grad, "dPrototypes")
     head = net.last_layer.weight if G is None else net.last_layer_group.weight
     _grad_close(head.grad, w0.grad, "dHead")
+
+
+def test_user_supplied_similarity_function(golden):
+    """A callable ``prototype_activation_function`` (segmentation/model/model_multiscale.py:329-330): the reference calls it
+    on the [B, P, H, W] distance map and feeds the result to ``last_layer``.  Here: the distance kernel, the user's torch
+    code, the fp32 MFMA product kernel - forward and backward against the same op sequence on the CPU."""
+    dev = _dev()
+    g = golden("proto_ms_small")
+
+    def similarity(d):
+        return 1.0 / (1.0 + d)
+
+    net = _proto_net(g, dev, prototype_activation_function=similarity)
+    conv = torch.from_numpy(g["conv"])
+    S = int(g["num_scales"])
+    P, K = g["class_identity"].shape
+    ranges = {s: tuple(net.scale_num_prototypes[s]) for s in range(S)}
+    c0 = conv.clone().requires_grad_(True)
+    p0 = torch.from_numpy(g["prototype_vectors"]).clone().requires_grad_(True)
+    w0 = torch.from_numpy(g["last_layer_weight"]).clone().requires_grad_(True)
+    rd = O.scale_l2_convolution(c0, p0, ranges, S)
+    ra = similarity(rd).permute(0, 2, 3, 1).reshape(-1, P)
+    rl = torch.nn.functional.linear(ra, w0).reshape(rd.shape[0], rd.shape[2], rd.shape[3], K)
+    gen = torch.Generator().manual_seed(77)
+    g_logits = torch.randn(rl.shape, generator=gen) * 1e-3
+    g_dist = torch.randn(rd.shape, generator=gen) * 1e-3
+    ((rl * g_logits).sum() + (rd * g_dist).sum()).backward()
+
+    x = conv.to(dev).requires_grad_(True)
+    logits, dist, act = net.forward_from_conv_features(x, return_activations=True, return_distances=True)
+    _close_fwd(dist, rd.detach(), "distances")
+    _close_fwd(act, ra.detach(), "activations")
+    _close_fwd(logits, rl.detach(), "logits")
+    ((logits * g_logits.to(dev)).sum() + (dist * g_dist.to(dev)).sum()).backward()
+    _grad_close(x.grad, c0.grad, "dX")
+    _grad_close(net.prototype_vectors.grad, p0.grad, "dPrototypes")
+    _grad_close(net.last_layer.weight.grad, w0.grad, "dLastLayer")
+    assert len(net.forward_from_conv_features(x.detach())) == 2
 
 
 # ------------------------------------------------------------------------------------------------------------------
