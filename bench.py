@@ -151,7 +151,22 @@ def secondary_modes(dev, spx, F_, steps=5, warmup=2):
         return f
     out["class_gathered_step_1024x2048_p190_s1"] = entry(timed(gathered(False)), M, fwd_b + bwd_b, 6 * P * (C // S))
     out["class_gathered_kld_step_1024x2048_p190_s1"] = entry(timed(gathered(True)), M, fwd_b + bwd_b, 6 * P * (C // S))
-    del x, bank, head, g_logits, g_cls, gather, labels0, patches, target1
+    # (3b) the prototype push's per-image reduction (push_multiscale_optimization.py:68-91) on one 1024x2048 latent grid:
+    # fused into the distance kernel (spx_dist_push_min: features in, [P] minima out, no map) against the two-step form
+    # (spx_dist_fwd writes the fp32 map, spx_push_argmin reduces it)
+    push_target = target1.to(torch.int64)
+
+    def push_fused():
+        with torch.no_grad():
+            F_.push_min_from_features(x, bank, layout, push_target, ident, void_class=0, keys=keys)
+
+    def push_two_step():
+        with torch.no_grad():
+            _, dmap, _ = spx.proto_head_forward(x, bank, None, layout, want_distances=True)
+            spx.push_masked_argmin(dmap, push_target, ident, void_class=0)
+    out["push_min_fused_1024x2048_p190_s1"] = entry(timed(push_fused), M, 2 * C + 4, 2 * P * (C // S))
+    out["push_min_two_step_1024x2048_p190_s1"] = entry(timed(push_two_step), M, 2 * C + 4, 2 * P * (C // S))
+    del x, bank, head, g_logits, g_cls, gather, labels0, patches, target1, push_target
     torch.cuda.empty_cache()
 
     # (4) / (5) the reference's own shapes as HIP-graph replays of one fwd+bwd (eager is host-bound at these sizes)

@@ -21,6 +21,7 @@ from .functional import (  # noqa: F401
     class_gather_table,
     proto_head_forward,
     push_masked_argmin,
+    push_min_from_features,
     upsample_argext,
 )
 from .checkpoint import export_state, import_state, load_reference_state_dict  # noqa: F401

@@ -20,6 +20,10 @@ struct SpxFwdArgs {
     const uint32_t* proto_key; // [npanels][32 npb] (class << 16) | slot per padded prototype row, 0xFFFFFFFF = none
     float* cls_dist;           // [B, J, HW] slot planes
     int J;
+    // fused prototype push (spx_dist_push_min): instead of the slot planes, the class-masked minimum of every prototype's
+    // distance row over the image, as (ordered float key << 32 | flat pixel index) integer minima
+    unsigned long long* push_keys;   // [B, P], caller-initialised to all ones; NULL = off
+    float push_max;                  // the reference's max_dist (1e10)
     // grouping-head tail (spx_dist_fwd_group): logits = W_g . exp(units), units = the head product
     const char* packed_tail;   // W_g A-fragments (spx_pack_group_tail); NULL = no tail
     float* gact;               // [B*HW, U] exp(units) (optional)
@@ -119,6 +123,7 @@ hipError_t spx_launch_sum_groups(const float* parts, size_t n, int groups, float
 int spx_split_groups(const spx_plan& pl, int B, int HW, int32_t* group_first);
 hipError_t spx_launch_group_tail(const float* parts, int groups, long long M, int U, const float* Wg, int K2, float* gact,
                                  float* logits, const int32_t* labels, float* lse, int32_t* pred, float* partials, hipStream_t s);
+hipError_t spx_launch_push_finalize(const uint64_t* scratch, int n, int64_t* idx, float* val, hipStream_t s);
 size_t spx_gemm_workspace(int M, int N, int K, int flags);
 hipError_t spx_launch_gemm(const float* A, long long ras, long long kas, const float* B, long long rbs, long long kbs,
                            float* C, long long ldc, int M, int N, int K, int flags, const float* E, long long lde,

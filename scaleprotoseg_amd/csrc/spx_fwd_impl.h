@@ -200,7 +200,44 @@ __global__ __launch_bounds__(256 * SPLIT, (NPB == 2 && NCB == 1 ? 3 : SPX_FWD_WA
 #pragma unroll
                     for (int reg = 0; reg < 16; ++reg) av[reg] = -dv[reg];
                 }
-                if (GATHER) {
+                if (GATHER && a.push_keys) {
+                    // Fused prototype push (push_multiscale_optimization.py:74-91): v = d + max_dist * (1 - mask) with the
+                    // reference's rounding, its minimum over the wave's 32 pixels per prototype row (lowest pixel index on
+                    // ties), one integer atomicMin per row and wave - skipped when the row's current minimum (read past
+                    // the vector cache) is already lower.  The P-wide map never exists.
+                    float* const sc = (float*)(smem + wave * SPX_FWD_TSCRATCH);
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const u32x4 kv = *(const u32x4*)(keys + pb * 32 + 8 * g4 + 4 * h);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float one_minus_mask = (kv[e] >> 16) == lab16 ? 0.0f : 1.0f;
+                            const float v = px_ok ? dv[4 * g4 + e] + a.push_max * one_minus_mask : __builtin_inff();
+                            sc[(e + 8 * g4 + 4 * h) * SPX_FWD_TROW + r] = v;
+                        }
+                    }
+                    unsigned long long* const krow = a.push_keys + (size_t)b * P + p0 + pb * 32;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int row = 8 * q + (lane >> 3);
+                        const f32x4 v = *(const f32x4*)(sc + row * SPX_FWD_TROW + 4 * (lane & 7));
+                        float best = v[0];
+                        int bi = pxw;
+#pragma unroll
+                        for (int e = 1; e < 4; ++e)
+                            if (v[e] < best) { best = v[e]; bi = pxw + e; }
+#pragma unroll
+                        for (int m = 1; m <= 4; m <<= 1) {
+                            const float ov = __shfl_xor(best, m);
+                            const int oi = __shfl_xor(bi, m);
+                            if (ov < best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+                        }
+                        if ((lane & 7) == 0 && pb * 32 + row < np) {
+                            const unsigned long long key = ((unsigned long long)float_key(best + 0.0f) << 32) | (uint32_t)bi;
+                            if (key < __hip_atomic_load(krow + row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(krow + row, key);
+                        }
+                    }
+                } else if (GATHER) {
                     // a lane stores the rows whose class is its pixel's class, at [px][slot]; everything else is
                     // dropped by the out-of-range offset (rows of one class are few: ~P/K of the 32 per block).
                     // Label maps are piecewise constant, so most (wave, block) pairs have no match at all: one

@@ -186,6 +186,11 @@ hipError_t spx_launch_push_argmin(const float* dist, const int32_t* labels, cons
     return hipGetLastError();
 }
 
+hipError_t spx_launch_push_finalize(const uint64_t* scratch, int n, int64_t* idx, float* val, hipStream_t s) {
+    hipLaunchKernelGGL(spx_push_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (const unsigned long long*)scratch, n, idx, val);
+    return hipGetLastError();
+}
+
 hipError_t spx_launch_argmin_images(const float* values, int N, int P, int64_t* best, hipStream_t s) {
     hipLaunchKernelGGL(spx_argmin_images_kernel, dim3((P + 255) / 256), dim3(256), 0, s, values, N, P, best);
     return hipGetLastError();

@@ -85,6 +85,7 @@ class FusedCrossEntropy:
     pred: torch.Tensor
     labels: torch.Tensor
     target: Optional[torch.Tensor] = None      # the caller's label tensor (0 = void, 1..K) the labels were derived from
+    target_version: int = -1                   # ... and its version counter at that time
 
 
 def cross_entropy_from_logits(logits: torch.Tensor, labels0: torch.Tensor) -> FusedCrossEntropy:
@@ -746,6 +747,71 @@ def push_masked_argmin(
             float(max_dist), _lib.ptr(idx), _lib.ptr(val), _lib.ptr(scratch), _lib.stream_ptr(),
         )
     )
+    return idx, val
+
+
+def push_class_labels(labels: torch.Tensor, num_classes: int, void_class: Optional[int]) -> torch.Tensor:
+    """The push's label convention (push_multiscale_optimization.py:74-83: one_hot over K + 1 values, the void column
+    dropped) as the class index 0..K-1 per pixel, -1 = matches no prototype - the decode spx_push_argmin does per pixel."""
+    lab = labels.to(torch.int64)
+    if void_class is None or void_class < 0:
+        c = lab
+    else:
+        c = torch.where(lab < void_class, lab, lab - 1)
+        c = torch.where(lab == void_class, torch.full_like(c, -1), c)
+    c = torch.where((c >= 0) & (c < num_classes), c, torch.full_like(c, -1))
+    return c.to(torch.int32)
+
+
+def identity_is_one_hot(class_identity: torch.Tensor) -> bool:
+    """True when every row of prototype_class_identity is one-hot or all zero (what the reference builds,
+    model_multiscale.py:89-97): the fused push compares class indices instead of multiplying by the mask."""
+    ident = class_identity.detach()
+    return bool((((ident == 0) | (ident == 1)).all() & (ident.sum(dim=1) <= 1).all()).item())
+
+
+def push_min_from_features(
+    conv_features: torch.Tensor,
+    bank: torch.Tensor,
+    layout: BankLayout,
+    labels: torch.Tensor,
+    class_identity: torch.Tensor,
+    *,
+    void_class: Optional[int] = 0,
+    max_dist: float = 1e10,
+    keys: Optional[torch.Tensor] = None,
+) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(indices int64 [B,P], values f32 [B,P]) of the class-masked per-prototype minimum over each image's latent grid
+    (push_multiscale_optimization.py:68-91), computed INSIDE the distance kernel from the features: the [B, P, H, W] map
+    is never written (spx_dist_push_min).  Bit-identical to ``push_masked_argmin`` on the map ``proto_head_forward`` writes.
+    ``labels`` [B, H, W] in the push's convention (``void_class`` as in ``push_masked_argmin``); ``class_identity`` must be
+    one-hot per row (``identity_is_one_hot``); ``keys``: a cached ``class_gather_table(layout, class_identity, device)[0]``."""
+    lib = _lib.load()
+    if not conv_features.is_cuda:
+        raise SpxError("scaleprotoseg_amd runs on an AMD GPU only; there is no CPU fallback")
+    B, HW = _check_x(conv_features, layout)
+    H, W = conv_features.shape[2], conv_features.shape[3]
+    if tuple(labels.shape) != (B, H, W):
+        raise SpxError(f"labels must be [{B}, {H}, {W}], got {tuple(labels.shape)}")
+    if keys is None:
+        if not identity_is_one_hot(class_identity):
+            raise SpxError("the fused push needs a one-hot prototype_class_identity (use push_masked_argmin on the distance map)")
+        keys = class_gather_table(layout, class_identity, conv_features.device)[0]
+    P, K = layout.num_prototypes, int(class_identity.shape[1])
+    x = conv_features.detach().contiguous()
+    dev = x.device
+    lab = push_class_labels(labels.to(dev), K, void_class).reshape(B, HW).contiguous()
+    bank2d = bank.detach().reshape(P, layout.channels_per_scale).contiguous().float()
+    plan = layout.plan()
+    plan_key = (layout.num_prototypes, layout.num_classes, layout.num_scales, layout.channels_per_scale,
+                tuple(tuple(int(v) for v in r_) for r_ in layout.scale_ranges))
+    packs = _cached_packs(plan_key, plan, bank, None, None, bank2d, None, None, False)
+    idx = torch.empty((B, P), dtype=torch.int64, device=dev)
+    val = torch.empty((B, P), dtype=torch.float32, device=dev)
+    scratch = torch.empty((B * P,), dtype=torch.int64, device=dev)
+    _lib.check(lib.spx_dist_push_min(C.byref(plan), _lib.ptr(x), _x_dtype_code(x), B, HW, _lib.ptr(packs.bank), _lib.ptr(packs.p2),
+                                     _lib.ptr(lab), _lib.ptr(keys), float(max_dist), _lib.ptr(idx), _lib.ptr(val),
+                                     _lib.ptr(scratch), _lib.stream_ptr()))
     return idx, val
 
 

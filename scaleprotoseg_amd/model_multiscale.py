@@ -185,6 +185,32 @@ class _PrototypeBankMixin:
             return [(c, self._scale_l2_convolution(c)) for c in conv]
         return conv, self._scale_l2_convolution(conv)
 
+    def push_min_distances(self, x, labels_for_grid, void_class=None, max_dist: float = 1e10):
+        """Class-masked per-prototype minimum of the distance map of ``x`` over its latent grid, taken INSIDE the distance
+        kernel (push_multiscale_optimization.py:68-91 without the [B, P, H, W] map): (indices int64 [B, P], values [B, P]).
+        ``labels_for_grid((H, W))`` returns the label map [B, H, W] at the latent resolution (the grid is only known after
+        the backbone has run).  Returns None when the fused kernel does not apply (MSC list input, a
+        prototype_class_identity that is not one-hot, features off the GPU): the caller then reduces the written map."""
+        from .functional import class_gather_table, identity_is_one_hot, push_min_from_features
+
+        conv = self.conv_features(x)
+        if isinstance(conv, list) or not conv.is_cuda:
+            return None
+        self._check_fusable()
+        layout = self._layout(1)
+        ident = self.prototype_class_identity
+        tag = (self._tables_version, ident._version, layout.scale_ranges, str(conv.device))
+        cache = getattr(self, "_push_key_cache", None)
+        if cache is None or cache[0] is not ident or cache[1] != tag:
+            keys = class_gather_table(layout, ident, conv.device)[0] if identity_is_one_hot(ident) else None
+            cache = (ident, tag, keys)
+            self._push_key_cache = cache
+        if cache[2] is None:
+            return None
+        labels = labels_for_grid((conv.shape[2], conv.shape[3]))
+        return push_min_from_features(conv, self.prototype_vectors, layout, labels, ident, void_class=void_class,
+                                      max_dist=max_dist, keys=cache[2])
+
     def forward(self, x, **kwargs):
         conv = self.conv_features(x)
         if isinstance(conv, list):  # MSC
@@ -281,6 +307,7 @@ class PPNetMultiScale(_PrototypeBankMixin, nn.Module):
         logits = logits.reshape(B, H, W, -1)
         if fused_ce is not None:
             fused_ce.target = ce_target
+            fused_ce.target_version = ce_target._version      # an in-place edit of the labels afterwards voids the attachment
             logits.spx_ce = fused_ce
         if return_activations and not return_distances:
             return logits, act

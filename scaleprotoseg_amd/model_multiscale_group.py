@@ -195,6 +195,7 @@ class PPNetMultiScale(_PrototypeBankMixin, nn.Module):
         logits = logits.reshape(B, H, W, -1)
         if fused_ce is not None:
             fused_ce.target = ce_target
+            fused_ce.target_version = ce_target._version      # an in-place edit of the labels afterwards voids the attachment
             logits.spx_ce = fused_ce
         if return_activations and not return_distances:
             return logits, act

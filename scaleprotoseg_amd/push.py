@@ -40,9 +40,16 @@ def compute_distances(
     device = device or str(ppnet.prototype_vectors.device)
     ppnet.eval()
     x = img.unsqueeze(0).to(device) if img.dim() == 3 else img.to(device)
-    _, distances = ppnet(x, return_activations=False)
     if dataset is not None and getattr(dataset, "convert_targets", None) is not None:
         target = dataset.convert_targets(target)
+    fused = getattr(ppnet, "push_min_distances", None)
+    if fused is not None:
+        # the minimum is taken inside the distance kernel: the [1, P, H, W] map is never written (spx_dist_push_min)
+        out = fused(x, lambda hw: resize_label(np.asarray(target), (hw[1], hw[0])).unsqueeze(0), void_class=void_class,
+                    max_dist=max_dist)
+        if out is not None:
+            return out
+    _, distances = ppnet(x, return_activations=False)
     lab = resize_label(np.asarray(target), (distances.shape[3], distances.shape[2])).unsqueeze(0)
     return push_masked_argmin(
         distances, lab, ppnet.prototype_class_identity, void_class=void_class, max_dist=max_dist
@@ -56,11 +63,13 @@ def min_across_dataset(
     void_class: Optional[int] = None,
     device: Optional[str] = None,
     image_range: Optional[range] = None,
-) -> Tuple[torch.Tensor, List[torch.Tensor]]:
+    return_values: bool = False,
+):
     """(best image per prototype int64 [P], per-image flat indices) — push_multiscale_optimization.py:94-137.
 
     ``image_range`` restricts the scan to a shard of the image list (data-parallel push, see dp.py); the
-    returned image ids are then positions inside the shard."""
+    returned image ids are then positions inside the shard.  ``return_values=True`` appends the per-image minima
+    ([n_images, P] fp32) the sharded reduction needs."""
     rng = image_range if image_range is not None else range(len(dataset))
     list_idx, list_val = [], []
     for i in rng:
@@ -69,8 +78,8 @@ def min_across_dataset(
         list_idx.append(idx)
         list_val.append(val)
     tot = torch.cat(list_val, dim=0)
-    min_across_dataset.last_values = tot  # kept for the sharded reduction
-    return argmin_over_images(tot), list_idx
+    best = argmin_over_images(tot)
+    return (best, list_idx, tot) if return_values else (best, list_idx)
 
 
 def _winning_patches(best: Sequence[int], list_min_patch, dataset, ppnet, device, image_offset: int = 0,
@@ -189,8 +198,8 @@ def push_prototypes_multiscale(
     dev = torch.device(device)
     ar = torch.arange(P, device=dev)
     if len(rng) > 0:
-        best_local, tot_idx = min_across_dataset(dataset, net, num_classes, void_class=0, device=device, image_range=rng)
-        tot_val = min_across_dataset.last_values                       # [n_local, P]
+        best_local, tot_idx, tot_val = min_across_dataset(dataset, net, num_classes, void_class=0, device=device, image_range=rng,
+                                                          return_values=True)                    # tot_val: [n_local, P]
         local_val = tot_val[best_local, ar]
         local_flat = torch.cat(list(tot_idx), dim=0)[best_local, ar]
     else:                                                              # more ranks than images: this rank never wins

@@ -751,6 +751,33 @@ def test_fused_cross_entropy_with_a_second_use_of_the_logits():
     _grad_close(net.last_layer.weight.grad, w0.grad, "dLastLayer")
 
 
+def test_fused_cross_entropy_is_dropped_when_the_labels_change():
+    """The attachment is only valid for the label tensor it was computed from, AS IT WAS: another tensor or an in-place
+    edit (version counter) sends the loss through the stand-alone kernels on the current labels."""
+    import scaleprotoseg_amd as spx
+    from scaleprotoseg_amd.loss import PixelWiseCrossEntropyLoss
+
+    dev = _dev()
+    B, S, Cs, P, K, H, W = 1, 2, 16, 20, 5, 6, 7
+    gen = torch.Generator().manual_seed(9)
+    conv = O.bf16_representable(torch.sigmoid(torch.randn(B, S * Cs, H, W, generator=gen))).to(dev)
+    net = spx.PPNetMultiScale(_Backbone(S * Cs), 64, (P, Cs, 1, 1), [], K, add_on_layers_type="deeplab_simple",
+                              patch_classification=True, num_scales=S).to(dev)
+    tgt = torch.randint(1, K + 1, (B, H, W), generator=gen).to(dev)
+    crit = PixelWiseCrossEntropyLoss(ignore_index=-1)
+    with torch.no_grad():
+        logits, _ = net.forward_from_conv_features(conv, ce_target=tgt)
+        assert crit(logits, tgt) is logits.spx_ce.loss
+        ref = lambda t: torch.nn.functional.cross_entropy(logits.reshape(-1, K).cpu(), t.reshape(-1).cpu() - 1, ignore_index=-1).item()
+        tgt2 = tgt.clone()
+        tgt2[0, 0, :] = (tgt2[0, 0, :] % K) + 1                               # another tensor
+        got = crit(logits, tgt2)
+        assert got is not logits.spx_ce.loss and abs(got.item() - ref(tgt2)) <= 1e-5 * max(1.0, abs(ref(tgt2)))
+        tgt[0, 1, :] = (tgt[0, 1, :] % K) + 1                                 # the same tensor, edited in place
+        got = crit(logits, tgt)
+        assert got is not logits.spx_ce.loss and abs(got.item() - ref(tgt)) <= 1e-5 * max(1.0, abs(ref(tgt)))
+
+
 @pytest.mark.parametrize("B,H,W", [(2, 9, 11), (1, 40, 65)])
 def test_group_module_fused_cross_entropy(golden, B, H, W):
     """Group phase: ce_target through the module (tail kernel: summed units -> exp -> W_g -> logits -> CE statistics),

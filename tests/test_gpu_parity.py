@@ -265,6 +265,68 @@ def test_push_argmin_random(hw):
     assert (ref_val == 1e10).any()
 
 
+PUSH_FUSED_SHAPES = [
+    # B, S, Cs,  P,   K,  H,   W
+    (2, 4, 64, 228, 19, 33, 65),      # the gin's bank, odd grid (ragged last tile, unaligned rows)
+    (1, 1, 256, 190, 19, 64, 128),    # north-star bank, 64 full tiles
+    (3, 2, 32, 44, 11, 9, 13),        # tiny: one partial tile per image
+    (1, 4, 64, 1800, 150, 17, 19),    # ADE bank: several panels per scale
+]
+
+
+@pytest.mark.parametrize("shape", PUSH_FUSED_SHAPES)
+@pytest.mark.parametrize("x_dtype", [torch.float32, torch.bfloat16])
+def test_fused_push_minimum_equals_the_two_step_push(shape, x_dtype):
+    """spx_dist_push_min (minimum taken inside the distance kernel, no map) against (a) the two-step path - the map
+    spx_dist_fwd writes reduced by spx_push_argmin - bit for bit, and (b) the oracle's push on that same map
+    (push_multiscale_optimization.py:74-91).  Absent classes, void pixels, duplicated prototypes (exact ties between rows)
+    and a prototype copied from a pixel (distance 0) are all in."""
+    from scaleprotoseg_amd.functional import proto_head_forward, push_masked_argmin, push_min_from_features
+
+    dev = _dev()
+    B, S, Cs, P, K, H, W = shape
+    conv, bank, Wl, ident, ranges = _problem(*shape, seed=31)
+    conv[:, :, 2:4, :] = conv[:, :, 0:2, :]            # repeated rows of pixels: exact ties along a prototype row
+    cv = conv[0].view(S, Cs, H, W)
+    p_sel = next(p for p in range(P // S) if int(ident[p].argmax()) != 2)
+    bank[p_sel, :, 0, 0] = cv[0, :, 1, 2]                  # a pushed prototype: distance 0 at (1, 2) - and at its copy (3, 2)
+    bank[p_sel + 2] = bank[p_sel + 1]
+    g = torch.Generator().manual_seed(32)
+    target = torch.randint(0, K + 1, (B, H, W), generator=g)
+    target[target == 3] = 1                                # class 2 absent everywhere
+    target[0, 1, 2] = target[0, 3, 2] = int(ident[p_sel].argmax()) + 1
+    layout = _layout(P, 1, S, Cs, ranges)
+    x = conv.to(dev, x_dtype)
+    _, dist, _ = proto_head_forward(x, bank.to(dev), None, layout)
+    idx2, val2 = push_masked_argmin(dist, target.to(dev), ident, void_class=0)
+    idx, val = push_min_from_features(x, bank.to(dev), layout, target.to(dev), ident, void_class=0)
+    np.testing.assert_array_equal(idx.cpu().numpy(), idx2.cpu().numpy())
+    np.testing.assert_array_equal(val.cpu().numpy(), val2.cpu().numpy())
+    ref_idx, ref_val = O.push_masked_argmin(dist.cpu(), target, ident, K, void_class=0)
+    np.testing.assert_array_equal(idx.cpu().numpy(), ref_idx.numpy())
+    np.testing.assert_array_equal(val.cpu().numpy(), ref_val.numpy())
+    assert (ref_val == 1e10).any() and (ref_val < 1e-3).any()
+    # labels without a void value (void_class=None: 0..K-1)
+    idx3, val3 = push_min_from_features(x, bank.to(dev), layout, (target - 1).clamp(min=0).to(dev), ident, void_class=None)
+    r3 = O.push_masked_argmin(dist.cpu(), (target - 1).clamp(min=0), ident, K, void_class=None)
+    np.testing.assert_array_equal(idx3.cpu().numpy(), r3[0].numpy())
+    np.testing.assert_array_equal(val3.cpu().numpy(), r3[1].numpy())
+
+
+def test_fused_push_rejects_a_fractional_identity():
+    from scaleprotoseg_amd import SpxError
+    from scaleprotoseg_amd.functional import push_min_from_features
+
+    dev = _dev()
+    shape = (1, 1, 32, 20, 5, 4, 8)
+    B, S, Cs, P, K, H, W = shape
+    conv, bank, Wl, ident, ranges = _problem(*shape, seed=33)
+    ident = ident.clone()
+    ident[0, 0] = 0.5
+    with pytest.raises(SpxError):
+        push_min_from_features(conv.to(dev), bank.to(dev), _layout(P, 1, S, Cs, ranges), torch.zeros(B, H, W, dtype=torch.long), ident)
+
+
 def test_argmin_over_images():
     from scaleprotoseg_amd.functional import argmin_over_images
 
