@@ -300,15 +300,17 @@ int spx_push_argmin(const float* distances, const int32_t* labels, const float* 
                     int64_t* indices, float* values, uint64_t* scratch, void* stream);
 
 /* The same reduction FUSED into the distance kernel (the P-wide distance map is never written): features in, per
- * (image, prototype) minimum + flat index out.  labels_cls: int32 [B, HW] class per pixel as 0..K-1 (anything else = no
- * class: void, ignored); proto_key: the (class << 16 | slot) table of spx_dist_fwd_cls (class of every padded prototype
- * row) - i.e. a one-hot prototype_class_identity, which is what the reference builds (model_multiscale.py:89-97).
+ * (image, prototype) minimum + flat index out.  labels / void_class / K: exactly as spx_push_argmin takes them (raw int32
+ * [B, HW] labels; label == void_class or outside the K classes matches no prototype; void_class < 0: labels are 0..K-1);
+ * proto_key: the (class << 16 | slot) table of spx_dist_fwd_cls (class of every padded prototype row) in place of the
+ * fp32 class_identity - i.e. a one-hot prototype_class_identity, which is what the reference builds
+ * (model_multiscale.py:89-97).
  * Arithmetic and tie rule as spx_push_argmin (distances as spx_dist_fwd computes them; d + max_dist * (1 - mask) rounded
  * as the reference rounds it; lowest flat index on ties; absent class -> (0, max_dist)).  Integer atomic minima:
  * run-to-run identical.  scratch: uint64 [B*P]. */
 int spx_dist_push_min(const spx_plan* plan, const void* x, int32_t x_dtype, int32_t B, int32_t HW, const void* packed_bank,
-                      const float* packed_p2, const int32_t* labels_cls, const uint32_t* proto_key, float max_dist,
-                      int64_t* indices, float* values, uint64_t* scratch, void* stream);
+                      const float* packed_p2, const int32_t* labels, int32_t void_class, int32_t K, const uint32_t* proto_key,
+                      float max_dist, int64_t* indices, float* values, uint64_t* scratch, void* stream);
 
 /* Lexicographic (value, image) argmin over images per prototype: tot_dist.argmin(dim=0),
  * push_multiscale_optimization.py:135-137.  values fp32 [N, P] -> best int64 [P]. */

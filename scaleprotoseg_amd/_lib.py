@@ -88,7 +88,7 @@ SIGNATURES = {
     "spx_bwd_fused_workspace_bytes": (C.c_size_t, [_PP, _I, _I]),
     "spx_dist_bwd_fused": (C.c_int, [_PP, _V, _I, _I, _I, _V, _V, _V, _V, _V, _V, _V, _V, _I, _V, _V, _V, _V, _V, _V, _F, _I, _V]),
     "spx_push_argmin": (C.c_int, [_V, _V, _V, _I, _I, _I, _I, _I, _F, _V, _V, _V, _V]),
-    "spx_dist_push_min": (C.c_int, [_PP, _V, _I, _I, _I, _V, _V, _V, _V, _F, _V, _V, _V, _V]),
+    "spx_dist_push_min": (C.c_int, [_PP, _V, _I, _I, _I, _V, _V, _V, _I, _I, _V, _F, _V, _V, _V, _V]),
     "spx_argmin_images": (C.c_int, [_V, _I, _I, _V, _V]),
     "spx_kld_segment_max": (C.c_int, [_V, _V, _I, _I, _I, _I, _I, _V, _V, _V]),
     "spx_kld_segment_sumexp": (C.c_int, [_V, _V, _I, _I, _I, _I, _I, _V, _V, _V]),

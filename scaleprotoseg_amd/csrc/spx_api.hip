@@ -195,7 +195,7 @@ static int dist_fwd_impl(const spx_plan* pl, const void* x, int32_t x_dtype, int
                          const int32_t* labels, const uint32_t* proto_key, int32_t J, float* cls_dist,
                          float* activations, float* logits, float epsilon, int32_t act_fn, void* stream,
                          SpxTailFwd tail = SpxTailFwd{nullptr, 0, nullptr}, const spx_ce* ce = nullptr, void* split_ws = nullptr,
-                         bool keep_partials = false, unsigned long long* push_keys = nullptr, float push_max = 0.0f) {
+                         bool keep_partials = false, unsigned long long* push_keys = nullptr, float push_max = 0.0f, int push_void = -1, int push_K = 0) {
     if (check_plan(pl)) return 1;
     if (!x || !packed_bank || !packed_p2) return fail("spx_dist_fwd: NULL operand");
     if (x_dtype != 0 && x_dtype != 1) return fail("spx_dist_fwd: x_dtype %d (0 = bf16, 1 = fp32)", x_dtype);
@@ -224,6 +224,8 @@ static int dist_fwd_impl(const spx_plan* pl, const void* x, int32_t x_dtype, int
     a.J = J;
     a.push_keys = push_keys;
     a.push_max = push_max;
+    a.push_void = push_void;
+    a.push_K = push_K;
     a.packed_tail = (const char*)tail.packed_tail;
     a.gact = tail.gact;
     a.K2 = tail.K2;
@@ -326,15 +328,16 @@ int spx_dist_fwd_cls(const spx_plan* pl, const void* x, int32_t x_dtype, int32_t
 }
 
 int spx_dist_push_min(const spx_plan* pl, const void* x, int32_t x_dtype, int32_t B, int32_t HW, const void* packed_bank,
-                      const float* packed_p2, const int32_t* labels, const uint32_t* proto_key, float max_dist,
-                      int64_t* indices, float* values, uint64_t* scratch, void* stream) {
+                      const float* packed_p2, const int32_t* labels, int32_t void_class, int32_t K, const uint32_t* proto_key,
+                      float max_dist, int64_t* indices, float* values, uint64_t* scratch, void* stream) {
     if (check_cls("spx_dist_push_min", labels, proto_key, 1, HW)) return 1;
+    if (K < 1 || K > 0xFFFD) return fail("spx_dist_push_min: K %d out of range", K);
     if (!indices || !values || !scratch) return fail("spx_dist_push_min: NULL output / scratch");
     if (check_plan(pl)) return 1;
     const size_t n = (size_t)B * pl->num_prototypes;
     if (hip_status(hipMemsetAsync(scratch, 0xFF, n * sizeof(uint64_t), (hipStream_t)stream), "spx_dist_push_min (scratch fill)")) return 1;
     if (dist_fwd_impl(pl, x, x_dtype, B, HW, packed_bank, packed_p2, nullptr, nullptr, labels, proto_key, 1, nullptr, nullptr, nullptr,
-                      1e-4f, 0, stream, SpxTailFwd{nullptr, 0, nullptr}, nullptr, nullptr, false, (unsigned long long*)scratch, max_dist))
+                      1e-4f, 0, stream, SpxTailFwd{nullptr, 0, nullptr}, nullptr, nullptr, false, (unsigned long long*)scratch, max_dist, void_class, K))
         return 1;
     return hip_status(spx_launch_push_finalize(scratch, (int)n, indices, values, (hipStream_t)stream), "spx_dist_push_min (decode)");
 }

@@ -24,6 +24,7 @@ struct SpxFwdArgs {
     // distance row over the image, as (ordered float key << 32 | flat pixel index) integer minima
     unsigned long long* push_keys;   // [B, P], caller-initialised to all ones; NULL = off
     float push_max;                  // the reference's max_dist (1e10)
+    int push_void, push_K;           // label decode of spx_push_argmin: labels are raw (void_class dropped from 0..K), see spx_hip.h
     // grouping-head tail (spx_dist_fwd_group): logits = W_g . exp(units), units = the head product
     const char* packed_tail;   // W_g A-fragments (spx_pack_group_tail); NULL = no tail
     float* gact;               // [B*HW, U] exp(units) (optional)

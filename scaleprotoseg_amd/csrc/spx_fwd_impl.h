@@ -41,7 +41,7 @@ __host__ __device__ constexpr int spx_fwd_region0_bytes() {
 }
 template <int NPB, int NCB, int SPLIT>
 __host__ __device__ constexpr int spx_fwd_lds_bytes() {
-    return spx_fwd_region0_bytes<NPB, SPLIT>() + spx_fwd_head_lds_bytes<NPB, NCB>() + 3 * NPB * 32 * 4;   // + |p|^2, class keys, slot plane offsets
+    return spx_fwd_region0_bytes<NPB, SPLIT>() + spx_fwd_head_lds_bytes<NPB, NCB>() + 3 * NPB * 32 * 4 + NPB * 32 * 8;   // + |p|^2, class keys, slot plane offsets, push minima
 }
 
 // SPLIT = waves per 32-pixel group.  SPLIT 1: 4 waves, each with all NPB blocks of its pixels (<= 256 VGPRs, two
@@ -92,6 +92,7 @@ __global__ __launch_bounds__(256 * SPLIT, (NPB == 2 && NCB == 1 ? 3 : SPX_FWD_WA
     float* const p2s = (float*)(wlds + head_lds);
     uint32_t* const keys = (uint32_t*)(p2s + NPB * 32);     // GATHER: (class << 16) | slot per padded prototype row
     uint32_t* const koff = keys + NPB * 32;                 // GATHER: byte offset of the row's slot plane (slot * HW * 4)
+    unsigned long long* const pmin = (unsigned long long*)(koff + NPB * 32);   // fused push: the workgroup's (value key, pixel) minimum per row
 
     Pipe pipe;
     f32x16 acc[NH];
@@ -135,6 +136,13 @@ __global__ __launch_bounds__(256 * SPLIT, (NPB == 2 && NCB == 1 ? 3 : SPX_FWD_WA
         const spx_rsrc labr = make_rsrc_pred(a.labels + (size_t)b * a.HW);
         const uint32_t l = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(labr, px_ok ? (uint32_t)px * 4u : SPX_OOB, 0, 0);
         lab16 = (px_ok && l < 0xFFFEu) ? l : 0xFFFEu;
+        if (a.push_keys) {
+            // the push's raw labels (push_multiscale_optimization.py:74-83: one_hot over K + 1 values, the void column dropped)
+            const int li = (int)l;
+            int c = li;
+            if (a.push_void >= 0) c = li == a.push_void ? -1 : (li < a.push_void ? li : li - 1);
+            lab16 = (px_ok && c >= 0 && c < a.push_K) ? (uint32_t)c : 0xFFFEu;
+        }
         voff_c = px_ok ? (uint32_t)px * 4u : SPX_OOB;          // [slot][px] planes: a wave's 32 pixels are one 128-B run
     }
 
@@ -167,6 +175,7 @@ __global__ __launch_bounds__(256 * SPLIT, (NPB == 2 && NCB == 1 ? 3 : SPX_FWD_WA
         if (GATHER && tid < NPB * 32) {
             keys[tid] = keyreg;
             koff[tid] = (keyreg & 0xFFFFu) * HW * 4u;
+            if (a.push_keys) pmin[tid] = ~0ull;
         }
     };
 
@@ -203,8 +212,8 @@ __global__ __launch_bounds__(256 * SPLIT, (NPB == 2 && NCB == 1 ? 3 : SPX_FWD_WA
                 if (GATHER && a.push_keys) {
                     // Fused prototype push (push_multiscale_optimization.py:74-91): v = d + max_dist * (1 - mask) with the
                     // reference's rounding, its minimum over the wave's 32 pixels per prototype row (lowest pixel index on
-                    // ties), one integer atomicMin per row and wave - skipped when the row's current minimum (read past
-                    // the vector cache) is already lower.  The P-wide map never exists.
+                    // ties) as an integer minimum into the workgroup's LDS row table; the table meets the global one once
+                    // per panel (below).  The P-wide map never exists.
                     float* const sc = (float*)(smem + wave * SPX_FWD_TSCRATCH);
 #pragma unroll
                     for (int g4 = 0; g4 < 4; ++g4) {
@@ -216,7 +225,6 @@ __global__ __launch_bounds__(256 * SPLIT, (NPB == 2 && NCB == 1 ? 3 : SPX_FWD_WA
                             sc[(e + 8 * g4 + 4 * h) * SPX_FWD_TROW + r] = v;
                         }
                     }
-                    unsigned long long* const krow = a.push_keys + (size_t)b * P + p0 + pb * 32;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const int row = 8 * q + (lane >> 3);
@@ -232,9 +240,9 @@ __global__ __launch_bounds__(256 * SPLIT, (NPB == 2 && NCB == 1 ? 3 : SPX_FWD_WA
                             const int oi = __shfl_xor(bi, m);
                             if (ov < best || (ov == best && oi < bi)) { best = ov; bi = oi; }
                         }
-                        if ((lane & 7) == 0 && pb * 32 + row < np) {
+                        if ((lane & 7) == 0) {
                             const unsigned long long key = ((unsigned long long)float_key(best + 0.0f) << 32) | (uint32_t)bi;
-                            if (key < __hip_atomic_load(krow + row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(krow + row, key);
+                            __hip_atomic_fetch_min(pmin + pb * 32 + row, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         }
                     }
                 } else if (GATHER) {
@@ -332,6 +340,16 @@ __global__ __launch_bounds__(256 * SPLIT, (NPB == 2 && NCB == 1 ? 3 : SPX_FWD_WA
                         }
                     }
                 }
+            }
+        }
+        if (GATHER && a.push_keys) {
+            // one global integer atomicMin per prototype row and workgroup - skipped when the row's current minimum (read
+            // past the vector cache; it only ever decreases) is already lower: a single memory round trip per panel
+            __syncthreads();
+            if (tid < np) {
+                unsigned long long* const gk = a.push_keys + (size_t)b * P + p0 + tid;
+                const unsigned long long key = pmin[tid];
+                if (key < __hip_atomic_load(gk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(gk, key);
             }
         }
         // the next panel (if any) accumulates from zero

@@ -750,19 +750,6 @@ def push_masked_argmin(
     return idx, val
 
 
-def push_class_labels(labels: torch.Tensor, num_classes: int, void_class: Optional[int]) -> torch.Tensor:
-    """The push's label convention (push_multiscale_optimization.py:74-83: one_hot over K + 1 values, the void column
-    dropped) as the class index 0..K-1 per pixel, -1 = matches no prototype - the decode spx_push_argmin does per pixel."""
-    lab = labels.to(torch.int64)
-    if void_class is None or void_class < 0:
-        c = lab
-    else:
-        c = torch.where(lab < void_class, lab, lab - 1)
-        c = torch.where(lab == void_class, torch.full_like(c, -1), c)
-    c = torch.where((c >= 0) & (c < num_classes), c, torch.full_like(c, -1))
-    return c.to(torch.int32)
-
-
 def identity_is_one_hot(class_identity: torch.Tensor) -> bool:
     """True when every row of prototype_class_identity is one-hot or all zero (what the reference builds,
     model_multiscale.py:89-97): the fused push compares class indices instead of multiplying by the mask."""
@@ -800,7 +787,7 @@ def push_min_from_features(
     P, K = layout.num_prototypes, int(class_identity.shape[1])
     x = conv_features.detach().contiguous()
     dev = x.device
-    lab = push_class_labels(labels.to(dev), K, void_class).reshape(B, HW).contiguous()
+    lab = labels.to(device=dev, dtype=torch.int32).reshape(B, HW).contiguous()
     bank2d = bank.detach().reshape(P, layout.channels_per_scale).contiguous().float()
     plan = layout.plan()
     plan_key = (layout.num_prototypes, layout.num_classes, layout.num_scales, layout.channels_per_scale,
@@ -810,7 +797,8 @@ def push_min_from_features(
     val = torch.empty((B, P), dtype=torch.float32, device=dev)
     scratch = torch.empty((B * P,), dtype=torch.int64, device=dev)
     _lib.check(lib.spx_dist_push_min(C.byref(plan), _lib.ptr(x), _x_dtype_code(x), B, HW, _lib.ptr(packs.bank), _lib.ptr(packs.p2),
-                                     _lib.ptr(lab), _lib.ptr(keys), float(max_dist), _lib.ptr(idx), _lib.ptr(val),
+                                     _lib.ptr(lab), -1 if void_class is None else int(void_class), K, _lib.ptr(keys), float(max_dist),
+                                     _lib.ptr(idx), _lib.ptr(val),
                                      _lib.ptr(scratch), _lib.stream_ptr()))
     return idx, val
 
