@@ -321,9 +321,13 @@ int spx_argmin_images(const float* values, int32_t N, int32_t P, int64_t* best, 
  * each reading vals once; all segment reductions use integer atomics (run-to-run identical results):
  *   spx_kld_segment_max    smax_keys uint32 [B, K, J] (caller zero-fills): ordered key of max_px vals over the segment
  *                          (key k -> float: k & 0x80000000 ? k ^ 0x80000000 : ~k); counts uint32 [B, K] (zero-filled,
- *                          may be NULL): pixels per segment (loss.py:113-127 skips segments of fewer than two)
+ *                          may be NULL): pixels per segment (loss.py:113-127 skips segments of fewer than two);
+ *                          range_keys uint32 [2] (zero-filled, may be NULL): ordered keys of max(v) and max(-v) over
+ *                          every value that enters a segment (the value range the fixed-point scale below is sized for)
  *   spx_kld_segment_sumexp ssum_fx uint64 [B, K, J] (zero-filled): sum_px exp(vals - smax) * 2^40, smax from the keys
- *   spx_kld_segment_lse    lse fp32 [n = B*K*J]: smax + log(ssum_fx / 2^40), 0 for a segment without pixels
+ *   spx_kld_segment_lse    lse fp32 [n = B*K*J]: smax + log(ssum_fx / 2^40), 0 for a segment without pixels; with `scale`
+ *                          (ONE double in device memory; needs range_keys and HW) also the fixed-point scale of the
+ *                          pair sums: the power of two 2^floor(log2(2^61 / (HW * (max - min + 32)))) - no host sync
  *   spx_kld_pair_sums      a_fx int64 [B, K, J, J] (zero-filled): sum_px p_j * (l_k - l_j) * scale = -KL(j || k) of the
  *                          segment, i.e. the Gram matrix sum_px p_j l_k minus its row's diagonal entry (diagonal 0);
  *                          scale: ONE double in DEVICE memory, so the caller can derive it from the data without a
@@ -333,13 +337,20 @@ int spx_argmin_images(const float* values, int32_t N, int32_t P, int64_t* best, 
  * W (the three reduction passes): row length of the pixel grid (must divide HW) lets a wave walk down a 64-pixel column
  * strip, which crosses fewer class boundaries than a row (partial results are published per class run); 0 = unknown
  * (linear walk).  W changes only the rounding of fp32 partial sums.
- * The [B, K, J, J]-sized algebra between the passes (loss.py:113-142: symmetric KL of the slot pairs of one scale,
- * exp(-kld), mean) is left to the caller.  J <= 16 and K*J*J*8 bytes must fit the LDS table (~60 KiB). */
+ *   spx_kld_gram_loss      the [B, K, J, J]-sized algebra between the passes (loss.py:113-142) as one small kernel:
+ *                          A = a_fx / scale [nseg = B*K, J, J]; kld_jk = (A_jj + A_kk - A_jk - A_kj) / 2; an entry is
+ *                          valid when pair_ok[class][j][k] (uint8 [K, J, J]: j < k, both slots exist, same scale) and the
+ *                          segment has >= 2 pixels; loss[0] = mean over the valid entries of exp(-kld) (0 if none);
+ *                          Cf = dLoss/dA (what spx_kld_backward takes); E: scratch [nseg, J, J].  Fixed-order sums.
+ * J <= 16 and K*J*J*8 bytes must fit the LDS table (~60 KiB). */
 int spx_kld_segment_max(const float* vals, const int32_t* labels, int32_t B, int32_t J, int32_t HW, int32_t W, int32_t K,
-                        uint32_t* smax_keys, uint32_t* counts, void* stream);
+                        uint32_t* smax_keys, uint32_t* counts, uint32_t* range_keys, void* stream);
 int spx_kld_segment_sumexp(const float* vals, const int32_t* labels, int32_t B, int32_t J, int32_t HW, int32_t W, int32_t K,
                            const uint32_t* smax_keys, uint64_t* ssum_fx, void* stream);
-int spx_kld_segment_lse(const uint32_t* smax_keys, const uint64_t* ssum_fx, int32_t n, float* lse, void* stream);
+int spx_kld_segment_lse(const uint32_t* smax_keys, const uint64_t* ssum_fx, int32_t n, float* lse, const uint32_t* range_keys,
+                        int32_t HW, double* scale, void* stream);
+int spx_kld_gram_loss(const int64_t* a_fx, const double* scale, const uint32_t* counts, const uint8_t* pair_ok, int32_t nseg, int32_t K,
+                      int32_t J, float* A, float* E, float* Cf, float* loss, void* stream);
 int spx_kld_pair_sums(const float* vals, const int32_t* labels, int32_t B, int32_t J, int32_t HW, int32_t W, int32_t K,
                       const float* lse, const double* scale, int64_t* a_fx, void* stream);
 int spx_kld_backward(const float* vals, const int32_t* labels, int32_t B, int32_t J, int32_t HW, int32_t K,

@@ -90,9 +90,10 @@ SIGNATURES = {
     "spx_push_argmin": (C.c_int, [_V, _V, _V, _I, _I, _I, _I, _I, _F, _V, _V, _V, _V]),
     "spx_dist_push_min": (C.c_int, [_PP, _V, _I, _I, _I, _V, _V, _V, _I, _I, _V, _F, _V, _V, _V, _V]),
     "spx_argmin_images": (C.c_int, [_V, _I, _I, _V, _V]),
-    "spx_kld_segment_max": (C.c_int, [_V, _V, _I, _I, _I, _I, _I, _V, _V, _V]),
+    "spx_kld_segment_max": (C.c_int, [_V, _V, _I, _I, _I, _I, _I, _V, _V, _V, _V]),
     "spx_kld_segment_sumexp": (C.c_int, [_V, _V, _I, _I, _I, _I, _I, _V, _V, _V]),
-    "spx_kld_segment_lse": (C.c_int, [_V, _V, _I, _V, _V]),
+    "spx_kld_segment_lse": (C.c_int, [_V, _V, _I, _V, _V, _I, _V, _V]),
+    "spx_kld_gram_loss": (C.c_int, [_V, _V, _V, _V, _I, _I, _I, _V, _V, _V, _V, _V]),
     "spx_kld_pair_sums": (C.c_int, [_V, _V, _I, _I, _I, _I, _I, _V, _V, _V, _V]),
     "spx_kld_backward": (C.c_int, [_V, _V, _I, _I, _I, _I, _V, _V, _V, _V, _V]),
     "spx_upsample_argext": (C.c_int, [_V, _I, _I, _I, _I, _I, _I, _I, _V, _V, _V]),

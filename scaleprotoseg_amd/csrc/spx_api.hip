@@ -666,9 +666,9 @@ static int kld_check_w(const char* fn, int32_t HW, int32_t W) {
     return 0;
 }
 int spx_kld_segment_max(const float* vals, const int32_t* labels, int32_t B, int32_t J, int32_t HW, int32_t W, int32_t K,
-                        uint32_t* smax_keys, uint32_t* counts, void* stream) {
+                        uint32_t* smax_keys, uint32_t* counts, uint32_t* range_keys, void* stream) {
     if (kld_check("spx_kld_segment_max", vals, labels, B, J, HW, K, smax_keys, 0) || kld_check_w("spx_kld_segment_max", HW, W)) return 1;
-    return hip_status(spx_launch_kld(0, vals, labels, B, J, HW, W, K, (const float*)counts, nullptr, nullptr, nullptr, smax_keys, (hipStream_t)stream), "spx_kld_segment_max");
+    return hip_status(spx_launch_kld(0, vals, labels, B, J, HW, W, K, (const float*)counts, (const float*)range_keys, nullptr, nullptr, smax_keys, (hipStream_t)stream), "spx_kld_segment_max");
 }
 int spx_kld_segment_sumexp(const float* vals, const int32_t* labels, int32_t B, int32_t J, int32_t HW, int32_t W, int32_t K,
                            const uint32_t* smax_keys, uint64_t* ssum_fx, void* stream) {
@@ -676,11 +676,19 @@ int spx_kld_segment_sumexp(const float* vals, const int32_t* labels, int32_t B, 
     if (kld_check_w("spx_kld_segment_sumexp", HW, W)) return 1;
     return hip_status(spx_launch_kld(1, vals, labels, B, J, HW, W, K, (const float*)smax_keys, nullptr, nullptr, nullptr, ssum_fx, (hipStream_t)stream), "spx_kld_segment_sumexp");
 }
-int spx_kld_segment_lse(const uint32_t* smax_keys, const uint64_t* ssum_fx, int32_t n, float* lse, void* stream) {
+int spx_kld_segment_lse(const uint32_t* smax_keys, const uint64_t* ssum_fx, int32_t n, float* lse, const uint32_t* range_keys, int32_t HW,
+                        double* scale, void* stream) {
     if (!smax_keys || !ssum_fx || !lse) return fail("spx_kld_segment_lse: NULL pointer");
     if (n < 0) return fail("spx_kld_segment_lse: n < 0");
+    if (scale && (!range_keys || HW < 1)) return fail("spx_kld_segment_lse: the scale needs range_keys and HW");
     if (n == 0) return 0;
-    return hip_status(spx_launch_kld_lse(smax_keys, ssum_fx, n, lse, (hipStream_t)stream), "spx_kld_segment_lse");
+    return hip_status(spx_launch_kld_lse(smax_keys, ssum_fx, n, lse, range_keys, HW, scale, (hipStream_t)stream), "spx_kld_segment_lse");
+}
+int spx_kld_gram_loss(const int64_t* a_fx, const double* scale, const uint32_t* counts, const uint8_t* pair_ok, int32_t nseg, int32_t K,
+                      int32_t J, float* A, float* E, float* Cf, float* loss, void* stream) {
+    if (!a_fx || !scale || !counts || !pair_ok || !A || !E || !Cf || !loss) return fail("spx_kld_gram_loss: NULL pointer");
+    if (nseg < 1 || K < 1 || J < 1 || J > 16 || nseg % K) return fail("spx_kld_gram_loss: bad sizes (nseg=%d K=%d J=%d)", nseg, K, J);
+    return hip_status(spx_launch_kld_gram_loss(a_fx, scale, counts, pair_ok, nseg, K, J, A, E, Cf, loss, (hipStream_t)stream), "spx_kld_gram_loss");
 }
 int spx_kld_pair_sums(const float* vals, const int32_t* labels, int32_t B, int32_t J, int32_t HW, int32_t W, int32_t K,
                       const float* lse, const double* scale, int64_t* a_fx, void* stream) {

@@ -74,12 +74,14 @@ __device__ __forceinline__ SpxKldWalk spx_kld_walk(int HW, int W, int lane, int 
 // pass 0: smax_key[b][c][j] = max over the segment's pixels of vals (ordered-uint key of the float)
 __global__ __launch_bounds__(SPX_KLD_THREADS) void spx_kld_max_kernel(const float* __restrict__ vals, const int32_t* __restrict__ labels,
                                                                      int J, int HW, int W, int K, unsigned int* __restrict__ smax_key,
-                                                                     unsigned int* __restrict__ counts) {
+                                                                     unsigned int* __restrict__ counts, unsigned int* __restrict__ range_keys) {
     extern __shared__ unsigned long long kld_smem[];
     unsigned int* tab = (unsigned int*)kld_smem;          // [K][J]
     unsigned int* cnt = tab + K * J;                      // [K] pixels of the class in this workgroup's range
+    unsigned int* rng = cnt + K;                          // [2] keys of max(v) and max(-v) over every value that enters a segment
     const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < K * J + K; i += SPX_KLD_THREADS) tab[i] = 0u;
+    for (int i = tid; i < K * J + K + 2; i += SPX_KLD_THREADS) tab[i] = 0u;
+    float vmx = -3.0e38f, vmn = 3.0e38f;
     __syncthreads();
     const float* v = vals + (size_t)b * J * HW;
     const int32_t* lab = labels + (size_t)b * HW;
@@ -109,8 +111,16 @@ __global__ __launch_bounds__(SPX_KLD_THREADS) void spx_kld_max_kernel(const floa
         const bool uniform = __builtin_amdgcn_ballot_w64(c != c0) == 0;
         float d[SPX_KLD_MAXJ];
         spx_kld_load_planes(d, v, J, HW, step < w.nvalid ? px : 0);
+        if (range_keys) {
+#pragma unroll
+            for (int j = 0; j < SPX_KLD_MAXJ; ++j) vmn = fminf(vmn, (ok && j < J) ? d[j] : 3.0e38f);
+        }
 #pragma unroll
         for (int j = 0; j < SPX_KLD_MAXJ; ++j) d[j] = (ok && j < J) ? d[j] : -3.0e38f;
+        if (range_keys) {
+#pragma unroll
+            for (int j = 0; j < SPX_KLD_MAXJ; ++j) vmx = fmaxf(vmx, d[j]);
+        }
         if (uniform) {
             if (!ok) continue;                             // a step of void pixels
             if (c0 != cur) {
@@ -128,9 +138,17 @@ __global__ __launch_bounds__(SPX_KLD_THREADS) void spx_kld_max_kernel(const floa
         }
     }
     publish();
+    if (range_keys) {
+        const float wmx = wave_max_f32(vmx), wmn = -wave_max_f32(-vmn);
+        if (lane == 0 && wmx >= wmn) {                     // (a wave without a class pixel leaves max < min)
+            atomicMax(&rng[0], float_key(wmx));
+            atomicMax(&rng[1], float_key(-wmn));
+        }
+    }
     __syncthreads();
     for (int i = tid; i < K * J; i += SPX_KLD_THREADS)
         if (tab[i]) atomicMax(&smax_key[(size_t)b * K * J + i], tab[i]);
+    if (range_keys && tid < 2 && rng[tid]) atomicMax(&range_keys[tid], rng[tid]);
     if (counts)
         for (int i = tid; i < K; i += SPX_KLD_THREADS)
             if (cnt[i]) atomicAdd(&counts[(size_t)b * K + i], cnt[i]);
@@ -353,25 +371,92 @@ __global__ __launch_bounds__(SPX_KLD_THREADS) void spx_kld_backward_kernel(const
 
 // lse[i] = smax + log(sum exp(v - smax)) of segment slot i from passes 0 and 1; 0 where the segment has no pixel
 __global__ void spx_kld_lse_kernel(const unsigned int* __restrict__ smax_key, const unsigned long long* __restrict__ ssum_fx, int n,
-                                   float* __restrict__ lse) {
+                                   float* __restrict__ lse, const unsigned int* __restrict__ range_keys, int HW,
+                                   double* __restrict__ scale_out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0 && scale_out) {
+        // fixed-point scale of the pair sums: a power of two such that HW terms of size <= 2 (value range) + 32 stay inside int64
+        double span = 32.0;
+        if (range_keys[0] && range_keys[1]) span += (double)(key_float(range_keys[0]) + key_float(range_keys[1]));   // max - min, in fp32
+        *scale_out = exp2(floor(log2(2305843009213693952.0 / ((double)HW * span))));
+    }
     if (i >= n) return;
     const unsigned int k = smax_key[i];
     const double s = (double)ssum_fx[i] * (1.0 / 1099511627776.0);
     lse[i] = (k != 0u && s > 0.0) ? (float)((double)key_float(k) + log(s)) : 0.0f;
 }
-hipError_t spx_launch_kld_lse(const uint32_t* keys, const uint64_t* ssum_fx, int n, float* lse, hipStream_t s) {
-    hipLaunchKernelGGL(spx_kld_lse_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, keys, (const unsigned long long*)ssum_fx, n, lse);
+hipError_t spx_launch_kld_lse(const uint32_t* keys, const uint64_t* ssum_fx, int n, float* lse, const uint32_t* range_keys, int HW,
+                              double* scale_out, hipStream_t s) {
+    hipLaunchKernelGGL(spx_kld_lse_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, keys, (const unsigned long long*)ssum_fx, n, lse,
+                       range_keys, HW, scale_out);
     return hipGetLastError();
 }
 
+// The [B, K, J, J]-sized algebra between the pair sums and the gradient pass (loss.py:113-142), one workgroup:
+//   A = a_fx / scale;  kld_jk = (A_jj + A_kk - A_jk - A_kj) / 2;  valid = pair_ok[class][j][k] and the segment has >= 2 pixels;
+//   loss = mean over valid of exp(-kld) (0 when there is none);  Cf = dLoss/dA = (es - diag(rowsum es)) / 2,
+//   es = e + e^T, e = valid * exp(-kld) / n.
+// Sums run in double in a fixed order (thread-strided partials, LDS tree): run-to-run identical.
+__global__ __launch_bounds__(256) void spx_kld_gram_loss_kernel(const long long* __restrict__ a_fx, const double* __restrict__ scale,
+                                                                const unsigned int* __restrict__ counts,
+                                                                const unsigned char* __restrict__ pair_ok, int nseg, int K, int J,
+                                                                float* __restrict__ A, float* __restrict__ E, float* __restrict__ Cf,
+                                                                float* __restrict__ loss) {
+    __shared__ double ssum[256];
+    __shared__ double scnt[256];
+    const int tid = threadIdx.x, JJ = J * J, n = nseg * JJ;
+    const double inv_scale = 1.0 / *scale;
+    for (int i = tid; i < n; i += 256) A[i] = (float)((double)a_fx[i] * inv_scale);
+    __syncthreads();
+    double se = 0.0, sn = 0.0;
+    for (int i = tid; i < n; i += 256) {
+        const int seg = i / JJ, j = (i % JJ) / J, k = i % J;
+        const float* As = A + (size_t)seg * JJ;
+        const bool valid = pair_ok[(size_t)(seg % K) * JJ + j * J + k] && counts[seg] >= 2u;
+        const float kld = 0.5f * (((As[j * J + j] + As[k * J + k]) - As[j * J + k]) - As[k * J + j]);
+        const float e = valid ? expf(-kld) : 0.0f;
+        E[i] = e;
+        se += (double)e;
+        sn += valid ? 1.0 : 0.0;
+    }
+    ssum[tid] = se;
+    scnt[tid] = sn;
+    __syncthreads();
+    for (int m = 128; m >= 1; m >>= 1) {
+        if (tid < m) {
+            ssum[tid] += ssum[tid + m];
+            scnt[tid] += scnt[tid + m];
+        }
+        __syncthreads();
+    }
+    const float inv = 1.0f / (float)(scnt[0] < 1.0 ? 1.0 : scnt[0]);
+    if (tid == 0) *loss = (float)ssum[0] * inv;
+    for (int i = tid; i < n; i += 256) {
+        const int seg = i / JJ, j = (i % JJ) / J, k = i % J;
+        const float* Es = E + (size_t)seg * JJ;
+        float v = (Es[j * J + k] + Es[k * J + j]) * inv;
+        if (j == k) {
+            float row = 0.0f;
+            for (int m = 0; m < J; ++m) row += (Es[j * J + m] + Es[m * J + j]) * inv;
+            v -= row;
+        }
+        Cf[i] = 0.5f * v;
+    }
+}
+hipError_t spx_launch_kld_gram_loss(const int64_t* a_fx, const double* scale, const uint32_t* counts, const uint8_t* pair_ok, int nseg, int K,
+                                    int J, float* A, float* E, float* Cf, float* loss, hipStream_t s) {
+    hipLaunchKernelGGL(spx_kld_gram_loss_kernel, dim3(1), dim3(256), 0, s, (const long long*)a_fx, scale, counts, pair_ok, nseg, K, J, A, E, Cf, loss);
+    return hipGetLastError();
+}
+
+// (pass 0: t0 = counts, t1 = range keys)
 hipError_t spx_launch_kld(int pass, const float* vals, const int32_t* labels, int B, int J, int HW, int W, int K, const float* t0,
                           const float* t1, const float* t2, const double* scale, void* out, hipStream_t s) {
     dim3 grid((unsigned)((HW + SPX_KLD_PX_PER_WG - 1) / SPX_KLD_PX_PER_WG), (unsigned)B);
     dim3 blk(SPX_KLD_THREADS);
     if (W > 0 && pass != 3) grid.x = (unsigned)(((W + SPX_KLD_THREADS - 1) / SPX_KLD_THREADS) * ((HW / W + SPX_KLD_STRIP_ROWS - 1) / SPX_KLD_STRIP_ROWS));
     if (pass == 0)
-        hipLaunchKernelGGL(spx_kld_max_kernel, grid, blk, (size_t)(K * J + K) * 4, s, vals, labels, J, HW, W, K, (unsigned int*)out, (unsigned int*)t0);
+        hipLaunchKernelGGL(spx_kld_max_kernel, grid, blk, (size_t)(K * J + K + 2) * 4, s, vals, labels, J, HW, W, K, (unsigned int*)out, (unsigned int*)t0, (unsigned int*)t1);
     else if (pass == 1)
         hipLaunchKernelGGL(spx_kld_sumexp_kernel, grid, blk, (size_t)K * J * 12, s, vals, labels, J, HW, W, K, (const unsigned int*)t0, (unsigned long long*)out);
     else if (pass == 2) {

@@ -136,6 +136,67 @@ def _kld_kernels_usable(vals: torch.Tensor, K: int, J: int) -> bool:
     return vals.is_cuda and vals.dtype == torch.float32 and J <= 16 and K * J * J * 8 + K * J * 8 <= 60 * 1024
 
 
+def _kld_segment_passes(lib, v, lab, K, Wk, s):
+    """The three reduction passes over the gathered planes (csrc/spx_kld.hip): (a_fx int64 [B,K,J,J], counts [B,K], lse [B,K,J],
+    scale double [1]).  One zero-filled workspace holds the integer tables: [a_fx | ssum_fx | scale | keys | counts | range keys];
+    the fixed-point scale of the pair sums is derived on the device (segment-lse kernel) from the value range pass 0 collects:
+    |p_j (l_k - l_j)| is bounded by twice the range, and HW terms must stay inside int64 - no host sync, no torch glue."""
+    from . import _lib
+
+    B, J, HW = v.shape
+    dev = v.device
+    n_a, n_s = B * K * J * J, B * K * J
+    ws = torch.zeros(n_a + n_s + 1 + (n_s + B * K + 2 + 1) // 2, dtype=torch.int64, device=dev)
+    a_fx, ssum_fx = ws[:n_a].view(B, K, J, J), ws[n_a:n_a + n_s]
+    scale = ws[n_a + n_s:n_a + n_s + 1].view(torch.float64)
+    tail32 = ws[n_a + n_s + 1:].view(torch.int32)
+    keys, counts, rng = tail32[:n_s], tail32[n_s:n_s + B * K].view(B, K), tail32[n_s + B * K:n_s + B * K + 2]
+    _lib.check(lib.spx_kld_segment_max(_lib.ptr(v), _lib.ptr(lab), B, J, HW, Wk, K, _lib.ptr(keys), _lib.ptr(counts), _lib.ptr(rng), s))
+    _lib.check(lib.spx_kld_segment_sumexp(_lib.ptr(v), _lib.ptr(lab), B, J, HW, Wk, K, _lib.ptr(keys), _lib.ptr(ssum_fx), s))
+    lse = torch.empty((B, K, J), dtype=torch.float32, device=dev)
+    _lib.check(lib.spx_kld_segment_lse(_lib.ptr(keys), _lib.ptr(ssum_fx), n_s, _lib.ptr(lse), _lib.ptr(rng), HW, _lib.ptr(scale), s))
+    _lib.check(lib.spx_kld_pair_sums(_lib.ptr(v), _lib.ptr(lab), B, J, HW, Wk, K, _lib.ptr(lse), _lib.ptr(scale), _lib.ptr(a_fx), s))
+    return a_fx, counts, lse, scale
+
+
+class _KLDFusedLoss(torch.autograd.Function):
+    """The whole loss of class-gathered planes on the GPU in SIX launches (workspace fill, segment max + value range, segment
+    sum-exp, lse + fixed-point scale, pair sums, and spx_kld_gram_loss: symmetric KL of the slot pairs, exp(-kld), mean and its
+    gradient with respect to the pair sums, loss.py:113-142); backward: one scalar multiply + the per-pixel gradient pass."""
+
+    @staticmethod
+    def forward(ctx, vals, labels, K, W, pair_ok):
+        from . import _lib
+
+        lib = _lib.load()
+        B, J, HW = vals.shape
+        v = vals.detach().contiguous()
+        lab = labels.to(device=v.device, dtype=torch.int32).contiguous()
+        s = _lib.stream_ptr()
+        Wk = int(W) if W and HW % int(W) == 0 else 0
+        a_fx, counts, lse, scale = _kld_segment_passes(lib, v, lab, K, Wk, s)
+        out = torch.empty((3 * B * K * J * J + 1,), dtype=torch.float32, device=v.device)
+        n = B * K * J * J
+        A, E, cf, loss = out[:n], out[n:2 * n], out[2 * n:3 * n], out[3 * n:]
+        _lib.check(lib.spx_kld_gram_loss(_lib.ptr(a_fx), _lib.ptr(scale), _lib.ptr(counts), _lib.ptr(pair_ok), B * K, K, J,
+                                         _lib.ptr(A), _lib.ptr(E), _lib.ptr(cf), _lib.ptr(loss), s))
+        ctx.save_for_backward(v, lab, lse, A, cf)
+        ctx.K = K
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import _lib
+
+        lib = _lib.load()
+        v, lab, lse, A, cf = ctx.saved_tensors
+        B, J, HW = v.shape
+        grad = torch.empty_like(v)
+        cfg = (cf * g).contiguous()
+        _lib.check(lib.spx_kld_backward(_lib.ptr(v), _lib.ptr(lab), B, J, HW, ctx.K, _lib.ptr(lse), _lib.ptr(A), _lib.ptr(cfg), _lib.ptr(grad), _lib.stream_ptr()))
+        return grad, None, None, None, None
+
+
 class _KLDSegmentGram(torch.autograd.Function):
     """(A [B,K,J,J], lse [B,K,J]) of class-gathered distances through the HIP kernels (csrc/spx_kld.hip): A[seg][j][k] =
     sum_px p_j (l_k - l_j) = -KL(j || k), l the log_softmax over the segment's pixels (the Gram matrix sum p_j l_k of
@@ -152,22 +213,7 @@ class _KLDSegmentGram(torch.autograd.Function):
         dev = v.device
         s = _lib.stream_ptr()
         Wk = int(W) if W and HW % int(W) == 0 else 0          # traversal hint of the reduction passes
-        # one zero-filled workspace for the integer tables of the passes: [a_fx | ssum_fx | keys | counts]
-        n_a, n_s = B * K * J * J, B * K * J
-        ws = torch.zeros(n_a + n_s + (n_s + B * K + 1) // 2, dtype=torch.int64, device=dev)
-        a_fx, ssum_fx = ws[:n_a].view(B, K, J, J), ws[n_a:n_a + n_s]
-        tail32 = ws[n_a + n_s:].view(torch.int32)
-        keys, counts = tail32[:n_s], tail32[n_s:n_s + B * K].view(B, K)
-        _lib.check(lib.spx_kld_segment_max(_lib.ptr(v), _lib.ptr(lab), B, J, HW, Wk, K, _lib.ptr(keys), _lib.ptr(counts), s))
-        _lib.check(lib.spx_kld_segment_sumexp(_lib.ptr(v), _lib.ptr(lab), B, J, HW, Wk, K, _lib.ptr(keys), _lib.ptr(ssum_fx), s))
-        lse = torch.empty((B, K, J), dtype=torch.float32, device=dev)
-        _lib.check(lib.spx_kld_segment_lse(_lib.ptr(keys), _lib.ptr(ssum_fx), n_s, _lib.ptr(lse), s))
-        # fixed-point scale of the Gram sums (a power of two, computed on the device: no host sync): |p * l| is bounded
-        # by twice the value range of a slot (the sums are p_j (l_k - l_j)), and HW terms must stay inside int64
-        vmin, vmax = torch.aminmax(v)
-        span = (vmax - vmin).double() + 32.0
-        scale = torch.exp2(torch.floor(torch.log2((2.0 ** 61) / (HW * span)))).reshape(1).contiguous()
-        _lib.check(lib.spx_kld_pair_sums(_lib.ptr(v), _lib.ptr(lab), B, J, HW, Wk, K, _lib.ptr(lse), _lib.ptr(scale), _lib.ptr(a_fx), s))
+        a_fx, counts, lse, scale = _kld_segment_passes(lib, v, lab, K, Wk, s)
         A = (a_fx.to(torch.float64) / scale).float()
         ctx.save_for_backward(v, lab, lse, A)
         ctx.K = K
@@ -273,8 +319,7 @@ class KLDLoss(nn.Module):
         if planes is not None and _kld_kernels_usable(planes, K, J):
             # the gathered planes on the GPU: segment statistics and the gradient run in the HIP kernels; nothing on
             # this path reads a value back to the host (capturable in a HIP graph)
-            A, _, counts = _KLDSegmentGram.apply(planes, lab, K, width)
-            return self._loss_from_gram(A.reshape(nseg, J, J), counts.reshape(nseg), table, K, nseg)
+            return _KLDFusedLoss.apply(planes, lab, K, width, self._pair_mask_u8(table, dev))
         if not self.torch_formulation:
             raise SpxError(
                 f"KLD loss: input {tuple(vals.shape)} {vals.dtype} on {vals.device} (K={K}, J={J}) is outside the HIP kernels' "
@@ -315,6 +360,15 @@ class KLDLoss(nn.Module):
             A = A + _pixel_outer(z.view(pp.shape[0], ns1 * J), lp)
         A = A.view(ns1, J, J)[:nseg]
         return self._loss_from_gram(A, count, table, K, nseg)
+
+    def _pair_mask_u8(self, table: torch.Tensor, dev) -> torch.Tensor:
+        """The [K, J, J] pair mask as uint8 on ``dev`` (cached with the mask it is made from)."""
+        m = self._pair_mask(table)
+        c = getattr(self, "_pair_u8_cache", None)
+        if c is None or c[0] is not m or c[1].device != torch.device(dev):
+            c = (m, m.to(device=dev, dtype=torch.uint8).contiguous())
+            self._pair_u8_cache = c
+        return c[1]
 
     def _loss_from_gram(self, A: torch.Tensor, count: torch.Tensor, table: torch.Tensor, K: int, nseg: int) -> torch.Tensor:
         """Symmetric KL of the slot pairs from the segment Gram matrices, exp(-kld), mean (loss.py:113-142)."""

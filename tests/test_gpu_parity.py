@@ -1087,14 +1087,17 @@ def test_no_write_outside_the_output_buffers_extended_ops(seed):
     for z in (kk, cnt, ssum, afx):
         z.body(torch.uint8).zero_()
     Wk = W if seed % 2 else 0
-    _lib.check(lib.spx_kld_segment_max(cd.ptr, _lib.ptr(labels), B, J, HW, Wk, K, kk.ptr, cnt.ptr, s))
+    rngk, scale = _Guarded(8, dev), _Guarded(8, dev)
+    rngk.body(torch.uint8).zero_()
+    _lib.check(lib.spx_kld_segment_max(cd.ptr, _lib.ptr(labels), B, J, HW, Wk, K, kk.ptr, cnt.ptr, rngk.ptr, s))
     _lib.check(lib.spx_kld_segment_sumexp(cd.ptr, _lib.ptr(labels), B, J, HW, Wk, K, kk.ptr, ssum.ptr, s))
-    _lib.check(lib.spx_kld_segment_lse(kk.ptr, ssum.ptr, B * K * J, lse.ptr, s))
-    scale = torch.tensor([2.0 ** 30], dtype=torch.float64, device=dev)
-    _lib.check(lib.spx_kld_pair_sums(cd.ptr, _lib.ptr(labels), B, J, HW, Wk, K, lse.ptr, _lib.ptr(scale), afx.ptr, s))
-    A = torch.zeros(B, K, J, J, device=dev)
-    Cf = torch.rand(B, K, J, J, device=dev, generator=g)
-    _lib.check(lib.spx_kld_backward(cd.ptr, _lib.ptr(labels), B, J, HW, K, lse.ptr, _lib.ptr(A), _lib.ptr(Cf), grad.ptr, s))
+    _lib.check(lib.spx_kld_segment_lse(kk.ptr, ssum.ptr, B * K * J, lse.ptr, rngk.ptr, HW, scale.ptr, s))
+    _lib.check(lib.spx_kld_pair_sums(cd.ptr, _lib.ptr(labels), B, J, HW, Wk, K, lse.ptr, scale.ptr, afx.ptr, s))
+    A, E, Cf, kloss = (_Guarded(B * K * J * J * 4, dev), _Guarded(B * K * J * J * 4, dev), _Guarded(B * K * J * J * 4, dev),
+                       _Guarded(4, dev))
+    pair_ok = torch.triu(torch.ones(J, J, dtype=torch.uint8, device=dev), diagonal=1).repeat(K, 1, 1).contiguous()
+    _lib.check(lib.spx_kld_gram_loss(afx.ptr, scale.ptr, cnt.ptr, _lib.ptr(pair_ok), B * K, K, J, A.ptr, E.ptr, Cf.ptr, kloss.ptr, s))
+    _lib.check(lib.spx_kld_backward(cd.ptr, _lib.ptr(labels), B, J, HW, K, lse.ptr, A.ptr, Cf.ptr, grad.ptr, s))
     # evaluation map: upsample the small map by a non-integer factor
     Ho, Wo = int(rng.integers(H, 5 * H + 3)), int(rng.integers(W, 5 * W + 3))
     src = torch.rand(B, P, H, W, device=dev, generator=g)
@@ -1104,6 +1107,7 @@ def test_no_write_outside_the_output_buffers_extended_ops(seed):
     tag = f"B{B} S{S} Cs{Cs} P{P} K{K} J{J} {H}x{W} -> {Ho}x{Wo}"
     for name, gb in (("class distances", cd), ("logits", logits), ("dX", dx), ("G blob", gs), ("a blob", as_), ("kld keys", kk),
                      ("kld counts", cnt), ("kld sums", ssum), ("kld lse", lse), ("kld pair sums", afx), ("kld grad", grad),
+                     ("kld range keys", rngk), ("kld scale", scale), ("kld A", A), ("kld E", E), ("kld Cf", Cf), ("kld loss", kloss),
                      ("eval idx", eidx), ("eval val", eval_)):
         assert gb.intact(), f"{name}: write outside the buffer ({tag})"
 
