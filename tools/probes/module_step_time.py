@@ -57,4 +57,4 @@ run("cityscapes group phase 10x65x65 + fused CE", net, 10, 65, 65, 19, ce=True)
 net = spx.PPNetMultiScale(BB(256), 64, (1800, 64, 1, 1), [], 150, **mk).to(dev)
 run("ade prototype phase 2x65x65", net, 2, 65, 65, 150)
 net = GroupNet(BB(256), 64, (1800, 64, 1, 1), [], 150, num_groups=3, **mk).to(dev)
-run("ade group phase 2x65x65 (450 units: library GEMMs)", net, 2, 65, 65, 150)
+run("ade group phase 2x65x65 (450 units: fp32 MFMA product kernels)", net, 2, 65, 65, 150)
