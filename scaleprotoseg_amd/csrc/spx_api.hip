@@ -104,6 +104,8 @@ int spx_version(void) { return SPX_ABI_VERSION; }
 void spx_diag_set_debug_buffer(void* p) { g_dbg = (unsigned long long*)p; }
 /* Not part of the product ABI either: experiment switch for the block -> tile permutation (1 = identity). */
 void spx_diag_set_tile_mul(int m) { g_tile_mul_req = m; }
+/* ... and for the tile / split choice of spx_rows_gemm (0 = the shape-derived default). */
+void spx_diag_set_gemm(int wm, int splits) { spx_gemm_force(wm, splits); }
 const char* spx_last_error(void) { return g_err; }
 
 int spx_make_plan(int32_t P, int32_t K, int32_t S, int32_t Cs, const int32_t* lo, const int32_t* hi, spx_plan* out) {

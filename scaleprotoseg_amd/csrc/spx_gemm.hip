@@ -15,9 +15,8 @@
 #include "spx_args.h"
 #include "spx_common.h"
 
-#define SPX_G_TI 128
-#define SPX_G_TK 16
-#define SPX_G_LD 17
+#define SPX_G_TK 32          // k ranges of a split contraction are multiples of this (both chunk sizes divide it)
+
 
 typedef float spx_f4u __attribute__((ext_vector_type(4), aligned(4)));      // rows of [pixel][n] tensors are only 4-B aligned in general
 
@@ -32,121 +31,129 @@ struct SpxGemmArgs {
     float* ws;                              // [splits][M][N] partials when splits > 1
 };
 
-// one operand tile: 128 rows x 16 k into registers (8 floats per thread), then into its LDS image
-template <bool KCONT>
+// one operand tile: TI rows x TK k into registers (8 floats per thread), then into its LDS image.  The values stay untouched
+// in registers until commit() (the exponential of the grouping tail included), so a load can stay in flight across two chunks.
+template <bool KCONT, int TI, int TK>
 struct SpxGemmStager {
+    static constexpr int LD = TK + 1;
     float r[8];
-    int row, kk;        // KCONT: row of the tile, first of this thread's 8 k;   else: k row (0..15) and first of 8 tile rows
+    unsigned valid;     // bit e: element e is inside the operand (others are zero)
+    int row, kk;        // KCONT: row of the tile, first of this thread's 8 k;   else: k row and first of 8 tile rows
     __device__ __forceinline__ void init(int tid) {
-        if (KCONT) { row = tid >> 1; kk = (tid & 1) * 8; }
-        else { kk = tid >> 4; row = (tid & 15) * 8; }
+        if (KCONT) { row = tid / (TK / 8); kk = (tid % (TK / 8)) * 8; }
+        else { kk = tid / (TI / 8); row = (tid % (TI / 8)) * 8; }
     }
-    __device__ __forceinline__ void load(const float* __restrict__ P, long long rs, long long ks, int r0, int nrows, int k0, int kend, bool ex) {
-        if (KCONT) {
-            const int gi = r0 + row, k = k0 + kk;
-            const float* p = P + (long long)gi * rs + k;
-            if (gi < nrows && k + 8 <= kend) {
-                const spx_f4u v0 = *(const spx_f4u*)p, v1 = *(const spx_f4u*)(p + 4);
+    __device__ __forceinline__ void load(const float* __restrict__ P, long long rs, long long ks, int r0, int nrows, int k0, int kend) {
+        // KCONT: 8 consecutive k of one row;  else: 8 consecutive rows of one k.  (Measured against unconditional 16-B buffer
+        // loads with out-of-range predication + masking at commit: those ran 30-40 % slower on every shape.)
+        const int gi = r0 + row, k = k0 + kk;
+        const float* p = KCONT ? P + (long long)gi * rs + k : P + (long long)k * ks + gi;
+        const bool whole = KCONT ? (gi < nrows && k + 8 <= kend) : (k < kend && gi + 8 <= nrows);
+        if (whole) {
+            const spx_f4u v0 = *(const spx_f4u*)p, v1 = *(const spx_f4u*)(p + 4);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { r[e] = v0[e]; r[4 + e] = v1[e]; }
-                if (ex) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) r[e] = expf(r[e]);
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    float v = 0.0f;
-                    if (gi < nrows && k + e < kend) { v = p[e]; if (ex) v = expf(v); }
-                    r[e] = v;
-                }
-            }
+            for (int e = 0; e < 4; ++e) { r[e] = v0[e]; r[4 + e] = v1[e]; }
+            valid = 0xFFu;
         } else {
-            const int k = k0 + kk, gi = r0 + row;
-            const float* p = P + (long long)k * ks + gi;
-            if (k < kend && gi + 8 <= nrows) {
-                const spx_f4u v0 = *(const spx_f4u*)p, v1 = *(const spx_f4u*)(p + 4);
+            valid = 0u;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { r[e] = v0[e]; r[4 + e] = v1[e]; }
-                if (ex) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) r[e] = expf(r[e]);
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    float v = 0.0f;
-                    if (k < kend && gi + e < nrows) { v = p[e]; if (ex) v = expf(v); }
-                    r[e] = v;
-                }
+            for (int e = 0; e < 8; ++e) {
+                const bool ok = KCONT ? (gi < nrows && k + e < kend) : (k < kend && gi + e < nrows);
+                r[e] = 0.0f;
+                if (ok) { r[e] = p[e]; valid |= 1u << e; }
             }
         }
     }
-    __device__ __forceinline__ void commit(float* __restrict__ img) const {
+    __device__ __forceinline__ void commit(float* __restrict__ img, bool ex) {
+        if (ex) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) r[e] = (valid >> e) & 1u ? expf(r[e]) : 0.0f;
+        }
         if (KCONT) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) img[row * SPX_G_LD + kk + e] = r[e];
+            for (int e = 0; e < 8; ++e) img[row * LD + kk + e] = r[e];
         } else {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) img[(row + e) * SPX_G_LD + kk] = r[e];
+            for (int e = 0; e < 8; ++e) img[(row + e) * LD + kk] = r[e];
         }
     }
 };
 
-template <bool AK, bool BK>
+// WM = MFMA tiles per wave and dimension: 2 -> 128 x 128 workgroup tiles (64 x 64 per wave) in k-chunks of 16, 1 -> 64 x 64
+// (32 x 32 per wave) in k-chunks of 32: the small tile halves the operand re-use but quarters the work quantum, for shapes
+// whose 128-tiles would leave most CUs waiting for a few (8450 x 450: 268 big tiles on 256 CUs = two rounds for 5 % more
+// work than one).  Global loads run TWO chunks ahead of the matrix pipe through two register sets (a chunk's MFMAs take
+// ~1 us, an HBM round trip under load ~2 us: one chunk of lead left a lone workgroup at half speed).
+template <bool AK, bool BK, int WM>
 __global__ __launch_bounds__(256) void spx_gemm_kernel(const SpxGemmArgs a) {
-    __shared__ float As[2][SPX_G_TI * SPX_G_LD];
-    __shared__ float Bs[2][SPX_G_TI * SPX_G_LD];
+    constexpr int TI = 64 * WM, TK = WM == 2 ? 16 : 32, LD = TK + 1;
+    __shared__ float As[2][TI * LD];
+    __shared__ float Bs[2][TI * LD];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wi = wave >> 1, wj = wave & 1;
-    const int i0 = blockIdx.x * SPX_G_TI, j0 = blockIdx.y * SPX_G_TI;
+    const int i0 = blockIdx.x * TI, j0 = blockIdx.y * TI;
     const int kbeg = blockIdx.z * a.kper;
     const int kend = (kbeg + a.kper < a.K) ? kbeg + a.kper : a.K;
     const bool exa = a.flags & 1, exb = a.flags & 2;
 
-    f32x16 acc[2][2];
+    f32x16 acc[WM][WM];
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int u = 0; u < WM; ++u)
 #pragma unroll
-        for (int v = 0; v < 2; ++v)
+        for (int v = 0; v < WM; ++v)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[u][v][r] = 0.0f;
 
-    SpxGemmStager<AK> sa;
-    SpxGemmStager<BK> sb;
-    sa.init(tid);
-    sb.init(tid);
-    if (kbeg < kend) {
-        sa.load(a.A, a.ras, a.kas, i0, a.M, kbeg, kend, exa);
-        sb.load(a.B, a.rbs, a.kbs, j0, a.N, kbeg, kend, exb);
-        sa.commit(As[0]);
-        sb.commit(Bs[0]);
-    }
-    __syncthreads();
-    int buf = 0;
-    for (int k0 = kbeg; k0 < kend; k0 += SPX_G_TK) {
-        const bool more = k0 + SPX_G_TK < kend;
-        if (more) {
-            sa.load(a.A, a.ras, a.kas, i0, a.M, k0 + SPX_G_TK, kend, exa);
-            sb.load(a.B, a.rbs, a.kbs, j0, a.N, k0 + SPX_G_TK, kend, exb);
-        }
-        const float* ap = As[buf] + (wi * 64 + (lane & 31)) * SPX_G_LD + (lane >> 5);
-        const float* bp = Bs[buf] + (wj * 64 + (lane & 31)) * SPX_G_LD + (lane >> 5);
+    SpxGemmStager<AK, TI, TK> sa[2];
+    SpxGemmStager<BK, TI, TK> sb[2];
 #pragma unroll
-        for (int kk = 0; kk < SPX_G_TK / 2; ++kk) {
-            const float a0 = ap[2 * kk], a1 = ap[32 * SPX_G_LD + 2 * kk];
-            const float b0 = bp[2 * kk], b1 = bp[32 * SPX_G_LD + 2 * kk];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    for (int q = 0; q < 2; ++q) {
+        sa[q].init(tid);
+        sb[q].init(tid);
+    }
+    auto fetch = [&](int q, int k0) {       // (a chunk past the end loads nothing: every element is out of range)
+        sa[q].load(a.A, a.ras, a.kas, i0, a.M, k0, kend);
+        sb[q].load(a.B, a.rbs, a.kbs, j0, a.N, k0, kend);
+    };
+    auto commit = [&](int q, int buf) {
+        sa[q].commit(As[buf], exa);
+        sb[q].commit(Bs[buf], exb);
+    };
+    auto compute = [&](int buf) {
+        const float* ap = As[buf] + (wi * 32 * WM + (lane & 31)) * LD + (lane >> 5);
+        const float* bp = Bs[buf] + (wj * 32 * WM + (lane & 31)) * LD + (lane >> 5);
+#pragma unroll
+        for (int kk = 0; kk < TK / 2; ++kk) {
+            float av[WM], bv[WM];
+#pragma unroll
+            for (int u = 0; u < WM; ++u) {
+                av[u] = ap[u * 32 * LD + 2 * kk];
+                bv[u] = bp[u * 32 * LD + 2 * kk];
+            }
+#pragma unroll
+            for (int u = 0; u < WM; ++u)
+#pragma unroll
+                for (int v = 0; v < WM; ++v) acc[u][v] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[v], acc[u][v], 0, 0, 0);
         }
-        if (more) {
-            sa.commit(As[buf ^ 1]);
-            sb.commit(Bs[buf ^ 1]);
-        }
+    };
+    // chunk c lives in LDS buffer c & 1; register set q holds chunk c + 1 + q's data on its way there
+    fetch(0, kbeg);
+    commit(0, 0);
+    fetch(0, kbeg + TK);
+    fetch(1, kbeg + 2 * TK);
+    __syncthreads();
+    for (int k0 = kbeg; k0 < kend; k0 += 2 * TK) {
+        // even chunk: buffer 0 feeds the pipe; set 0 (chunk + 1) goes to buffer 1 and is re-armed with chunk + 3
+        commit(0, 1);
+        fetch(0, k0 + 3 * TK);
+        compute(0);
         __syncthreads();
-        buf ^= 1;
+        if (k0 + TK >= kend) break;
+        // odd chunk: buffer 1 feeds the pipe; set 1 (chunk + 2) goes to buffer 0 and is re-armed with chunk + 4
+        commit(1, 0);
+        fetch(1, k0 + 4 * TK);
+        compute(1);
+        __syncthreads();
     }
 
     // accumulator tile: register r of lane l is row (r & 3) + 8 (r >> 2) + 4 (l >> 5), column l & 31: a store instruction
@@ -155,13 +162,13 @@ __global__ __launch_bounds__(256) void spx_gemm_kernel(const SpxGemmArgs a) {
     const long long ldo = a.splits > 1 ? a.N : a.ldc;
     const bool mulexp = (a.flags & 4) && a.splits == 1;
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int u = 0; u < WM; ++u)
 #pragma unroll
-        for (int v = 0; v < 2; ++v) {
-            const int j = j0 + wj * 64 + v * 32 + (lane & 31);
+        for (int v = 0; v < WM; ++v) {
+            const int j = j0 + (wj * WM + v) * 32 + (lane & 31);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int i = i0 + wi * 64 + u * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int i = i0 + (wi * WM + u) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (i < a.M && j < a.N) {
                     float val = acc[u][v][r];
                     if (mulexp) val *= expf(a.E[(long long)i * a.lde + j]);
@@ -180,30 +187,41 @@ __global__ __launch_bounds__(256) void spx_gemm_reduce_kernel(const float* __res
     C[(g / N) * ldc + (g % N)] = s;
 }
 
-// split policy: a pure function of the shape (so results do not depend on the machine state)
-static void spx_gemm_split(int M, int N, int K, int flags, int& splits, int& kper) {
-    const long long tiles = (long long)((M + SPX_G_TI - 1) / SPX_G_TI) * ((N + SPX_G_TI - 1) / SPX_G_TI);
-    int s = 1;
-    if (tiles < 128 && K >= 1024 && !(flags & 4)) {      // (the exp-scaled epilogue is applied by the product kernel itself)
-        s = (int)(512 / tiles);
-        const int smax = K / 256;
-        if (s > smax) s = smax;
-        if (s > 64) s = 64;
-        if (s < 1) s = 1;
+// Tile and split policy: a pure function of the shape (results never depend on the machine state).
+struct SpxGemmPlan { int wm, splits, kper; };
+static int g_gemm_force_wm = 0, g_gemm_force_splits = 0;      // experiments only (spx_diag_set_gemm)
+void spx_gemm_force(int wm, int splits) { g_gemm_force_wm = wm; g_gemm_force_splits = splits; }
+static SpxGemmPlan spx_gemm_plan(int M, int N, int K, int flags) {
+    if (g_gemm_force_wm) {
+        int sfor = g_gemm_force_splits < 1 || (flags & 4) ? 1 : g_gemm_force_splits;
+        int kp = ((K + sfor - 1) / sfor + SPX_G_TK - 1) / SPX_G_TK * SPX_G_TK;
+        return SpxGemmPlan{g_gemm_force_wm, (K + kp - 1) / kp, kp};
     }
-    int kp = (K + s - 1) / s;
-    kp = (kp + SPX_G_TK - 1) / SPX_G_TK * SPX_G_TK;
-    if (kp < SPX_G_TK) kp = SPX_G_TK;
-    s = (K + kp - 1) / kp;
-    if (s < 1) s = 1;
-    splits = s;
-    kper = kp;
+    // Measured on MI355X over the wide-head shapes (tools/probes/gemm_sweep.py): a workgroup alone on a CU runs at about half
+    // the matrix pipe's rate (its barriers and LDS commits are exposed), so the launch should put ~8 workgroups on every CU;
+    // the 64-tiles beat the 128-tiles until there are several thousand of them, and a contraction is split (slabs summed in
+    // order by a second kernel) until that many workgroups exist, keeping >= 512 k per slab.
+    const long long t64 = (long long)((M + 63) / 64) * ((N + 63) / 64);
+    if (t64 >= 8192) return SpxGemmPlan{2, 1, (K + SPX_G_TK - 1) / SPX_G_TK * SPX_G_TK};
+    int sp = 1;
+    while (!(flags & 4) && sp < 32 && t64 * sp < 2048 && K / (2 * sp) >= 512) sp *= 2;
+    int kp = ((K + sp - 1) / sp + SPX_G_TK - 1) / SPX_G_TK * SPX_G_TK;
+    return SpxGemmPlan{1, (K + kp - 1) / kp, kp};
 }
 
 size_t spx_gemm_workspace(int M, int N, int K, int flags) {
-    int s, kp;
-    spx_gemm_split(M, N, K, flags, s, kp);
-    return s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
+    const SpxGemmPlan p = spx_gemm_plan(M, N, K, flags);
+    return p.splits > 1 ? (size_t)p.splits * M * N * sizeof(float) : 0;
+}
+
+template <int WM>
+static void spx_launch_gemm_wm(const SpxGemmArgs& a, bool ak, bool bk, hipStream_t s) {
+    constexpr int TI = 64 * WM;
+    const dim3 grid((a.M + TI - 1) / TI, (a.N + TI - 1) / TI, a.splits);
+    if (ak && bk) hipLaunchKernelGGL((spx_gemm_kernel<true, true, WM>), grid, dim3(256), 0, s, a);
+    else if (ak) hipLaunchKernelGGL((spx_gemm_kernel<true, false, WM>), grid, dim3(256), 0, s, a);
+    else if (bk) hipLaunchKernelGGL((spx_gemm_kernel<false, true, WM>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((spx_gemm_kernel<false, false, WM>), grid, dim3(256), 0, s, a);
 }
 
 hipError_t spx_launch_gemm(const float* A, long long ras, long long kas, const float* B, long long rbs, long long kbs,
@@ -216,14 +234,13 @@ hipError_t spx_launch_gemm(const float* A, long long ras, long long kas, const f
     a.E = E; a.lde = lde;
     a.M = M; a.N = N; a.K = K;
     a.flags = flags;
-    spx_gemm_split(M, N, K, flags, a.splits, a.kper);
+    const SpxGemmPlan p = spx_gemm_plan(M, N, K, flags);
+    a.splits = p.splits;
+    a.kper = p.kper;
     a.ws = ws;
-    const dim3 grid((M + SPX_G_TI - 1) / SPX_G_TI, (N + SPX_G_TI - 1) / SPX_G_TI, a.splits);
     const bool ak = kas == 1, bk = kbs == 1;
-    if (ak && bk) hipLaunchKernelGGL((spx_gemm_kernel<true, true>), grid, dim3(256), 0, s, a);
-    else if (ak) hipLaunchKernelGGL((spx_gemm_kernel<true, false>), grid, dim3(256), 0, s, a);
-    else if (bk) hipLaunchKernelGGL((spx_gemm_kernel<false, true>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((spx_gemm_kernel<false, false>), grid, dim3(256), 0, s, a);
+    if (p.wm == 2) spx_launch_gemm_wm<2>(a, ak, bk, s);
+    else spx_launch_gemm_wm<1>(a, ak, bk, s);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (a.splits > 1) {
