@@ -1,7 +1,7 @@
 """Extended randomised parity run (not collected by pytest): the bodies of test_random_configurations and
 test_random_gather_and_tail over many more seeds than the suite carries.  Usage (GPU box):
     python tests/fuzz_extended.py FIRST LAST [LOGFILE]
-    python tests/fuzz_extended.py kld|push FIRST LAST [LOGFILE]
+    python tests/fuzz_extended.py kld|push|pushfused FIRST LAST [LOGFILE]
 Prints one line per failing seed and a summary; progress goes to LOGFILE every 10 seeds."""
 import os
 import sys
@@ -82,6 +82,46 @@ def push_case(seed):
     assert torch.equal(val.cpu(), ref_val), tag
 
 
+def push_fused_case(seed):
+    """Fused push (spx_dist_push_min: the minimum taken inside the distance kernel) on random banks, grids, label ranges and
+    void classes against the two-step push on the map the same kernel writes, and the oracle's push on that map: bit-exact."""
+    import numpy as np
+    import torch
+    from scaleprotoseg_amd.functional import proto_head_forward, push_masked_argmin, push_min_from_features
+
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(7500 + seed)
+    S = int(rng.choice([1, 2, 4]))
+    Cs = int(rng.choice([16, 32, 48, 64, 128, 256]))
+    K = int(rng.integers(1, 25))
+    P = S * K * int(rng.integers(1, 5))
+    if rng.random() < 0.2:
+        P = S * int(rng.integers(1, 500))              # prototype counts that are no multiple of the classes (several panels)
+    B, H, W = int(rng.integers(1, 4)), int(rng.integers(1, 70)), int(rng.integers(1, 140))
+    void = None if seed % 3 == 0 else int(rng.integers(0, K + 1))
+    xdt = torch.bfloat16 if seed % 2 else torch.float32
+    g = torch.Generator().manual_seed(seed)
+    conv = T.O.bf16_representable(torch.sigmoid(torch.randn(B, S * Cs, H, W, generator=g)))
+    if H > 2:
+        conv[:, :, 1] = conv[:, :, 0]                  # a repeated row of pixels: exact ties
+    bank = T.O.bf16_representable(torch.rand(P, Cs, 1, 1, generator=g))
+    ranges = T.O.default_scale_ranges(P, S)
+    ident = torch.zeros(P, K)
+    cls = torch.randint(0, K, (P,), generator=g)
+    ident[torch.arange(P), cls] = 1.0
+    ident[torch.rand(P, generator=g) < 0.1] = 0.0      # prototypes of no class
+    target = torch.randint(0, K if void is None else K + 1, (B, H, W), generator=g)
+    lay = T._layout(P, 1, S, Cs, ranges)
+    x = conv.to(dev, xdt)
+    _, dist, _ = proto_head_forward(x, bank.to(dev), None, lay)
+    idx2, val2 = push_masked_argmin(dist, target.to(dev), ident, void_class=void)
+    idx, val = push_min_from_features(x, bank.to(dev), lay, target.to(dev), ident, void_class=void)
+    ref_idx, ref_val = T.O.push_masked_argmin(dist.cpu(), target, ident, K, void_class=void)
+    tag = f"B{B} S{S} Cs{Cs} P{P} K{K} {H}x{W} void {void} {xdt}"
+    assert torch.equal(idx, idx2) and torch.equal(val, val2), "fused vs two-step: " + tag
+    assert torch.equal(idx.cpu(), ref_idx) and torch.equal(val.cpu(), ref_val), "fused vs oracle: " + tag
+
+
 def grad_stats(first, last):
     """Peak err / max|ref| per gradient over the randomised configurations (no assertion): what the tolerances are set from."""
     peaks = {}
@@ -103,8 +143,8 @@ def grad_stats(first, last):
 def main():
     if sys.argv[1] == "gradstats":
         return grad_stats(int(sys.argv[2]), int(sys.argv[3]))
-    if sys.argv[1] in ("kld", "push"):
-        case = kld_case if sys.argv[1] == "kld" else push_case
+    if sys.argv[1] in ("kld", "push", "pushfused"):
+        case = {"kld": kld_case, "push": push_case, "pushfused": push_fused_case}[sys.argv[1]]
         first, last = int(sys.argv[2]), int(sys.argv[3])
         log = open(sys.argv[4], "a") if len(sys.argv) > 4 else sys.stdout
         fails = []
@@ -117,7 +157,7 @@ def main():
                 if not isinstance(e, AssertionError):
                     traceback.print_exc(file=log)
             if seed % 20 == 0:
-                print(f"kld seed {seed} done, {len(fails)} failures so far", file=log, flush=True)
+                print(f"{sys.argv[1]} seed {seed} done, {len(fails)} failures so far", file=log, flush=True)
         print(f"{sys.argv[1]} fuzz {first}..{last}: {len(fails)} failures {fails}")
         return 1 if fails else 0
     first, last = int(sys.argv[1]), int(sys.argv[2])

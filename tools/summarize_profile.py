@@ -20,6 +20,19 @@ for f in glob.glob(root + "/trace/*/*kernel_stats.csv"):
             continue
         print(f"| `{name}` | {r['Calls']} | {float(r['AverageNs'])/1e3:.1f} | {float(r['TotalDurationNs'])/1e6:.2f} | {float(r['Percentage']):.1f} |")
     print()
+# the bench line printed by the SAME profiled process: its HIP-event kernel durations are the ones to hold against the table above
+# (a profiled run clocks lower than an unprofiled one)
+if os.path.exists(root + "/trace.log"):
+    for line in open(root + "/trace.log", errors="replace"):
+        line = line.strip()
+        if line.startswith("{") and '"metric"' in line:
+            try:
+                j = json.loads(line)
+            except ValueError:
+                continue
+            ks = {k: v.get("ms") for k, v in j.get("kernels", {}).items()}
+            print("## bench.py line of this profiled run (HIP events inside bench.py)\n")
+            print(f"ms_per_step {j.get('ms_per_step')}; kernel ms (HIP events): {json.dumps(ks)}; roofline.frac {j.get('roofline', {}).get('frac')}\n")
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(root + "/pmc_*/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
