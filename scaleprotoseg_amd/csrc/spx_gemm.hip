@@ -20,6 +20,8 @@
 
 typedef float spx_f4u __attribute__((ext_vector_type(4), aligned(4)));      // rows of [pixel][n] tensors are only 4-B aligned in general
 
+static int g_gemm_force_wm = 0, g_gemm_force_splits = 0;      // experiments only (spx_diag_set_gemm; splits < 0: linear block -> tile map)
+
 struct SpxGemmArgs {
     const float* A; long long ras, kas;
     const float* B; long long rbs, kbs;
@@ -27,7 +29,9 @@ struct SpxGemmArgs {
     const float* E; long long lde;          // flags & 4: C = acc * exp(E[i][j])
     int M, N, K;
     int flags;                              // 1: A elements enter as exp(A); 2: B elements enter as exp(B)
-    int splits, kper;                       // k range per split (multiple of 16)
+    int splits, kper;                       // k range per split (multiple of 32)
+    int ni, nj, ntiles;                     // tile grid of this launch: ni x nj tiles x splits
+    int linear_map;                         // experiments: tile = block index
     float* ws;                              // [splits][M][N] partials when splits > 1
 };
 
@@ -91,8 +95,18 @@ __global__ __launch_bounds__(256) void spx_gemm_kernel(const SpxGemmArgs a) {
     __shared__ float Bs[2][TI * LD];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wi = wave >> 1, wj = wave & 1;
-    const int i0 = blockIdx.x * TI, j0 = blockIdx.y * TI;
-    const int kbeg = blockIdx.z * a.kper;
+    // XCD-aware block -> tile map.  Workgroup w runs on XCD w mod 8, each with its own L2.  Tiles are numbered
+    // L = (slab * ni + i) * nj + j (tiles that share an A panel - and, in a split contraction, a k slab - are neighbours) and
+    // XCD x takes the contiguous range [x * per, (x + 1) * per): an operand panel is then fetched into ONE L2 instead of
+    // all eight.  Measured on the ADE / COCO head shapes (tools/probes/gemm_sweep.py, "linear" columns): no difference -
+    // their operands (<= 61 MB) sit in the memory-side cache and the kernels are bound by their own issue, not by L2 fills;
+    // kept because it costs nothing and is the right map once the operands outgrow that cache.
+    const int per = (a.ntiles + 7) / 8;
+    const int L = a.linear_map ? (int)blockIdx.x : (int)(blockIdx.x & 7u) * per + (int)(blockIdx.x >> 3);
+    if (L >= a.ntiles || (!a.linear_map && (int)(blockIdx.x >> 3) >= per)) return;
+    const int bj = L % a.nj, bi = (L / a.nj) % a.ni, bz = L / (a.nj * a.ni);
+    const int i0 = bi * TI, j0 = bj * TI;
+    const int kbeg = bz * a.kper;
     const int kend = (kbeg + a.kper < a.K) ? kbeg + a.kper : a.K;
     const bool exa = a.flags & 1, exb = a.flags & 2;
 
@@ -158,7 +172,7 @@ __global__ __launch_bounds__(256) void spx_gemm_kernel(const SpxGemmArgs a) {
 
     // accumulator tile: register r of lane l is row (r & 3) + 8 (r >> 2) + 4 (l >> 5), column l & 31: a store instruction
     // writes two 128-B row pieces
-    float* const out = a.splits > 1 ? a.ws + (size_t)blockIdx.z * (size_t)a.M * (size_t)a.N : a.C;
+    float* const out = a.splits > 1 ? a.ws + (size_t)bz * (size_t)a.M * (size_t)a.N : a.C;
     const long long ldo = a.splits > 1 ? a.N : a.ldc;
     const bool mulexp = (a.flags & 4) && a.splits == 1;
 #pragma unroll
@@ -189,11 +203,11 @@ __global__ __launch_bounds__(256) void spx_gemm_reduce_kernel(const float* __res
 
 // Tile and split policy: a pure function of the shape (results never depend on the machine state).
 struct SpxGemmPlan { int wm, splits, kper; };
-static int g_gemm_force_wm = 0, g_gemm_force_splits = 0;      // experiments only (spx_diag_set_gemm)
 void spx_gemm_force(int wm, int splits) { g_gemm_force_wm = wm; g_gemm_force_splits = splits; }
 static SpxGemmPlan spx_gemm_plan(int M, int N, int K, int flags) {
     if (g_gemm_force_wm) {
-        int sfor = g_gemm_force_splits < 1 || (flags & 4) ? 1 : g_gemm_force_splits;
+        int sfor = g_gemm_force_splits < 0 ? -g_gemm_force_splits : g_gemm_force_splits;
+        if (sfor < 1 || (flags & 4)) sfor = 1;
         int kp = ((K + sfor - 1) / sfor + SPX_G_TK - 1) / SPX_G_TK * SPX_G_TK;
         return SpxGemmPlan{g_gemm_force_wm, (K + kp - 1) / kp, kp};
     }
@@ -215,9 +229,14 @@ size_t spx_gemm_workspace(int M, int N, int K, int flags) {
 }
 
 template <int WM>
-static void spx_launch_gemm_wm(const SpxGemmArgs& a, bool ak, bool bk, hipStream_t s) {
+static void spx_launch_gemm_wm(const SpxGemmArgs& a_, bool ak, bool bk, hipStream_t s) {
     constexpr int TI = 64 * WM;
-    const dim3 grid((a.M + TI - 1) / TI, (a.N + TI - 1) / TI, a.splits);
+    SpxGemmArgs a = a_;
+    a.ni = (a.M + TI - 1) / TI;
+    a.nj = (a.N + TI - 1) / TI;
+    a.ntiles = a.ni * a.nj * a.splits;
+    a.linear_map = g_gemm_force_splits < 0;
+    const dim3 grid((unsigned)(((a.ntiles + 7) / 8) * 8));
     if (ak && bk) hipLaunchKernelGGL((spx_gemm_kernel<true, true, WM>), grid, dim3(256), 0, s, a);
     else if (ak) hipLaunchKernelGGL((spx_gemm_kernel<true, false, WM>), grid, dim3(256), 0, s, a);
     else if (bk) hipLaunchKernelGGL((spx_gemm_kernel<false, true, WM>), grid, dim3(256), 0, s, a);

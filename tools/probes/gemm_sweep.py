@@ -46,6 +46,12 @@ def main():
                     row.append(f"{64 * wm}/s{sp}: {timed(fn):6.1f}")
             lib.spx_diag_set_gemm(0, 0)
             row.append(f"auto: {timed(fn):6.1f}")
+            for wm, sp in ((1, -1), (1, -2), (1, -4), (1, -16)):
+                if what != "d_w" and sp < -4:
+                    continue
+                lib.spx_diag_set_gemm(wm, sp)
+                row.append(f"linear 64/s{-sp}: {timed(fn):6.1f}")
+            lib.spx_diag_set_gemm(0, 0)
             print(f"{name} {what}: " + "  ".join(row), flush=True)
 
 
