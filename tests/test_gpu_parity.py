@@ -705,7 +705,10 @@ def test_random_configurations(seed):
     _grad_close(w.grad, dw_ref, "dLastLayer " + tag)
 
 
-@pytest.mark.parametrize("seed", list(range(12)))
+# (40, 48, 84: the grouping-tail configurations that missed a 0.1 max|l| per-element floor in the round-2 fuzz run, kept as
+# fixed regression cases of the bound stated in _assert_fwd; the fuzz runner's seed 378 sits 0.2 % over it and is recorded in
+# profiles/r3_fuzz_summary.txt)
+@pytest.mark.parametrize("seed", list(range(12)) + [40, 48, 84])
 def test_random_gather_and_tail(seed):
     """Randomised shapes for the two extended modes: class-gathered distances (even seeds) and the fused grouping
     tail (odd seeds), forward + all gradients against the oracle."""
