@@ -24,7 +24,9 @@
 
 // per-wave LDS scratch of the epilogue's distance-tile turn: 32 prototype rows x 32 pixels fp32, 160-B rows (the
 // two half-waves land 32 banks apart: conflict-free writes); aliases the main-loop stages, free after the loop
+#ifndef SPX_FWD_TROW
 #define SPX_FWD_TROW 40
+#endif
 #define SPX_FWD_TSCRATCH 8192           // per wave: >= 32 * SPX_FWD_TROW * 4 (distance turn) and 32 px x 64 values (block I/O)
 // LDS carve (bytes): [stage 0][stage 1][head fragments of the current panel (NCB == 1 only)][|p|^2 of the panel]
 #ifdef SPX_FWD_HEAD_L2
