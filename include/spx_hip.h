@@ -334,14 +334,18 @@ int spx_argmin_images(const float* values, int32_t N, int32_t P, int64_t* best, 
  *                          host sync; l = vals - lse (the log_softmax over the segment's pixels, loss.py:110), p = exp(l).
  *   spx_kld_backward       grad fp32 [B, J, HW] = dLoss/dvals given A = a_fx / scale and Cf = dLoss/dA [B, K, J, J]
  *                          (diagonal entries of Cf are not read: A's diagonal is identically 0)
- * W (the three reduction passes): row length of the pixel grid (must divide HW) lets a wave walk down a 64-pixel column
- * strip, which crosses fewer class boundaries than a row (partial results are published per class run); 0 = unknown
+ * W (the three reduction passes): row length of the pixel grid (must divide HW) lets a wave take the pixels as compact
+ * 16 x 4 blocks down a 16-pixel column strip, which cross fewer class boundaries than a row segment (partial results are
+ * published per class run); 0 = unknown
  * (linear walk).  W changes only the rounding of fp32 partial sums.
- *   spx_kld_gram_loss      the [B, K, J, J]-sized algebra between the passes (loss.py:113-142) as one small kernel:
- *                          A = a_fx / scale [nseg = B*K, J, J]; kld_jk = (A_jj + A_kk - A_jk - A_kj) / 2; an entry is
- *                          valid when pair_ok[class][j][k] (uint8 [K, J, J]: j < k, both slots exist, same scale) and the
- *                          segment has >= 2 pixels; loss[0] = mean over the valid entries of exp(-kld) (0 if none);
- *                          Cf = dLoss/dA (what spx_kld_backward takes); E: scratch [nseg, J, J].  Fixed-order sums.
+ *   spx_kld_gram_loss      the [B, K, J, J]-sized algebra between the passes (loss.py:113-142), one workgroup per segment
+ *                          + a one-workgroup finish: A = a_fx / scale [nseg = B*K, J, J]; kld_jk = (A_jj + A_kk - A_jk -
+ *                          A_kj) / 2; an entry is valid when pair_ok[class][j][k] (uint8 [K, J, J]: j < k, both slots exist,
+ *                          same scale) and the segment has >= 2 pixels; loss[0] = mean over the valid entries of exp(-kld)
+ *                          (0 if none), loss[1] = 1 / max(number of valid entries, 1); Cf = dLoss/dA WITHOUT that factor
+ *                          (spx_kld_backward applies it: cf_scale); partials: double [2 * nseg] scratch.  Fixed-order sums.
+ *   spx_kld_backward       cf_scale: ONE float in device memory that multiplies Cf (NULL = 1): the caller's
+ *                          dLoss_total/dLoss times loss[1], formed on the device
  * J <= 16 and K*J*J*8 bytes must fit the LDS table (~60 KiB). */
 int spx_kld_segment_max(const float* vals, const int32_t* labels, int32_t B, int32_t J, int32_t HW, int32_t W, int32_t K,
                         uint32_t* smax_keys, uint32_t* counts, uint32_t* range_keys, void* stream);
@@ -350,11 +354,11 @@ int spx_kld_segment_sumexp(const float* vals, const int32_t* labels, int32_t B, 
 int spx_kld_segment_lse(const uint32_t* smax_keys, const uint64_t* ssum_fx, int32_t n, float* lse, const uint32_t* range_keys,
                         int32_t HW, double* scale, void* stream);
 int spx_kld_gram_loss(const int64_t* a_fx, const double* scale, const uint32_t* counts, const uint8_t* pair_ok, int32_t nseg, int32_t K,
-                      int32_t J, float* A, float* E, float* Cf, float* loss, void* stream);
+                      int32_t J, float* A, float* Cf, double* partials, float* loss, void* stream);
 int spx_kld_pair_sums(const float* vals, const int32_t* labels, int32_t B, int32_t J, int32_t HW, int32_t W, int32_t K,
                       const float* lse, const double* scale, int64_t* a_fx, void* stream);
 int spx_kld_backward(const float* vals, const int32_t* labels, int32_t B, int32_t J, int32_t HW, int32_t K,
-                     const float* lse, const float* A, const float* Cf, float* grad, void* stream);
+                     const float* lse, const float* A, const float* Cf, const float* cf_scale, float* grad, void* stream);
 
 /* Evaluation maps: F.interpolate(src, size=(H, W), mode="bilinear", align_corners=False) followed
  * by argmin (take_max = 0) or argmax (take_max = 1) over the channel dimension, without materialising the

@@ -95,7 +95,7 @@ SIGNATURES = {
     "spx_kld_segment_lse": (C.c_int, [_V, _V, _I, _V, _V, _I, _V, _V]),
     "spx_kld_gram_loss": (C.c_int, [_V, _V, _V, _V, _I, _I, _I, _V, _V, _V, _V, _V]),
     "spx_kld_pair_sums": (C.c_int, [_V, _V, _I, _I, _I, _I, _I, _V, _V, _V, _V]),
-    "spx_kld_backward": (C.c_int, [_V, _V, _I, _I, _I, _I, _V, _V, _V, _V, _V]),
+    "spx_kld_backward": (C.c_int, [_V, _V, _I, _I, _I, _I, _V, _V, _V, _V, _V, _V]),
     "spx_upsample_argext": (C.c_int, [_V, _I, _I, _I, _I, _I, _I, _I, _V, _V, _V]),
     "spx_fwd_split_groups": (C.c_int32, [_PP, _I, _I]),
     "spx_fwd_split_workspace_bytes": (C.c_size_t, [_PP, _I, _I]),

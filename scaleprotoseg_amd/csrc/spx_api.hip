@@ -687,10 +687,10 @@ int spx_kld_segment_lse(const uint32_t* smax_keys, const uint64_t* ssum_fx, int3
     return hip_status(spx_launch_kld_lse(smax_keys, ssum_fx, n, lse, range_keys, HW, scale, (hipStream_t)stream), "spx_kld_segment_lse");
 }
 int spx_kld_gram_loss(const int64_t* a_fx, const double* scale, const uint32_t* counts, const uint8_t* pair_ok, int32_t nseg, int32_t K,
-                      int32_t J, float* A, float* E, float* Cf, float* loss, void* stream) {
-    if (!a_fx || !scale || !counts || !pair_ok || !A || !E || !Cf || !loss) return fail("spx_kld_gram_loss: NULL pointer");
+                      int32_t J, float* A, float* Cf, double* partials, float* loss, void* stream) {
+    if (!a_fx || !scale || !counts || !pair_ok || !A || !Cf || !partials || !loss) return fail("spx_kld_gram_loss: NULL pointer");
     if (nseg < 1 || K < 1 || J < 1 || J > 16 || nseg % K) return fail("spx_kld_gram_loss: bad sizes (nseg=%d K=%d J=%d)", nseg, K, J);
-    return hip_status(spx_launch_kld_gram_loss(a_fx, scale, counts, pair_ok, nseg, K, J, A, E, Cf, loss, (hipStream_t)stream), "spx_kld_gram_loss");
+    return hip_status(spx_launch_kld_gram_loss(a_fx, scale, counts, pair_ok, nseg, K, J, A, Cf, partials, loss, (hipStream_t)stream), "spx_kld_gram_loss");
 }
 int spx_kld_pair_sums(const float* vals, const int32_t* labels, int32_t B, int32_t J, int32_t HW, int32_t W, int32_t K,
                       const float* lse, const double* scale, int64_t* a_fx, void* stream) {
@@ -699,10 +699,10 @@ int spx_kld_pair_sums(const float* vals, const int32_t* labels, int32_t B, int32
     return hip_status(spx_launch_kld(2, vals, labels, B, J, HW, W, K, lse, nullptr, nullptr, scale, a_fx, (hipStream_t)stream), "spx_kld_pair_sums");
 }
 int spx_kld_backward(const float* vals, const int32_t* labels, int32_t B, int32_t J, int32_t HW, int32_t K,
-                     const float* lse, const float* A, const float* Cf, float* grad, void* stream) {
+                     const float* lse, const float* A, const float* Cf, const float* cf_scale, float* grad, void* stream) {
     if (kld_check("spx_kld_backward", vals, labels, B, J, HW, K, grad, 1)) return 1;
     if (!lse || !A || !Cf) return fail("spx_kld_backward: NULL table");
-    return hip_status(spx_launch_kld(3, vals, labels, B, J, HW, 0, K, lse, A, Cf, nullptr, grad, (hipStream_t)stream), "spx_kld_backward");
+    return hip_status(spx_launch_kld(3, vals, labels, B, J, HW, 0, K, lse, A, Cf, nullptr, grad, (hipStream_t)stream, cf_scale), "spx_kld_backward");
 }
 
 }  // extern "C"

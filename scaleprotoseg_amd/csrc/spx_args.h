@@ -139,6 +139,6 @@ hipError_t spx_launch_ce_bwd(const float* logits, const float* lse, const int32_
 hipError_t spx_launch_kld_lse(const uint32_t* keys, const uint64_t* ssum_fx, int n, float* lse, const uint32_t* range_keys, int HW,
                               double* scale_out, hipStream_t s);
 hipError_t spx_launch_kld_gram_loss(const int64_t* a_fx, const double* scale, const uint32_t* counts, const uint8_t* pair_ok, int nseg, int K,
-                                    int J, float* A, float* E, float* Cf, float* loss, hipStream_t s);
+                                    int J, float* A, float* Cf, double* part, float* loss, hipStream_t s);
 hipError_t spx_launch_kld(int pass, const float* vals, const int32_t* labels, int B, int J, int HW, int W, int K, const float* t0,
-                          const float* t1, const float* t2, const double* scale, void* out, hipStream_t s);
+                          const float* t1, const float* t2, const double* scale, void* out, hipStream_t s, const float* cf_scale = nullptr);

@@ -10,11 +10,12 @@
 // tables and INTEGER atomics (ordered float keys for the max, 64-bit fixed point for the sums), so results do not
 // depend on the order of arrival: the loss is run-to-run bit-identical like the rest of the path.
 #include "spx_common.h"
+#include <type_traits>
 
 #define SPX_KLD_THREADS 256
 #define SPX_KLD_PX_PER_WG 2048
 #define SPX_KLD_MAXJ 16
-#define SPX_KLD_STRIP_ROWS 16           // pair sums, W given: rows of a wave's 64-pixel-wide column strip
+#define SPX_KLD_TILE 64                 // W given: a workgroup's tile (64 x 64 pixels: four 16-column strips of 16 steps of 4 rows)
 
 __device__ __forceinline__ double wave_sum_f64(double v) {
 #pragma unroll
@@ -24,18 +25,35 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
     }
     return v;      // fixed butterfly order: deterministic
 }
+// Sum over the 64 lanes in a fixed order without the LDS crossbar: four DPP adds leave every lane of a 16-lane row with its
+// row's sum, the four row sums are read back and added in row order.  ~8 vector instructions per value, against 12
+// ds_bpermute + 6 double adds for the butterfly above: the pair pass publishes 132 such sums per class run.
+__device__ __forceinline__ float wave_sum_f32(float v) {
+    auto dpp_add = [](float x, auto ctrl) {
+        return x + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xF, 0xF, true));
+    };
+    v = dpp_add(v, std::integral_constant<int, 0xB1>{});     // quad_perm [1,0,3,2]
+    v = dpp_add(v, std::integral_constant<int, 0x4E>{});     // quad_perm [2,3,0,1]
+    v = dpp_add(v, std::integral_constant<int, 0x141>{});    // row_half_mirror
+    v = dpp_add(v, std::integral_constant<int, 0x140>{});    // row_mirror
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+    return ((r0 + r1) + r2) + r3;
+}
 __device__ __forceinline__ float wave_max_f32(float v) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m));
     return v;
 }
 
-// The pixels a wave visits in the reduction passes.  W > 0: the pixels are rows of W and a wave walks DOWN a 64-pixel-wide
-// column strip (label maps are coherent in both directions; a strip crosses far fewer class boundaries than the same
-// pixels taken along one row).  W == 0: a linear walk.  This lane's pixel of step s is first + s*stride (s < nsteps,
-// real for s < nvalid).  The passes keep per-thread partial results while all 64 pixels of a step share one class and
-// reduce + publish them (wave butterfly, one LDS integer atomic per entry) only when the class changes or the walk ends;
-// steps whose pixels are not all of one class take the per-lane atomic path.
+// The pixels a wave visits in the reduction passes.  W > 0: the pixels are rows of W and a wave walks DOWN a 16-pixel-wide
+// column strip in steps of 16 x 4 pixel blocks (label maps are coherent in both directions; a compact block crosses far
+// fewer class boundaries than the same pixels taken along one row).  W == 0: a linear walk.  This lane's pixel of step s is
+// first + s*stride (s < nsteps, real for s < nvalid).  The passes keep per-thread partial results while all 64 pixels of a
+// step share one class and reduce + publish them (wave butterfly, one LDS integer atomic per entry) only when the class
+// changes or the walk ends; steps whose pixels are not all of one class take the per-lane atomic path.
 // The J plane values of one pixel, loaded UNCONDITIONALLY (a padded slot re-reads slot J-1, a lane without a pixel reads
 // pixel `px_safe`): a load under a per-lane condition becomes its own basic block with a full s_waitcnt in front of
 // its use, i.e. one exposed memory round trip per slot instead of one per pixel step (measured: 10 round trips per
@@ -49,17 +67,22 @@ __device__ __forceinline__ void spx_kld_load_planes(float (&raw)[JT], const floa
 struct SpxKldWalk {
     int first, stride, nsteps, nvalid;
 };
-__device__ __forceinline__ SpxKldWalk spx_kld_walk(int HW, int W, int lane, int wave) {
+__device__ __forceinline__ SpxKldWalk spx_kld_walk(int HW, int W, int trows, int lane, int wave) {
     SpxKldWalk w;
     if (W > 0) {
-        const int tiles_x = (W + SPX_KLD_THREADS - 1) / SPX_KLD_THREADS, H = HW / W;
+        // a step of a wave = a 16-column x 4-row block, the wave walks DOWN its 16-column strip (trows rows: 64 = 16 steps on
+        // large maps, fewer on small ones so that the chip fills), the four waves of a workgroup sit side by side.  A compact block lies inside ONE label region far more often
+        // than a 64 x 1 row segment does (a 64-pixel row of a map with 16-pixel regions is never of one class; 613 us -> see
+        // DESIGN.md for the pair pass at 2 Mpx), and every load instruction still moves four whole 64-B pieces.
+        const int tiles_x = (W + SPX_KLD_TILE - 1) / SPX_KLD_TILE, H = HW / W;
         const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
-        const int col = tx * SPX_KLD_THREADS + wave * 64 + lane, row0 = ty * SPX_KLD_STRIP_ROWS;
-        w.nsteps = min(SPX_KLD_STRIP_ROWS, H - row0);
-        if (tx * SPX_KLD_THREADS + wave * 64 >= W) w.nsteps = 0;          // wave-uniform
-        w.first = row0 * W + col;
-        w.stride = W;
-        w.nvalid = col < W ? w.nsteps : 0;
+        const int col = tx * SPX_KLD_TILE + wave * 16 + (lane & 15), row = ty * trows + (lane >> 4);
+        const int hend = min(H, (ty + 1) * trows);
+        w.nsteps = (hend - ty * trows + 3) / 4;
+        if (tx * SPX_KLD_TILE + wave * 16 >= W) w.nsteps = 0;             // wave-uniform
+        w.first = row * W + col;
+        w.stride = 4 * W;
+        w.nvalid = (col < W && row < hend) ? (hend - row + 3) / 4 : 0;
     } else {
         constexpr int PX_PER_WAVE = SPX_KLD_PX_PER_WG / (SPX_KLD_THREADS / 64);
         const int px0 = blockIdx.x * SPX_KLD_PX_PER_WG + wave * PX_PER_WAVE;
@@ -73,7 +96,7 @@ __device__ __forceinline__ SpxKldWalk spx_kld_walk(int HW, int W, int lane, int 
 
 // pass 0: smax_key[b][c][j] = max over the segment's pixels of vals (ordered-uint key of the float)
 __global__ __launch_bounds__(SPX_KLD_THREADS) void spx_kld_max_kernel(const float* __restrict__ vals, const int32_t* __restrict__ labels,
-                                                                     int J, int HW, int W, int K, unsigned int* __restrict__ smax_key,
+                                                                     int J, int HW, int W, int trows, int K, unsigned int* __restrict__ smax_key,
                                                                      unsigned int* __restrict__ counts, unsigned int* __restrict__ range_keys) {
     extern __shared__ unsigned long long kld_smem[];
     unsigned int* tab = (unsigned int*)kld_smem;          // [K][J]
@@ -85,7 +108,7 @@ __global__ __launch_bounds__(SPX_KLD_THREADS) void spx_kld_max_kernel(const floa
     __syncthreads();
     const float* v = vals + (size_t)b * J * HW;
     const int32_t* lab = labels + (size_t)b * HW;
-    const SpxKldWalk w = spx_kld_walk(HW, W, lane, wave);
+    const SpxKldWalk w = spx_kld_walk(HW, W, trows, lane, wave);
     float m[SPX_KLD_MAXJ];
 #pragma unroll
     for (int j = 0; j < SPX_KLD_MAXJ; ++j) m[j] = -3.0e38f;
@@ -107,8 +130,11 @@ __global__ __launch_bounds__(SPX_KLD_THREADS) void spx_kld_max_kernel(const floa
         const int px = w.first + step * w.stride;
         const int c = step < w.nvalid ? lab[px] : -1;
         const bool ok = c >= 0 && c < K;
-        const int c0 = __builtin_amdgcn_readfirstlane(c);
-        const bool uniform = __builtin_amdgcn_ballot_w64(c != c0) == 0;
+        // lanes without a class (void pixels, lanes past the map) contribute neutral values either way: a step is uniform when
+        // the lanes that HAVE a class agree on it (void borders and ragged tile edges do not send it down the per-lane path)
+        const unsigned long long okm = __builtin_amdgcn_ballot_w64(ok);
+        const int c0 = okm ? __builtin_amdgcn_readlane(c, __builtin_ffsll((long long)okm) - 1) : -1;
+        const bool uniform = __builtin_amdgcn_ballot_w64(ok && c != c0) == 0;
         float d[SPX_KLD_MAXJ];
         spx_kld_load_planes(d, v, J, HW, step < w.nvalid ? px : 0);
         if (range_keys) {
@@ -122,12 +148,12 @@ __global__ __launch_bounds__(SPX_KLD_THREADS) void spx_kld_max_kernel(const floa
             for (int j = 0; j < SPX_KLD_MAXJ; ++j) vmx = fmaxf(vmx, d[j]);
         }
         if (uniform) {
-            if (!ok) continue;                             // a step of void pixels
+            if (okm == 0) continue;                        // a step without a class pixel
             if (c0 != cur) {
                 publish();
                 cur = c0;
             }
-            run += 64u;
+            run += (unsigned)__builtin_popcountll(okm);
 #pragma unroll
             for (int j = 0; j < SPX_KLD_MAXJ; ++j) m[j] = fmaxf(m[j], d[j]);
         } else if (ok) {
@@ -156,7 +182,7 @@ __global__ __launch_bounds__(SPX_KLD_THREADS) void spx_kld_max_kernel(const floa
 
 // pass 1: ssum_fx[b][c][j] = sum exp(d - smax) in 2^40 fixed point (every term is in (0, 1], the maximum contributes 1)
 __global__ __launch_bounds__(SPX_KLD_THREADS) void spx_kld_sumexp_kernel(const float* __restrict__ vals, const int32_t* __restrict__ labels,
-                                                                        int J, int HW, int W, int K, const unsigned int* __restrict__ smax_key,
+                                                                        int J, int HW, int W, int trows, int K, const unsigned int* __restrict__ smax_key,
                                                                         unsigned long long* __restrict__ ssum_fx) {
     extern __shared__ unsigned long long kld_smem[];
     unsigned long long* tab = kld_smem;                    // [K][J]
@@ -170,8 +196,8 @@ __global__ __launch_bounds__(SPX_KLD_THREADS) void spx_kld_sumexp_kernel(const f
     const float* v = vals + (size_t)b * J * HW;
     const int32_t* lab = labels + (size_t)b * HW;
     const double FX = 1099511627776.0;                     // 2^40
-    const SpxKldWalk w = spx_kld_walk(HW, W, lane, wave);
-    float acc[SPX_KLD_MAXJ];                               // <= SPX_KLD_STRIP_ROWS terms of (0, 1] each: fp32 is ample
+    const SpxKldWalk w = spx_kld_walk(HW, W, trows, lane, wave);
+    float acc[SPX_KLD_MAXJ];                               // <= 16 terms (steps of the walk) of (0, 1] each: fp32 is ample
 #pragma unroll
     for (int j = 0; j < SPX_KLD_MAXJ; ++j) acc[j] = 0.0f;
     int cur = -1;
@@ -189,15 +215,18 @@ __global__ __launch_bounds__(SPX_KLD_THREADS) void spx_kld_sumexp_kernel(const f
         const int px = w.first + step * w.stride;
         const int c = step < w.nvalid ? lab[px] : -1;
         const bool ok = c >= 0 && c < K;
-        const int c0 = __builtin_amdgcn_readfirstlane(c);
-        const bool uniform = __builtin_amdgcn_ballot_w64(c != c0) == 0;
+        // lanes without a class (void pixels, lanes past the map) contribute neutral values either way: a step is uniform when
+        // the lanes that HAVE a class agree on it (void borders and ragged tile edges do not send it down the per-lane path)
+        const unsigned long long okm = __builtin_amdgcn_ballot_w64(ok);
+        const int c0 = okm ? __builtin_amdgcn_readlane(c, __builtin_ffsll((long long)okm) - 1) : -1;
+        const bool uniform = __builtin_amdgcn_ballot_w64(ok && c != c0) == 0;
         float e[SPX_KLD_MAXJ];
         spx_kld_load_planes(e, v, J, HW, step < w.nvalid ? px : 0);
         const float* smc = sm + (ok ? c : 0) * J;
 #pragma unroll
         for (int j = 0; j < SPX_KLD_MAXJ; ++j) e[j] = (ok && j < J) ? __expf(e[j] - smc[min(j, J - 1)]) : 0.0f;
         if (uniform) {
-            if (!ok) continue;
+            if (okm == 0) continue;
             if (c0 != cur) {
                 publish();
                 cur = c0;
@@ -223,7 +252,7 @@ __global__ __launch_bounds__(SPX_KLD_THREADS) void spx_kld_sumexp_kernel(const f
 // pixels (see SpxKldWalk).
 template <int JT>
 __global__ __launch_bounds__(SPX_KLD_THREADS) void spx_kld_pairs_kernel(const float* __restrict__ vals, const int32_t* __restrict__ labels,
-                                                                       int J, int HW, int W, int K, const float* __restrict__ lse,
+                                                                       int J, int HW, int W, int trows, int K, const float* __restrict__ lse,
                                                                        const double* __restrict__ scale_p, unsigned long long* __restrict__ A_fx) {
     extern __shared__ unsigned long long kld_smem[];
     unsigned long long* tab = kld_smem;                    // [K][J][J], two's complement
@@ -235,7 +264,7 @@ __global__ __launch_bounds__(SPX_KLD_THREADS) void spx_kld_pairs_kernel(const fl
     __syncthreads();
     const float* v = vals + (size_t)b * J * HW;
     const int32_t* lab = labels + (size_t)b * HW;
-    const SpxKldWalk w = spx_kld_walk(HW, W, lane, wave);
+    const SpxKldWalk w = spx_kld_walk(HW, W, trows, lane, wave);
     float acc[JT][JT];
 #pragma unroll
     for (int j = 0; j < JT; ++j)
@@ -249,7 +278,7 @@ __global__ __launch_bounds__(SPX_KLD_THREADS) void spx_kld_pairs_kernel(const fl
 #pragma unroll
             for (int k = 0; k < JT; ++k)
                 if (j != k && j < J && k < J) {
-                    const double s = wave_sum_f64((double)acc[j][k]);
+                    const double s = (double)wave_sum_f32(acc[j][k]);
                     if (lane == 0) atomicAdd(&tab[(cur * J + j) * J + k], (unsigned long long)(long long)llrint(s * scale));
                     acc[j][k] = 0.0f;
                 }
@@ -258,8 +287,11 @@ __global__ __launch_bounds__(SPX_KLD_THREADS) void spx_kld_pairs_kernel(const fl
         const int px = w.first + step * w.stride;
         const int c = step < w.nvalid ? lab[px] : -1;
         const bool ok = c >= 0 && c < K;
-        const int c0 = __builtin_amdgcn_readfirstlane(c);
-        const bool uniform = __builtin_amdgcn_ballot_w64(c != c0) == 0;
+        // lanes without a class (void pixels, lanes past the map) contribute neutral values either way: a step is uniform when
+        // the lanes that HAVE a class agree on it (void borders and ragged tile edges do not send it down the per-lane path)
+        const unsigned long long okm = __builtin_amdgcn_ballot_w64(ok);
+        const int c0 = okm ? __builtin_amdgcn_readlane(c, __builtin_ffsll((long long)okm) - 1) : -1;
+        const bool uniform = __builtin_amdgcn_ballot_w64(ok && c != c0) == 0;
         float l[JT], p[JT];          // JT = J rounded up to a multiple of 4: static indices, padded slots contribute 0
         spx_kld_load_planes(l, v, J, HW, step < w.nvalid ? px : 0);
         const float* lsc = ls + (ok ? c : 0) * J;
@@ -269,7 +301,7 @@ __global__ __launch_bounds__(SPX_KLD_THREADS) void spx_kld_pairs_kernel(const fl
             p[j] = (ok && j < J) ? __expf(l[j]) : 0.0f;
         }
         if (uniform) {
-            if (!ok) continue;                             // a step of void pixels
+            if (okm == 0) continue;                        // a step without a class pixel
             if (c0 != cur) {
                 publish();
                 cur = c0;
@@ -303,6 +335,7 @@ template <int JT>
 __global__ __launch_bounds__(SPX_KLD_THREADS) void spx_kld_backward_kernel(const float* __restrict__ vals, const int32_t* __restrict__ labels,
                                                                           int J, int HW, int K, const float* __restrict__ lse,
                                                                           const float* __restrict__ A, const float* __restrict__ Cf,
+                                                                          const float* __restrict__ cf_scale, int ppw,
                                                                           float* __restrict__ grad) {
     extern __shared__ unsigned long long kld_smem[];
     float* sA = (float*)kld_smem;                          // [K][J][J]
@@ -310,9 +343,10 @@ __global__ __launch_bounds__(SPX_KLD_THREADS) void spx_kld_backward_kernel(const
     float* sL = sC + K * J * J;                            // [K][J]
     float* sR = sL + K * J;                                // [K][J]   sum_j Cf[j][m]
     const int b = blockIdx.y, tid = threadIdx.x;
+    const float cs = cf_scale ? *cf_scale : 1.0f;          // Cf may arrive unnormalised with its factor in device memory
     for (int i = tid; i < K * J * J; i += SPX_KLD_THREADS) {
         sA[i] = A[(size_t)b * K * J * J + i];
-        sC[i] = Cf[(size_t)b * K * J * J + i];
+        sC[i] = Cf[(size_t)b * K * J * J + i] * cs;
     }
     for (int i = tid; i < K * J; i += SPX_KLD_THREADS) sL[i] = lse[(size_t)b * K * J + i];
     __syncthreads();
@@ -336,8 +370,8 @@ __global__ __launch_bounds__(SPX_KLD_THREADS) void spx_kld_backward_kernel(const
     const float* v = vals + (size_t)b * J * HW;
     float* g = grad + (size_t)b * J * HW;
     const int32_t* lab = labels + (size_t)b * HW;
-    const int px_end = min(HW, (int)(blockIdx.x + 1) * SPX_KLD_PX_PER_WG);
-    for (int px = blockIdx.x * SPX_KLD_PX_PER_WG + tid; px < px_end; px += SPX_KLD_THREADS) {
+    const int px_end = min(HW, (int)(blockIdx.x + 1) * ppw);
+    for (int px = blockIdx.x * ppw + tid; px < px_end; px += SPX_KLD_THREADS) {
         const int c = lab[px];
         const bool ok = c >= 0 && c < K;
         float l[JT], p[JT];
@@ -392,32 +426,68 @@ hipError_t spx_launch_kld_lse(const uint32_t* keys, const uint64_t* ssum_fx, int
     return hipGetLastError();
 }
 
-// The [B, K, J, J]-sized algebra between the pair sums and the gradient pass (loss.py:113-142), one workgroup:
+// The [B, K, J, J]-sized algebra between the pair sums and the gradient pass (loss.py:113-142).  One workgroup per segment:
 //   A = a_fx / scale;  kld_jk = (A_jj + A_kk - A_jk - A_kj) / 2;  valid = pair_ok[class][j][k] and the segment has >= 2 pixels;
-//   loss = mean over valid of exp(-kld) (0 when there is none);  Cf = dLoss/dA = (es - diag(rowsum es)) / 2,
-//   es = e + e^T, e = valid * exp(-kld) / n.
-// Sums run in double in a fixed order (thread-strided partials, LDS tree): run-to-run identical.
-__global__ __launch_bounds__(256) void spx_kld_gram_loss_kernel(const long long* __restrict__ a_fx, const double* __restrict__ scale,
-                                                                const unsigned int* __restrict__ counts,
-                                                                const unsigned char* __restrict__ pair_ok, int nseg, int K, int J,
-                                                                float* __restrict__ A, float* __restrict__ E, float* __restrict__ Cf,
-                                                                float* __restrict__ loss) {
-    __shared__ double ssum[256];
-    __shared__ double scnt[256];
-    const int tid = threadIdx.x, JJ = J * J, n = nseg * JJ;
+//   e = valid * exp(-kld);  Cf' = (es - diag(rowsum es)) / 2 with es = e + e^T  (dLoss/dA WITHOUT the 1/n of the mean);
+//   part[seg] = (sum e, number of valid entries).
+// A second, one-workgroup kernel sums the parts in a fixed order: loss = sum e / n (0 when n = 0) and inv = 1 / max(n, 1), the
+// factor the gradient pass applies to Cf'.  (One workgroup for everything took 222 us for 10 crops x 19 classes x 12 x 12.)
+__global__ __launch_bounds__(256) void spx_kld_gram_kernel(const long long* __restrict__ a_fx, const double* __restrict__ scale,
+                                                           const unsigned int* __restrict__ counts,
+                                                           const unsigned char* __restrict__ pair_ok, int K, int J,
+                                                           float* __restrict__ A, float* __restrict__ Cf, double* __restrict__ part) {
+    __shared__ float sA[256], sE[256];
+    __shared__ double ssum[256], scnt[256];
+    const int tid = threadIdx.x, seg = blockIdx.x, JJ = J * J;
+    const int j = tid / J, k = tid - j * J;
+    const bool in = tid < JJ;
     const double inv_scale = 1.0 / *scale;
-    for (int i = tid; i < n; i += 256) A[i] = (float)((double)a_fx[i] * inv_scale);
+    float a = 0.0f;
+    if (in) {
+        a = (float)((double)a_fx[(size_t)seg * JJ + tid] * inv_scale);
+        A[(size_t)seg * JJ + tid] = a;
+    }
+    sA[tid] = a;
     __syncthreads();
+    float e = 0.0f;
+    bool valid = false;
+    if (in) {
+        valid = pair_ok[(size_t)(seg % K) * JJ + tid] && counts[seg] >= 2u;
+        const float kld = 0.5f * (((sA[j * J + j] + sA[k * J + k]) - sA[j * J + k]) - sA[k * J + j]);
+        e = valid ? expf(-kld) : 0.0f;
+    }
+    sE[tid] = e;
+    ssum[tid] = (double)e;
+    scnt[tid] = valid ? 1.0 : 0.0;
+    __syncthreads();
+    if (in) {
+        float v = sE[j * J + k] + sE[k * J + j];
+        if (j == k) {
+            float row = 0.0f;
+            for (int m = 0; m < J; ++m) row += sE[j * J + m] + sE[m * J + j];
+            v -= row;
+        }
+        Cf[(size_t)seg * JJ + tid] = 0.5f * v;
+    }
+    for (int m = 128; m >= 1; m >>= 1) {
+        if (tid < m) {
+            ssum[tid] += ssum[tid + m];
+            scnt[tid] += scnt[tid + m];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        part[2 * seg] = ssum[0];
+        part[2 * seg + 1] = scnt[0];
+    }
+}
+__global__ __launch_bounds__(256) void spx_kld_gram_finish_kernel(const double* __restrict__ part, int nseg, float* __restrict__ loss) {
+    __shared__ double ssum[256], scnt[256];
+    const int tid = threadIdx.x;
     double se = 0.0, sn = 0.0;
-    for (int i = tid; i < n; i += 256) {
-        const int seg = i / JJ, j = (i % JJ) / J, k = i % J;
-        const float* As = A + (size_t)seg * JJ;
-        const bool valid = pair_ok[(size_t)(seg % K) * JJ + j * J + k] && counts[seg] >= 2u;
-        const float kld = 0.5f * (((As[j * J + j] + As[k * J + k]) - As[j * J + k]) - As[k * J + j]);
-        const float e = valid ? expf(-kld) : 0.0f;
-        E[i] = e;
-        se += (double)e;
-        sn += valid ? 1.0 : 0.0;
+    for (int i = tid; i < nseg; i += 256) {
+        se += part[2 * i];
+        sn += part[2 * i + 1];
     }
     ssum[tid] = se;
     scnt[tid] = sn;
@@ -429,50 +499,57 @@ __global__ __launch_bounds__(256) void spx_kld_gram_loss_kernel(const long long*
         }
         __syncthreads();
     }
-    const float inv = 1.0f / (float)(scnt[0] < 1.0 ? 1.0 : scnt[0]);
-    if (tid == 0) *loss = (float)ssum[0] * inv;
-    for (int i = tid; i < n; i += 256) {
-        const int seg = i / JJ, j = (i % JJ) / J, k = i % J;
-        const float* Es = E + (size_t)seg * JJ;
-        float v = (Es[j * J + k] + Es[k * J + j]) * inv;
-        if (j == k) {
-            float row = 0.0f;
-            for (int m = 0; m < J; ++m) row += (Es[j * J + m] + Es[m * J + j]) * inv;
-            v -= row;
-        }
-        Cf[i] = 0.5f * v;
+    if (tid == 0) {
+        const float inv = 1.0f / (float)(scnt[0] < 1.0 ? 1.0 : scnt[0]);
+        loss[0] = (float)ssum[0] * inv;
+        loss[1] = inv;
     }
 }
 hipError_t spx_launch_kld_gram_loss(const int64_t* a_fx, const double* scale, const uint32_t* counts, const uint8_t* pair_ok, int nseg, int K,
-                                    int J, float* A, float* E, float* Cf, float* loss, hipStream_t s) {
-    hipLaunchKernelGGL(spx_kld_gram_loss_kernel, dim3(1), dim3(256), 0, s, (const long long*)a_fx, scale, counts, pair_ok, nseg, K, J, A, E, Cf, loss);
+                                    int J, float* A, float* Cf, double* part, float* loss, hipStream_t s) {
+    hipLaunchKernelGGL(spx_kld_gram_kernel, dim3((unsigned)nseg), dim3(256), 0, s, (const long long*)a_fx, scale, counts, pair_ok, K, J, A, Cf, part);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(spx_kld_gram_finish_kernel, dim3(1), dim3(256), 0, s, (const double*)part, nseg, loss);
     return hipGetLastError();
 }
 
 // (pass 0: t0 = counts, t1 = range keys)
 hipError_t spx_launch_kld(int pass, const float* vals, const int32_t* labels, int B, int J, int HW, int W, int K, const float* t0,
-                          const float* t1, const float* t2, const double* scale, void* out, hipStream_t s) {
+                          const float* t1, const float* t2, const double* scale, void* out, hipStream_t s, const float* cf_scale) {
     dim3 grid((unsigned)((HW + SPX_KLD_PX_PER_WG - 1) / SPX_KLD_PX_PER_WG), (unsigned)B);
     dim3 blk(SPX_KLD_THREADS);
-    if (W > 0 && pass != 3) grid.x = (unsigned)(((W + SPX_KLD_THREADS - 1) / SPX_KLD_THREADS) * ((HW / W + SPX_KLD_STRIP_ROWS - 1) / SPX_KLD_STRIP_ROWS));
+    // rows of a workgroup's tile: 64 (16 steps per wave) on large maps; on small ones (training crops) 32 or 16, so that there
+    // are enough workgroups to fill the chip and a wave's chain of dependent steps is short (each step exposes a load round trip)
+    int trows = SPX_KLD_TILE;
+    if (W > 0 && pass != 3) {
+        const int tiles_x = (W + SPX_KLD_TILE - 1) / SPX_KLD_TILE, H = HW / W;
+        while (trows > 16 && (long long)B * tiles_x * ((H + trows - 1) / trows) < 1024) trows >>= 1;
+        grid.x = (unsigned)(tiles_x * ((H + trows - 1) / trows));
+    }
     if (pass == 0)
-        hipLaunchKernelGGL(spx_kld_max_kernel, grid, blk, (size_t)(K * J + K + 2) * 4, s, vals, labels, J, HW, W, K, (unsigned int*)out, (unsigned int*)t0, (unsigned int*)t1);
+        hipLaunchKernelGGL(spx_kld_max_kernel, grid, blk, (size_t)(K * J + K + 2) * 4, s, vals, labels, J, HW, W, trows, K, (unsigned int*)out, (unsigned int*)t0, (unsigned int*)t1);
     else if (pass == 1)
-        hipLaunchKernelGGL(spx_kld_sumexp_kernel, grid, blk, (size_t)K * J * 12, s, vals, labels, J, HW, W, K, (const unsigned int*)t0, (unsigned long long*)out);
+        hipLaunchKernelGGL(spx_kld_sumexp_kernel, grid, blk, (size_t)K * J * 12, s, vals, labels, J, HW, W, trows, K, (const unsigned int*)t0, (unsigned long long*)out);
     else if (pass == 2) {
         const size_t lds = (size_t)K * J * J * 8 + (size_t)K * J * 4;
         unsigned long long* o = (unsigned long long*)out;
-        if (J <= 4) hipLaunchKernelGGL(spx_kld_pairs_kernel<4>, grid, blk, lds, s, vals, labels, J, HW, W, K, t0, scale, o);
-        else if (J <= 8) hipLaunchKernelGGL(spx_kld_pairs_kernel<8>, grid, blk, lds, s, vals, labels, J, HW, W, K, t0, scale, o);
-        else if (J <= 12) hipLaunchKernelGGL(spx_kld_pairs_kernel<12>, grid, blk, lds, s, vals, labels, J, HW, W, K, t0, scale, o);
-        else hipLaunchKernelGGL(spx_kld_pairs_kernel<16>, grid, blk, lds, s, vals, labels, J, HW, W, K, t0, scale, o);
+        if (J <= 4) hipLaunchKernelGGL(spx_kld_pairs_kernel<4>, grid, blk, lds, s, vals, labels, J, HW, W, trows, K, t0, scale, o);
+        else if (J <= 8) hipLaunchKernelGGL(spx_kld_pairs_kernel<8>, grid, blk, lds, s, vals, labels, J, HW, W, trows, K, t0, scale, o);
+        else if (J <= 12) hipLaunchKernelGGL(spx_kld_pairs_kernel<12>, grid, blk, lds, s, vals, labels, J, HW, W, trows, K, t0, scale, o);
+        else hipLaunchKernelGGL(spx_kld_pairs_kernel<16>, grid, blk, lds, s, vals, labels, J, HW, W, trows, K, t0, scale, o);
     } else {
         const size_t lds = (size_t)(2 * K * J * J + 2 * K * J) * 4;
         float* o = (float*)out;
-        if (J <= 4) hipLaunchKernelGGL(spx_kld_backward_kernel<4>, grid, blk, lds, s, vals, labels, J, HW, K, t0, t1, t2, o);
-        else if (J <= 8) hipLaunchKernelGGL(spx_kld_backward_kernel<8>, grid, blk, lds, s, vals, labels, J, HW, K, t0, t1, t2, o);
-        else if (J <= 12) hipLaunchKernelGGL(spx_kld_backward_kernel<12>, grid, blk, lds, s, vals, labels, J, HW, K, t0, t1, t2, o);
-        else hipLaunchKernelGGL(spx_kld_backward_kernel<16>, grid, blk, lds, s, vals, labels, J, HW, K, t0, t1, t2, o);
+        // pixels per workgroup: 2048 on large maps; small maps (training crops) get enough workgroups to fill the chip - a thread
+        // then takes one pixel instead of walking eight in sequence behind the table set-up (80 -> ~20 us at 10 x 65 x 65)
+        int ppw = SPX_KLD_PX_PER_WG;
+        while (ppw > SPX_KLD_THREADS && (long long)B * ((HW + ppw - 1) / ppw) < 512) ppw >>= 1;
+        grid.x = (unsigned)((HW + ppw - 1) / ppw);
+        if (J <= 4) hipLaunchKernelGGL(spx_kld_backward_kernel<4>, grid, blk, lds, s, vals, labels, J, HW, K, t0, t1, t2, cf_scale, ppw, o);
+        else if (J <= 8) hipLaunchKernelGGL(spx_kld_backward_kernel<8>, grid, blk, lds, s, vals, labels, J, HW, K, t0, t1, t2, cf_scale, ppw, o);
+        else if (J <= 12) hipLaunchKernelGGL(spx_kld_backward_kernel<12>, grid, blk, lds, s, vals, labels, J, HW, K, t0, t1, t2, cf_scale, ppw, o);
+        else hipLaunchKernelGGL(spx_kld_backward_kernel<16>, grid, blk, lds, s, vals, labels, J, HW, K, t0, t1, t2, cf_scale, ppw, o);
     }
     return hipGetLastError();
 }

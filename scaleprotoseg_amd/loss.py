@@ -175,25 +175,27 @@ class _KLDFusedLoss(torch.autograd.Function):
         s = _lib.stream_ptr()
         Wk = int(W) if W and HW % int(W) == 0 else 0
         a_fx, counts, lse, scale = _kld_segment_passes(lib, v, lab, K, Wk, s)
-        out = torch.empty((3 * B * K * J * J + 1,), dtype=torch.float32, device=v.device)
         n = B * K * J * J
-        A, E, cf, loss = out[:n], out[n:2 * n], out[2 * n:3 * n], out[3 * n:]
+        out = torch.empty((2 * n + 2,), dtype=torch.float32, device=v.device)
+        A, cf, loss = out[:n], out[n:2 * n], out[2 * n:]                       # loss = (value, 1 / number of valid pairs)
+        part = torch.empty((2 * B * K,), dtype=torch.float64, device=v.device)
         _lib.check(lib.spx_kld_gram_loss(_lib.ptr(a_fx), _lib.ptr(scale), _lib.ptr(counts), _lib.ptr(pair_ok), B * K, K, J,
-                                         _lib.ptr(A), _lib.ptr(E), _lib.ptr(cf), _lib.ptr(loss), s))
-        ctx.save_for_backward(v, lab, lse, A, cf)
+                                         _lib.ptr(A), _lib.ptr(cf), _lib.ptr(part), _lib.ptr(loss), s))
+        ctx.save_for_backward(v, lab, lse, A, cf, loss)
         ctx.K = K
-        return loss.reshape(())
+        return loss[0].reshape(())
 
     @staticmethod
     def backward(ctx, g):
         from . import _lib
 
         lib = _lib.load()
-        v, lab, lse, A, cf = ctx.saved_tensors
+        v, lab, lse, A, cf, loss = ctx.saved_tensors
         B, J, HW = v.shape
         grad = torch.empty_like(v)
-        cfg = (cf * g).contiguous()
-        _lib.check(lib.spx_kld_backward(_lib.ptr(v), _lib.ptr(lab), B, J, HW, ctx.K, _lib.ptr(lse), _lib.ptr(A), _lib.ptr(cfg), _lib.ptr(grad), _lib.stream_ptr()))
+        coef = (g.reshape(()).float() * loss[1]).reshape(1).contiguous()       # dLoss_total/dloss x 1/n, on the device
+        _lib.check(lib.spx_kld_backward(_lib.ptr(v), _lib.ptr(lab), B, J, HW, ctx.K, _lib.ptr(lse), _lib.ptr(A), _lib.ptr(cf), _lib.ptr(coef),
+                                        _lib.ptr(grad), _lib.stream_ptr()))
         return grad, None, None, None, None
 
 
@@ -229,7 +231,7 @@ class _KLDSegmentGram(torch.autograd.Function):
         B, J, HW = v.shape
         grad = torch.empty_like(v)
         cf = gA.contiguous().float()
-        _lib.check(lib.spx_kld_backward(_lib.ptr(v), _lib.ptr(lab), B, J, HW, ctx.K, _lib.ptr(lse), _lib.ptr(A.contiguous()), _lib.ptr(cf), _lib.ptr(grad), _lib.stream_ptr()))
+        _lib.check(lib.spx_kld_backward(_lib.ptr(v), _lib.ptr(lab), B, J, HW, ctx.K, _lib.ptr(lse), _lib.ptr(A.contiguous()), _lib.ptr(cf), None, _lib.ptr(grad), _lib.stream_ptr()))
         return grad, None, None, None
 
 

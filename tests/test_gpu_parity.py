@@ -1096,11 +1096,11 @@ def test_no_write_outside_the_output_buffers_extended_ops(seed):
     _lib.check(lib.spx_kld_segment_sumexp(cd.ptr, _lib.ptr(labels), B, J, HW, Wk, K, kk.ptr, ssum.ptr, s))
     _lib.check(lib.spx_kld_segment_lse(kk.ptr, ssum.ptr, B * K * J, lse.ptr, rngk.ptr, HW, scale.ptr, s))
     _lib.check(lib.spx_kld_pair_sums(cd.ptr, _lib.ptr(labels), B, J, HW, Wk, K, lse.ptr, scale.ptr, afx.ptr, s))
-    A, E, Cf, kloss = (_Guarded(B * K * J * J * 4, dev), _Guarded(B * K * J * J * 4, dev), _Guarded(B * K * J * J * 4, dev),
-                       _Guarded(4, dev))
+    A, E, Cf, kloss = (_Guarded(B * K * J * J * 4, dev), _Guarded(B * K * 2 * 8, dev), _Guarded(B * K * J * J * 4, dev),
+                       _Guarded(8, dev))
     pair_ok = torch.triu(torch.ones(J, J, dtype=torch.uint8, device=dev), diagonal=1).repeat(K, 1, 1).contiguous()
-    _lib.check(lib.spx_kld_gram_loss(afx.ptr, scale.ptr, cnt.ptr, _lib.ptr(pair_ok), B * K, K, J, A.ptr, E.ptr, Cf.ptr, kloss.ptr, s))
-    _lib.check(lib.spx_kld_backward(cd.ptr, _lib.ptr(labels), B, J, HW, K, lse.ptr, A.ptr, Cf.ptr, grad.ptr, s))
+    _lib.check(lib.spx_kld_gram_loss(afx.ptr, scale.ptr, cnt.ptr, _lib.ptr(pair_ok), B * K, K, J, A.ptr, Cf.ptr, E.ptr, kloss.ptr, s))
+    _lib.check(lib.spx_kld_backward(cd.ptr, _lib.ptr(labels), B, J, HW, K, lse.ptr, A.ptr, Cf.ptr, kloss.ptr + 4, grad.ptr, s))
     # evaluation map: upsample the small map by a non-integer factor
     Ho, Wo = int(rng.integers(H, 5 * H + 3)), int(rng.integers(W, 5 * W + 3))
     src = torch.rand(B, P, H, W, device=dev, generator=g)
@@ -1110,7 +1110,7 @@ def test_no_write_outside_the_output_buffers_extended_ops(seed):
     tag = f"B{B} S{S} Cs{Cs} P{P} K{K} J{J} {H}x{W} -> {Ho}x{Wo}"
     for name, gb in (("class distances", cd), ("logits", logits), ("dX", dx), ("G blob", gs), ("a blob", as_), ("kld keys", kk),
                      ("kld counts", cnt), ("kld sums", ssum), ("kld lse", lse), ("kld pair sums", afx), ("kld grad", grad),
-                     ("kld range keys", rngk), ("kld scale", scale), ("kld A", A), ("kld E", E), ("kld Cf", Cf), ("kld loss", kloss),
+                     ("kld range keys", rngk), ("kld scale", scale), ("kld A", A), ("kld partials", E), ("kld Cf", Cf), ("kld loss", kloss),
                      ("eval idx", eidx), ("eval val", eval_)):
         assert gb.intact(), f"{name}: write outside the buffer ({tag})"
 
