@@ -658,7 +658,8 @@ static int kld_check(const char* who, const float* vals, const int32_t* labels, 
     if (!vals || !labels || !out) return fail("%s: NULL buffer", who);
     if (B < 1 || B > 65535 || HW < 1 || K < 1 || J < 1 || J > 16) return fail("%s: bad sizes (B=%d HW=%d K=%d J=%d; J <= 16)", who, B, HW, K, J);
     if ((long long)J * HW >= (1LL << 31)) return fail("%s: J*HW too large", who);
-    const long long lds = pairs ? (long long)K * J * J * 8 + (long long)K * J * 8 : (long long)K * J * 12 + (long long)K * 4;
+    const long long JT = (J + 3) / 4 * 4;       // the gradient pass pads its table rows to a multiple of four slots
+    const long long lds = pairs ? (long long)K * JT * JT * 8 + (long long)K * JT * 8 : (long long)K * J * 12 + (long long)K * 4;
     if (lds > 60 * 1024) return fail("%s: K*J*J = %d exceeds the LDS table (use the torch path)", who, K * J * J);
     return 0;
 }

@@ -338,33 +338,44 @@ __global__ __launch_bounds__(SPX_KLD_THREADS) void spx_kld_backward_kernel(const
                                                                           const float* __restrict__ cf_scale, int ppw,
                                                                           float* __restrict__ grad) {
     extern __shared__ unsigned long long kld_smem[];
-    float* sA = (float*)kld_smem;                          // [K][J][J]
-    float* sC = sA + K * J * J;                            // [K][J][J]
-    float* sL = sC + K * J * J;                            // [K][J]
-    float* sR = sL + K * J;                                // [K][J]   sum_j Cf[j][m]
+    // tables with rows padded to JT floats (16-B aligned: a pixel reads a row with ds_read_b128; lanes of one class broadcast)
+    float* sC = (float*)kld_smem;                          // [K][JT][JT]  Cf, diagonal fixed below
+    float* sT = sC + K * JT * JT;                          // [K][JT][JT]  first A, then Cf transposed
+    float* sL = sT + K * JT * JT;                          // [K][JT]      lse
+    float* sR = sL + K * JT;                               // [K][JT]      sum_j Cf[j][m] + sum_k Cf[m][k] A[m][k]
     const int b = blockIdx.y, tid = threadIdx.x;
     const float cs = cf_scale ? *cf_scale : 1.0f;          // Cf may arrive unnormalised with its factor in device memory
-    for (int i = tid; i < K * J * J; i += SPX_KLD_THREADS) {
-        sA[i] = A[(size_t)b * K * J * J + i];
-        sC[i] = Cf[(size_t)b * K * J * J + i] * cs;
+    for (int i = tid; i < K * JT * JT; i += SPX_KLD_THREADS) {
+        const int c = i / (JT * JT), m = (i / JT) % JT, k = i % JT;
+        const bool in = m < J && k < J;
+        const size_t src = (size_t)b * K * J * J + ((size_t)c * J + m) * J + k;
+        sT[i] = in ? A[src] : 0.0f;
+        sC[i] = in ? Cf[src] * cs : 0.0f;
     }
-    for (int i = tid; i < K * J; i += SPX_KLD_THREADS) sL[i] = lse[(size_t)b * K * J + i];
+    for (int i = tid; i < K * JT; i += SPX_KLD_THREADS) sL[i] = (i % JT) < J ? lse[(size_t)b * K * J + (i / JT) * J + (i % JT)] : 0.0f;
     __syncthreads();
     // A holds A[j][k] - A[j][j] (pass 2), so dLoss/d(Gram) has the off-diagonal entries of Cf and zero row sums;
     // with zero row sums the A[m][m] offset drops out of sum_k Cf[m][k] (l_k - A[m][k]) below
-    for (int i = tid; i < K * J; i += SPX_KLD_THREADS) {
-        const int c = i / J, m = i - c * J;
-        float s = 0.0f;
+    for (int i = tid; i < K * JT; i += SPX_KLD_THREADS) {
+        const int c = i / JT, m = i % JT;
+        float sum = 0.0f;
         for (int k = 0; k < J; ++k)
-            if (k != m) s += sC[(c * J + m) * J + k];
-        sC[(c * J + m) * J + m] = -s;
+            if (k != m) sum += sC[(c * JT + m) * JT + k];
+        if (m < J) sC[(c * JT + m) * JT + m] = -sum;
     }
     __syncthreads();
-    for (int i = tid; i < K * J; i += SPX_KLD_THREADS) {
-        const int c = i / J, m = i - c * J;
-        float s = 0.0f;
-        for (int j = 0; j < J; ++j) s += sC[(c * J + j) * J + m];
-        sR[i] = s;
+    // per (class, m): everything of the gradient that does not depend on the pixel
+    for (int i = tid; i < K * JT; i += SPX_KLD_THREADS) {
+        const int c = i / JT, m = i % JT;
+        float sum = 0.0f;
+        for (int j = 0; j < J; ++j) sum += sC[(c * JT + j) * JT + m];
+        for (int k = 0; k < J; ++k) sum += sC[(c * JT + m) * JT + k] * sT[(c * JT + m) * JT + k];
+        sR[i] = sum;
+    }
+    __syncthreads();
+    for (int i = tid; i < K * JT * JT; i += SPX_KLD_THREADS) {
+        const int c = i / (JT * JT), m = (i / JT) % JT, k = i % JT;
+        sT[i] = sC[(c * JT + k) * JT + m];                 // Cf^T: the second dot product reads rows too
     }
     __syncthreads();
     const float* v = vals + (size_t)b * J * HW;
@@ -376,28 +387,29 @@ __global__ __launch_bounds__(SPX_KLD_THREADS) void spx_kld_backward_kernel(const
         const bool ok = c >= 0 && c < K;
         float l[JT], p[JT];
         spx_kld_load_planes(l, v, J, HW, px);
-        const float* slc = sL + (ok ? c : 0) * J;
+        const float* slc = sL + (ok ? c : 0) * JT;
 #pragma unroll
         for (int j = 0; j < JT; ++j) {
-            l[j] = (ok && j < J) ? l[j] - slc[min(j, J - 1)] : 0.0f;
+            l[j] = (ok && j < J) ? l[j] - slc[j] : 0.0f;
             p[j] = (ok && j < J) ? __expf(l[j]) : 0.0f;
         }
+        const int cb = (ok ? c : 0) * JT;
 #pragma unroll
         for (int m = 0; m < JT; ++m) {
             if (m < J) {
-                float out = 0.0f;
-                if (ok) {
-                    float s1 = -sR[c * J + m], s2 = 0.0f;
+                // dLoss/dd_m = p_m (sum_k Cf[m][k] l_k - R[m]) + sum_k Cf[k][m] p_k      (padded entries are zero)
+                float s1 = -sR[cb + m], s2 = 0.0f;
 #pragma unroll
-                    for (int k = 0; k < JT; ++k) {
-                        if (k < J) {
-                            s1 += sC[(c * J + m) * J + k] * (l[k] - sA[(c * J + m) * J + k]);
-                            s2 += sC[(c * J + k) * J + m] * p[k];
-                        }
+                for (int k4 = 0; k4 < JT / 4; ++k4) {
+                    const f32x4 cr = *(const f32x4*)(sC + (cb + m) * JT + 4 * k4);
+                    const f32x4 ct = *(const f32x4*)(sT + (cb + m) * JT + 4 * k4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        s1 = fmaf(cr[e], l[4 * k4 + e], s1);
+                        s2 = fmaf(ct[e], p[4 * k4 + e], s2);
                     }
-                    out = p[m] * s1 + s2;
                 }
-                g[(size_t)m * HW + px] = out;
+                g[(size_t)m * HW + px] = ok ? fmaf(p[m], s1, s2) : 0.0f;
             }
         }
     }
@@ -539,7 +551,8 @@ hipError_t spx_launch_kld(int pass, const float* vals, const int32_t* labels, in
         else if (J <= 12) hipLaunchKernelGGL(spx_kld_pairs_kernel<12>, grid, blk, lds, s, vals, labels, J, HW, W, trows, K, t0, scale, o);
         else hipLaunchKernelGGL(spx_kld_pairs_kernel<16>, grid, blk, lds, s, vals, labels, J, HW, W, trows, K, t0, scale, o);
     } else {
-        const size_t lds = (size_t)(2 * K * J * J + 2 * K * J) * 4;
+        const int JT = J <= 4 ? 4 : (J <= 8 ? 8 : (J <= 12 ? 12 : 16));
+        const size_t lds = (size_t)(2 * K * JT * JT + 2 * K * JT) * 4;
         float* o = (float*)out;
         // pixels per workgroup: 2048 on large maps; small maps (training crops) get enough workgroups to fill the chip - a thread
         // then takes one pixel instead of walking eight in sequence behind the table set-up (80 -> ~20 us at 10 x 65 x 65)

@@ -133,7 +133,8 @@ class _SegmentGather(torch.autograd.Function):
 
 
 def _kld_kernels_usable(vals: torch.Tensor, K: int, J: int) -> bool:
-    return vals.is_cuda and vals.dtype == torch.float32 and J <= 16 and K * J * J * 8 + K * J * 8 <= 60 * 1024
+    jt = (J + 3) // 4 * 4                 # the gradient pass pads its table rows to a multiple of four slots
+    return vals.is_cuda and vals.dtype == torch.float32 and J <= 16 and K * jt * jt * 8 + K * jt * 8 <= 60 * 1024
 
 
 def _kld_segment_passes(lib, v, lab, K, Wk, s):
