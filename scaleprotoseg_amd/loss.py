@@ -5,8 +5,9 @@ The reference's KLDLoss reads, for a pixel of class c, only the distance columns
 (loss.py:89-107).  ``ClassDistances`` carries exactly those entries ([B, J, H*W] slot planes, produced by the fused kernels
 with ``forward_from_conv_features(..., target_labels=...)``), so the fp32 [B, P, H, W] map and its gradient never
 cross HBM.  ``KLDLoss`` accepts either form and returns the same value; on fp32 GPU tensors the pixel loops run in the
-HIP kernels of csrc/spx_kld.hip (differentiable through ``ClassDistances.values``); the vectorised torch form of the
-same algebra is opt-in (``torch_formulation=True``), never a silent fallback.
+HIP kernels of csrc/spx_kld.hip (differentiable through ``ClassDistances.values``).  There is no other backend: inputs the
+kernels do not take (CPU tensors, fp64, more than 16 slots per class) raise ``SpxError``.  (The torch restatement of the same
+algebra that the tests hold the kernels against is test infrastructure and lives outside the package.)
 """
 from __future__ import annotations
 
@@ -56,19 +57,6 @@ def gather_class_distances(prototype_distances: torch.Tensor, labels0: torch.Ten
     return torch.where(valid, out, torch.zeros_like(out))
 
 
-def _pixel_outer(a: torch.Tensor, b: torch.Tensor, chunk: int = 4096) -> torch.Tensor:
-    """a^T . b for tall-skinny [M, n] operands (M = pixels): chunked batched product + one sum (a plain
-    ``a.t() @ b`` runs as a single-workgroup-shaped GEMM on the GPU)."""
-    M = a.shape[0]
-    n = M // chunk
-    out = torch.zeros((a.shape[1], b.shape[1]), dtype=a.dtype, device=a.device)
-    if n:
-        out = out + torch.bmm(a[: n * chunk].reshape(n, chunk, -1).transpose(1, 2), b[: n * chunk].reshape(n, chunk, -1)).sum(0)
-    if M % chunk:
-        out = out + a[n * chunk :].t() @ b[n * chunk :]
-    return out
-
-
 class PixelWiseCrossEntropyLoss(nn.Module):
     """Drop-in for segmentation/model/loss.py:9-48: cross entropy over the [..., K] logits with labels shifted by one
     (1..K -> 0..K-1; the training modules pass ``ignore_index=-1`` so that void = 0 is skipped,
@@ -77,15 +65,12 @@ class PixelWiseCrossEntropyLoss(nn.Module):
     On GPU tensors the loss runs in HIP: if the logits come from ``forward_from_conv_features(..., ce_target=target)``
     the value was already computed in the logits epilogue (``logits.spx_ce``, SURVEY.md 8f-1) and is returned as is;
     otherwise the stand-alone kernels of csrc/spx_ce.hip run.  Labels outside 0..K-1 other than ``ignore_index`` make
-    torch raise; here they are ignored.  ``torch_formulation`` (keyword-only, not in the reference) allows the stock
-    torch form for tensors that are not on the GPU - off by default: no silent fallback."""
+    torch raise; here they are ignored.  Logits that are not on the GPU raise ``SpxError``: there is no other backend."""
 
-    def __init__(self, ignore_index: int = 255, return_correct: bool = False, *, torch_formulation: bool = False) -> None:
+    def __init__(self, ignore_index: int = 255, return_correct: bool = False) -> None:
         super().__init__()
-        self.loss = nn.CrossEntropyLoss(ignore_index=ignore_index)
         self.return_correct = return_correct
         self.ignore_index = ignore_index
-        self.torch_formulation = torch_formulation
 
     def forward(self, predicted_logits: torch.Tensor, target_labels: torch.Tensor):
         fused = getattr(predicted_logits, "spx_ce", None)
@@ -104,32 +89,7 @@ class PixelWiseCrossEntropyLoss(nn.Module):
             correct = fused.pred.reshape(-1).to(labels0.dtype) == labels0
             mask = (labels0 != self.ignore_index).nonzero().squeeze()                             # loss.py:43-46
             return fused.loss, correct[mask]
-        if not self.torch_formulation:
-            raise SpxError(f"cross entropy: logits on {predicted_logits.device}; the loss runs on the GPU "
-                           "(pass torch_formulation=True to allow the stock torch form - there is no silent fallback)")
-        predicted_logits = predicted_logits.reshape(-1, K)
-        target_labels = target_labels.reshape(-1) - 1
-        loss = self.loss(predicted_logits, target_labels)
-        if not self.return_correct:
-            return loss
-        correct = torch.argmax(predicted_logits, dim=-1) == target_labels
-        mask = (target_labels != self.ignore_index).nonzero().squeeze()
-        return loss, correct[mask]
-
-
-class _SegmentGather(torch.autograd.Function):
-    """rows[seg] whose backward is a segment sum (index_add) instead of autograd's index_put on duplicate indices."""
-
-    @staticmethod
-    def forward(ctx, rows, seg):
-        ctx.save_for_backward(seg)
-        ctx.n = rows.shape[0]
-        return rows[seg]
-
-    @staticmethod
-    def backward(ctx, g):
-        (seg,) = ctx.saved_tensors
-        return torch.zeros((ctx.n, g.shape[1]), device=g.device, dtype=g.dtype).index_add_(0, seg, g), None
+        raise SpxError(f"cross entropy: logits on {predicted_logits.device}; the loss runs on the GPU only (no CPU fallback)")
 
 
 def _kld_kernels_usable(vals: torch.Tensor, K: int, J: int) -> bool:
@@ -200,40 +160,21 @@ class _KLDFusedLoss(torch.autograd.Function):
         return grad, None, None, None, None
 
 
-class _KLDSegmentGram(torch.autograd.Function):
-    """(A [B,K,J,J], lse [B,K,J]) of class-gathered distances through the HIP kernels (csrc/spx_kld.hip): A[seg][j][k] =
-    sum_px p_j (l_k - l_j) = -KL(j || k), l the log_softmax over the segment's pixels (the Gram matrix sum p_j l_k of
-    the torch path minus its row's diagonal entry: the loss only uses those differences).  Backward: dLoss/dvals from dLoss/dA, per pixel."""
+def segment_pair_sums(planes: torch.Tensor, labels0: torch.Tensor, K: int, W: int = 0) -> torch.Tensor:
+    """A [B, K, J, J] = sum over the segment's pixels of p_j (l_k - l_j) (= -KL(j || k); diagonal 0) of class-gathered planes
+    [B, J, H*W] through the three reduction passes of csrc/spx_kld.hip - what ``KLDLoss`` builds its value from (no autograd;
+    diagnostics and tests).  ``W``: row length of the pixel grid (0 = unknown: linear walk)."""
+    from . import _lib
 
-    @staticmethod
-    def forward(ctx, vals, labels, K, W=0):
-        from . import _lib
-
-        lib = _lib.load()
-        B, J, HW = vals.shape
-        v = vals.detach().contiguous()
-        lab = labels.to(device=v.device, dtype=torch.int32).contiguous()
-        dev = v.device
-        s = _lib.stream_ptr()
-        Wk = int(W) if W and HW % int(W) == 0 else 0          # traversal hint of the reduction passes
-        a_fx, counts, lse, scale = _kld_segment_passes(lib, v, lab, K, Wk, s)
-        A = (a_fx.to(torch.float64) / scale).float()
-        ctx.save_for_backward(v, lab, lse, A)
-        ctx.K = K
-        ctx.mark_non_differentiable(lse, counts)
-        return A, lse, counts
-
-    @staticmethod
-    def backward(ctx, gA, _g_lse, _g_counts):
-        from . import _lib
-
-        lib = _lib.load()
-        v, lab, lse, A = ctx.saved_tensors
-        B, J, HW = v.shape
-        grad = torch.empty_like(v)
-        cf = gA.contiguous().float()
-        _lib.check(lib.spx_kld_backward(_lib.ptr(v), _lib.ptr(lab), B, J, HW, ctx.K, _lib.ptr(lse), _lib.ptr(A.contiguous()), _lib.ptr(cf), None, _lib.ptr(grad), _lib.stream_ptr()))
-        return grad, None, None, None
+    lib = _lib.load()
+    v = planes.detach().contiguous()
+    B, J, HW = v.shape
+    if not _kld_kernels_usable(v, K, J):
+        raise SpxError(f"segment_pair_sums: input {tuple(v.shape)} {v.dtype} on {v.device} is outside the HIP kernels' domain")
+    lab = labels0.to(device=v.device, dtype=torch.int32).contiguous()
+    Wk = int(W) if W and HW % int(W) == 0 else 0
+    a_fx, _, _, scale = _kld_segment_passes(lib, v, lab, K, Wk, _lib.stream_ptr())
+    return (a_fx.to(torch.float64) / scale).float()
 
 
 class KLDLoss(nn.Module):
@@ -242,16 +183,11 @@ class KLDLoss(nn.Module):
     ``ClassDistances``.  One pass of segment reductions instead of the reference's (image, class, scale, pair)
     Python loops with host syncs."""
 
-    def __init__(self, prototype_class_identity: torch.Tensor, num_scales: int, scale_num_prototypes: Dict[int, Tuple[int, int]],
-                 *, torch_formulation: bool = False) -> None:
-        """``torch_formulation`` (keyword-only, not in the reference): allow the vectorised torch form of the loss for
-        inputs the HIP kernels do not take (not on the GPU, not fp32, J > 16 or K*J*J beyond the LDS table).  Off by
-        default: like the rest of the package the loss then REFUSES such inputs instead of silently leaving the GPU path."""
+    def __init__(self, prototype_class_identity: torch.Tensor, num_scales: int, scale_num_prototypes: Dict[int, Tuple[int, int]]) -> None:
         super().__init__()
         self.prototype_class_identity = prototype_class_identity
         self.num_scales = num_scales
         self.scale_num_prototypes = scale_num_prototypes
-        self.torch_formulation = torch_formulation
 
     def _slot_table(self) -> torch.Tensor:
         """class_slot_table of the loss's identity, built once per identity OBJECT and in-place version (a strong
@@ -323,46 +259,10 @@ class KLDLoss(nn.Module):
             # the gathered planes on the GPU: segment statistics and the gradient run in the HIP kernels; nothing on
             # this path reads a value back to the host (capturable in a HIP graph)
             return _KLDFusedLoss.apply(planes, lab, K, width, self._pair_mask_u8(table, dev))
-        if not self.torch_formulation:
-            raise SpxError(
-                f"KLD loss: input {tuple(vals.shape)} {vals.dtype} on {vals.device} (K={K}, J={J}) is outside the HIP kernels' "
-                "domain (fp32 on the GPU, J <= 16, K*J*J*8 + K*J*8 <= 60 KiB); pass torch_formulation=True to the "
-                "constructor to allow the torch form - there is no silent fallback"
-            )
-        ok = ((lab >= 0) & (lab < K)).reshape(-1)
-        if not bool(ok.any()):
-            return torch.tensor(0.0)
-        # (image, class) segment of every pixel; pixels without a class go to a dummy segment that is dropped below
-        seg = (torch.arange(B, device=dev).unsqueeze(1) * K + lab.clamp(0, K - 1)).reshape(-1)
-        seg = torch.where(ok, seg, torch.full_like(seg, nseg))
-        d = vals.reshape(-1, J)                                          # [N, J], every pixel
-        count = torch.bincount(seg, minlength=nseg + 1)[:nseg]
-        # log_softmax over the segment's pixels, per slot (loss.py:110).  The shift is the slot's GLOBAL maximum and the
-        # sums run in fp64 (distances are bounded by the channel count, far inside exp's fp64 range), so no per-segment
-        # maximum - an atomics-bound scatter - is needed.
-        gm = d.detach().amax(dim=0)
-        e = torch.exp((d - gm).double())
-        ssum = torch.zeros((nseg + 1, J), device=dev, dtype=torch.float64)
-        cstep = max(4096, ((1 << 24) // (nseg + 1)) // 4096 * 4096)
-        for i in range(0, d.shape[0], cstep):        # segment sums as one-hot products (fp64 atomics are slow)
-            oh = torch.nn.functional.one_hot(seg[i:i + cstep], nseg + 1).to(torch.float64)
-            ssum = ssum + _pixel_outer(oh, e[i:i + cstep])
-        lse = (gm.double() + torch.log(ssum.clamp_min(1e-300))).to(d.dtype)
-        logp = d - _SegmentGather.apply(lse, seg)
-        p = torch.exp(logp)
-        # symmetric KL of every slot pair (loss.py:129-136): 0.5 * sum_px (p_j - p_k)(logp_j - logp_k)
-        #   = 0.5 * (A_jj + A_kk - A_jk - A_kj),  A[seg] = P_seg^T . L_seg  ([J, J] per (image, class) segment).
-        # A is ONE tall-skinny product per pixel chunk: rows of Z = p scattered into the pixel's segment block.
-        ns1 = nseg + 1
-        A = torch.zeros((ns1 * J, J), device=dev, dtype=d.dtype)
-        step = max(4096, ((1 << 26) // max(1, ns1 * J)) // 4096 * 4096)
-        for i in range(0, d.shape[0], step):
-            lp, pp, sg = logp[i:i + step], p[i:i + step], seg[i:i + step]
-            z = torch.zeros((pp.shape[0], ns1, J), device=dev, dtype=d.dtype)
-            z = z.scatter(1, sg.view(-1, 1, 1).expand(-1, 1, J), pp.unsqueeze(1))
-            A = A + _pixel_outer(z.view(pp.shape[0], ns1 * J), lp)
-        A = A.view(ns1, J, J)[:nseg]
-        return self._loss_from_gram(A, count, table, K, nseg)
+        raise SpxError(
+            f"KLD loss: input {tuple(vals.shape)} {vals.dtype} on {vals.device} (K={K}, J={J}) is outside the HIP kernels' "
+            "domain (fp32 on the GPU, J <= 16, K*J*J*8 + K*J*8 <= 60 KiB); there is no other backend"
+        )
 
     def _pair_mask_u8(self, table: torch.Tensor, dev) -> torch.Tensor:
         """The [K, J, J] pair mask as uint8 on ``dev`` (cached with the mask it is made from)."""
@@ -373,35 +273,6 @@ class KLDLoss(nn.Module):
             self._pair_u8_cache = c
         return c[1]
 
-    def _loss_from_gram(self, A: torch.Tensor, count: torch.Tensor, table: torch.Tensor, K: int, nseg: int) -> torch.Tensor:
-        """Symmetric KL of the slot pairs from the segment Gram matrices, exp(-kld), mean (loss.py:113-142)."""
-        pair_ok = self._pair_mask(table).to(A.device)                               # [K, J, J]
-        J = pair_ok.shape[-1]
-        valid = (pair_ok.unsqueeze(0) & (count.reshape(-1, K, 1, 1) >= 2)).reshape(nseg, J, J)   # loss.py:113-127 (len < 2 skipped)
-        return _GramLoss.apply(A, valid)
-
-
-class _GramLoss(torch.autograd.Function):
-    """mean over the valid (segment, j < k) entries of exp(-kld), kld = (A_jj + A_kk - A_jk - A_kj) / 2, 0.0 when there is
-    none (loss.py:129-144) - without a dynamic shape, and with the closed-form gradient (autograd through the dozen
-    tiny ops costs more GPU time than the segment kernels at 2 Mpx)."""
-
-    @staticmethod
-    def forward(ctx, A, valid):
-        diag = torch.diagonal(A, dim1=1, dim2=2)
-        kld = 0.5 * (diag.unsqueeze(2) + diag.unsqueeze(1) - A - A.transpose(1, 2))
-        n = valid.sum()
-        e = torch.where(valid, torch.exp(-kld), torch.zeros_like(kld))
-        inv = 1.0 / n.clamp_min(1).to(e.dtype)
-        ctx.save_for_backward(e * inv)
-        return e.sum() * inv                                   # n == 0: every term is masked, the sum is 0.0
-
-    @staticmethod
-    def backward(ctx, g):
-        (e,) = ctx.saved_tensors                               # E_jk = valid * exp(-kld_jk) / n;  dLoss/dkld_jk = -E_jk
-        es = e + e.transpose(1, 2)
-        return g * 0.5 * (es - torch.diag_embed(es.sum(dim=2))), None
-
 
 class KLDLossGroup(KLDLoss):
     """Drop-in for segmentation/model/loss.py:461-545: same constructor, same ``forward(list_group_activation,
@@ -409,13 +280,11 @@ class KLDLossGroup(KLDLoss):
     pair of a class is compared, loss.py:527-536), so the segment kernels are shared; ``list_group_activation`` may
     also be the concatenated [M, n_projections * num_groups] tensor the grouping head produces."""
 
-    def __init__(self, prototype_class_identity: torch.Tensor, group_class_identity: torch.Tensor, num_groups: int,
-                 *, torch_formulation: bool = False) -> None:
+    def __init__(self, prototype_class_identity: torch.Tensor, group_class_identity: torch.Tensor, num_groups: int) -> None:
         nn.Module.__init__(self)
         self.prototype_class_identity = prototype_class_identity
         self.group_class_identity = group_class_identity
         self.num_groups = num_groups
-        self.torch_formulation = torch_formulation
         self._tables = None
 
     def _class_tables(self):
@@ -441,7 +310,8 @@ class KLDLossGroup(KLDLoss):
             self._pair_mask_cache = cached
         return cached[2]
 
-    def forward(self, list_group_activation, target_labels: torch.Tensor) -> torch.Tensor:
+    def _gather_groups(self, list_group_activation, target_labels: torch.Tensor):
+        """(vals [B, HW, G]: the group activations of the pixel's class, labels0 [B, HW], stand-in slot table [K, G])."""
         G = self.num_groups
         labels0 = target_labels.reshape(target_labels.shape[0], -1).long() - 1          # loss.py:493
         B, HW = labels0.shape
@@ -455,4 +325,8 @@ class KLDLossGroup(KLDLoss):
         lab = labels0.to(dev)
         pix_proj = proj.to(dev)[lab.clamp(0, K - 1)].clamp_min(0)                       # [B, HW]; unused where no class
         vals = torch.gather(ga, 2, pix_proj.view(B, HW, 1, 1).expand(B, HW, 1, G)).squeeze(2)      # [B, HW, G]
+        return vals, labels0, table
+
+    def forward(self, list_group_activation, target_labels: torch.Tensor) -> torch.Tensor:
+        vals, labels0, table = self._gather_groups(list_group_activation, target_labels)
         return self._forward_gathered(vals, None, labels0, table, target_labels.shape[-1] if target_labels.dim() >= 3 else 0)

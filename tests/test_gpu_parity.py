@@ -17,6 +17,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
+from oracle import loss_oracle as LO
 from oracle import ppnet_oracle as O
 
 
@@ -844,10 +845,10 @@ def test_kld_kernels_large_random():
         v1 = base.clone().requires_grad_(True)
         l1 = loss_fn(spx.ClassDistances(v1, (t.reshape(1, -1) - 1).int(), table, (H, W)), t)
         l1.backward()
-        v2 = base.double().clone().requires_grad_(True)                      # fp64 -> the (opt-in) torch form
+        v2 = base.double().clone().requires_grad_(True)                      # fp64 -> the oracle's torch restatement
         with pytest.raises(spx.SpxError):
-            loss_fn(spx.ClassDistances(v2, (t.reshape(1, -1) - 1).int(), table, (H, W)), t)      # never a silent fallback
-        l2 = spx.KLDLoss(ident, S, {0: (0, P)}, torch_formulation=True)(spx.ClassDistances(v2, (t.reshape(1, -1) - 1).int(), table, (H, W)), t)
+            loss_fn(spx.ClassDistances(v2, (t.reshape(1, -1) - 1).int(), table, (H, W)), t)      # the product has no other backend
+        l2 = LO.kld_loss(loss_fn, spx.ClassDistances(v2, (t.reshape(1, -1) - 1).int(), table, (H, W)), t)
         l2.backward()
         torch.cuda.synchronize()
         assert abs(l1.item() - l2.item()) <= 1e-5 * max(1.0, abs(l2.item())), (l1.item(), l2.item())
@@ -900,7 +901,7 @@ def test_kld_kernels_ragged_grids(H, W):
     loss_fn = spx.KLDLoss(ident, S, {0: (0, P)})
     lab = (t.reshape(2, -1) - 1).int()
     v2 = base.double().clone().requires_grad_(True)
-    l2 = spx.KLDLoss(ident, S, {0: (0, P)}, torch_formulation=True)(spx.ClassDistances(v2, lab, table, (H, W)), t)
+    l2 = LO.kld_loss(loss_fn, spx.ClassDistances(v2, lab, table, (H, W)), t)
     l2.backward()
     for grid in ((H, W), (1, H * W)):               # column strips / one row (= the linear order)
         v1 = base.clone().requires_grad_(True)
@@ -911,8 +912,8 @@ def test_kld_kernels_ragged_grids(H, W):
         s = v2.grad.abs().max().item()
         assert (v1.grad.double() - v2.grad).abs().max().item() <= 1e-4 * s + 1e-12
     # W = 0 through the C ABI gives the same sums as the column walk up to fp32 rounding of partial sums
-    A_w, _, _ = L._KLDSegmentGram.apply(base, lab, K, W)
-    A_0, _, _ = L._KLDSegmentGram.apply(base, lab, K, 0)
+    A_w = L.segment_pair_sums(base, lab, K, W)
+    A_0 = L.segment_pair_sums(base, lab, K, 0)
     assert (A_w - A_0).abs().max().item() <= 1e-5 * (1.0 + A_0.abs().max().item())
 
 

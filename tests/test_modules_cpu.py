@@ -140,9 +140,11 @@ def test_resize_label_matches_pil_sampling():
 
 @pytest.mark.parametrize("tag", ["a", "b", "c"])
 def test_kld_loss_module_matches_reference(golden, tag):
-    """scaleprotoseg_amd.loss.KLDLoss (vectorised torch, host logic) against the reference's golden value and
-    gradient, on the full map and on the class-gathered form."""
+    """scaleprotoseg_amd.loss.KLDLoss's host logic (slot table, pair mask, class gather) under the oracle's torch restatement of
+    the algebra (oracle/loss_oracle.py) against the reference's golden value and gradient, on the full map and on the
+    class-gathered form.  (The HIP kernels are held against the same oracle in fp64 by tests/test_gpu_parity.py.)"""
     import numpy as np
+    from oracle import loss_oracle as LO
     from oracle import ppnet_oracle as O
     from scaleprotoseg_amd.loss import ClassDistances, KLDLoss, class_slot_table, gather_class_distances
 
@@ -152,7 +154,8 @@ def test_kld_loss_module_matches_reference(golden, tag):
     S = int(g[f"{tag}_S"])
     ranges = {s: tuple(int(v) for v in g[f"{tag}_ranges"][s]) for s in range(S)}
     d = torch.from_numpy(g[f"{tag}_dist"]).requires_grad_(True)
-    loss = KLDLoss(ident, S, ranges, torch_formulation=True)(d, t)
+    mod = KLDLoss(ident, S, ranges)              # the product's host logic (slot table, pair mask); the algebra: the oracle's
+    loss = LO.kld_loss(mod, d, t)
     loss.backward()
     assert abs(loss.item() - float(g[f"{tag}_loss"])) <= 1e-6
     scale = np.abs(g[f"{tag}_grad"]).max()
@@ -162,7 +165,7 @@ def test_kld_loss_module_matches_reference(golden, tag):
     lab0 = t.reshape(t.shape[0], -1) - 1
     cv = gather_class_distances(torch.from_numpy(g[f"{tag}_dist"]), lab0, table)
     assert torch.equal(cv, O.gather_class_distances(torch.from_numpy(g[f"{tag}_dist"]), lab0, ident))
-    lg = KLDLoss(ident, S, ranges, torch_formulation=True)(ClassDistances(cv.permute(0, 2, 1).contiguous(), lab0, table, tuple(t.shape[1:])), t)
+    lg = LO.kld_loss(mod, ClassDistances(cv.permute(0, 2, 1).contiguous(), lab0, table, tuple(t.shape[1:])), t)
     assert abs(lg.item() - float(g[f"{tag}_loss"])) <= 1e-6
 
 
@@ -171,7 +174,9 @@ def test_kld_loss_no_terms():
     from oracle import ppnet_oracle as O
 
     ident = O.default_class_identity(8, 4, 1)
-    assert KLDLoss(ident, 1, {0: (0, 8)}, torch_formulation=True)(torch.rand(1, 8, 3, 3), torch.zeros(1, 3, 3, dtype=torch.long)).item() == 0.0
+    from oracle import loss_oracle as LO
+
+    assert LO.kld_loss(KLDLoss(ident, 1, {0: (0, 8)}), torch.rand(1, 8, 3, 3), torch.zeros(1, 3, 3, dtype=torch.long)).item() == 0.0
 
 
 def test_reference_state_dict_after_push_dedup(tmp_path, golden):
@@ -277,7 +282,11 @@ def test_cross_entropy_matches_reference(golden):
 
     g = golden("kld_loss")
     lg = torch.from_numpy(g["ce_logits"]).requires_grad_(True)
-    ce, correct = PixelWiseCrossEntropyLoss(ignore_index=-1, return_correct=True, torch_formulation=True)(lg, torch.from_numpy(g["ce_target"]))
+    from oracle import loss_oracle as LO
+
+    ce, correct = LO.pixelwise_cross_entropy(lg, torch.from_numpy(g["ce_target"]), ignore_index=-1, return_correct=True)
+    with pytest.raises(spx.SpxError):            # the product class has no CPU backend
+        PixelWiseCrossEntropyLoss(ignore_index=-1)(lg, torch.from_numpy(g["ce_target"]))
     ce.backward()
     assert abs(ce.item() - float(g["ce_loss"])) <= 1e-6
     np.testing.assert_allclose(lg.grad.numpy(), g["ce_grad"], atol=1e-7)
@@ -285,7 +294,7 @@ def test_cross_entropy_matches_reference(golden):
 
 
 def test_kld_loss_group_module_matches_reference(golden):
-    """scaleprotoseg_amd.loss.KLDLossGroup (host logic, torch formulation on the CPU) against the reference's golden
+    """scaleprotoseg_amd.loss.KLDLossGroup (host logic; algebra: oracle/loss_oracle.py) against the reference's golden
     value and gradients; list input (the reference's) and the concatenated [M, U] tensor give the same loss."""
     import numpy as np
     from scaleprotoseg_amd.loss import KLDLossGroup
@@ -294,16 +303,18 @@ def test_kld_loss_group_module_matches_reference(golden):
     n = int(g["grp_n"])
     acts = [torch.from_numpy(g[f"grp_act{i}"]).requires_grad_(True) for i in range(n)]
     t = torch.from_numpy(g["grp_target"])
-    m = KLDLossGroup(torch.from_numpy(g["grp_ident"]), torch.from_numpy(g["grp_gci"]), int(g["grp_G"]), torch_formulation=True)
-    loss = m(acts, t)
+    from oracle import loss_oracle as LO
+
+    m = KLDLossGroup(torch.from_numpy(g["grp_ident"]), torch.from_numpy(g["grp_gci"]), int(g["grp_G"]))
+    loss = LO.kld_group_loss(m, acts, t)
     loss.backward()
     assert abs(loss.item() - float(g["grp_loss"])) <= 1e-6
     for i, a in enumerate(acts):
         ref = g[f"grp_grad{i}"]
         assert np.abs(a.grad.numpy() - ref).max() <= 1e-5 * max(np.abs(ref).max(), 1e-12)
     cat = torch.cat([a.detach() for a in acts], dim=1)
-    assert abs(m(cat, t).item() - loss.item()) <= 1e-7
-    assert m(acts, torch.zeros_like(t)).item() == 0.0                      # void only: no term (loss.py:541-542)
+    assert abs(LO.kld_group_loss(m, cat, t).item() - loss.item()) <= 1e-7
+    assert LO.kld_group_loss(m, acts, torch.zeros_like(t)).item() == 0.0   # void only: no term (loss.py:541-542)
 
 
 def test_kld_loss_refuses_inputs_outside_the_kernels():
