@@ -466,6 +466,46 @@ def test_push_stages_match_oracle():
     np.testing.assert_array_equal(np.reshape(patches, ref["bank"].shape), ref["bank"])
 
 
+def test_compute_distances_takes_the_fused_minimum_and_falls_back_when_it_must():
+    """``push.compute_distances`` takes the minimum inside the distance kernel (``push_min_distances``: no [1, P, H, W] map)
+    whenever the class identity is one-hot, and reduces the written map otherwise - with the same result either way."""
+    from scaleprotoseg_amd import push as push_mod
+
+    dev = _dev()
+    S, K = 4, 5
+    net, data, P = _push_problem(dev, S=S, K=K)
+    img, tgt = data[1]
+    calls = []
+    orig = net.push_min_distances
+
+    def spy(*a, **kw):
+        out = orig(*a, **kw)
+        calls.append(out is not None)
+        return out
+
+    net.push_min_distances = spy
+    idx_f, val_f = push_mod.compute_distances(net, data, img, tgt, K, void_class=0)
+    assert calls == [True]                                              # the fused kernel ran
+    # a fractional identity row: the mask is no longer a class comparison -> the module declines, the map path answers
+    ident = net.prototype_class_identity.clone()
+    net.prototype_class_identity = ident
+    idx_m, val_m = push_mod.compute_distances(net, data, img, tgt, K, void_class=0)        # (still one-hot: fused again)
+    assert torch.equal(idx_m, idx_f) and torch.equal(val_m, val_f)
+    frac = ident.clone()
+    frac[0] = frac[0] * 0.5
+    net.prototype_class_identity = frac
+    idx_h, val_h = push_mod.compute_distances(net, data, img, tgt, K, void_class=0)
+    assert calls[-1] is False                                           # declined
+    ref_conv = net.conv_features(img.unsqueeze(0).to(dev)).cpu()
+    ranges = {s: tuple(net.scale_num_prototypes[s]) for s in range(S)}
+    d = O.scale_l2_convolution(ref_conv, net.prototype_vectors.detach().cpu(), ranges, S)
+    lab = O.resize_label(tgt, (d.shape[3], d.shape[2])).unsqueeze(0)
+    ridx, rval = O.push_masked_argmin(d, lab, frac.cpu(), K, void_class=0)
+    assert torch.equal(idx_h.cpu()[:, 1:], ridx[:, 1:])                 # rows with a binary mask: bit-exact as ever
+    net.prototype_class_identity = ident
+    assert torch.equal(idx_h[:, 1:], idx_f[:, 1:])
+
+
 def test_push_prototypes_multiscale_end_to_end(tmp_path):
     from scaleprotoseg_amd.push import push_prototypes_multiscale
 
