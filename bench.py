@@ -187,6 +187,29 @@ def secondary_modes(dev, spx, F_, steps=5, warmup=2):
         out[name] = entry(ms, M, fb + bb, 6 * P * (C // S))
         del graph, x, bank, head, gl, gd
         torch.cuda.empty_cache()
+
+    # (6) the reference's training crops with the losses on the path's output inside the step: class-gathered distances +
+    # KLDLoss + logits gradient, 10 x 65 x 65 latent pixels, irregular label regions (argmax of smooth random fields), graph replay
+    C, P, S, K, H, W, B = 256, 228, 4, 19, 65, 65, 10
+    M = B * H * W
+    g, x, layout, bank, ident, head = problem(C, P, S, K, H, W, B, seed=3)
+    keys, J, table = spx.class_gather_table(layout, ident, dev)
+    coarse = torch.randn(B, K + 1, 5, 5, device=dev, generator=g)
+    target = torch.nn.functional.interpolate(coarse, size=(H, W), mode="bicubic", align_corners=False).argmax(dim=1)
+    gather = spx.ClassGather(labels=(target.reshape(B, -1) - 1).to(torch.int32).contiguous(), keys=keys, width=J, table=table)
+    kld_fn = spx.KLDLoss(ident, S, {s_: layout.scale_ranges[s_] for s_ in range(S)})
+    gl = torch.randn(M, K, device=dev, generator=g) * 1e-3
+
+    def crop_step():
+        x.grad = bank.grad = head.grad = None
+        logits, dmap, _ = spx.proto_head_forward(x, bank, head, layout, want_distances=False, class_gather=gather)
+        loss = kld_fn(spx.ClassDistances(dmap, gather.labels, gather.table, (H, W)), target)
+        torch.autograd.backward([logits, loss], [gl, None])
+    graph, _ = capture_step(crop_step, warmup=2)
+    ms = timed(graph.replay, n=20, w=3)
+    out["crops_10x65x65_p228_s4_gathered_kld_graph_step"] = entry(ms, M, 2 * C + 4 * K + 4 * J + 4 + 4 * K + 2 * C + 2 * C + 4 * J + 4, 6 * P * (C // S))
+    del graph, x, bank, head, gl
+    torch.cuda.empty_cache()
     return out
 
 
