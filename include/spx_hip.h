@@ -35,7 +35,7 @@ extern "C" {
 #endif
 
 #define SPX_MAX_PANELS 64   /* (scale, <=192-prototype block) work units per pixel tile */
-#define SPX_ABI_VERSION 11
+#define SPX_ABI_VERSION 12
 
 /* How the prototype bank is cut into MFMA panels.  Filled by spx_make_plan(). */
 typedef struct spx_plan {
@@ -90,11 +90,13 @@ int spx_dist_fwd(const spx_plan* plan, const void* x, int32_t x_dtype, int32_t B
 
 /* Backward, pixel side: recomputes the distance tile, forms
  *   G = (dDist + (dAct + dLogits.W) * act'(d)) * [d > 0]
- * and writes dX = 2 (rowsum_s(G) x - G.P) in X's dtype, plus 16-bit copies of G (fp16) and of the activations (int16), both
- * scaled per pixel and 32-prototype block by a power of two (the inverse scales follow the blobs), in MFMA-fragment order
- * for spx_bank_bwd (spx_bwd_scratch_bytes() each; opaque to the caller).  Replaces autograd through
- * model_multiscale.py:255-281,324-330,243-244.  d_dist / d_act / d_logits may be NULL (treated as 0);
- * dx may be NULL (X frozen); g_out / a_out may be NULL when the bank / head are frozen. */
+ * and writes dX = 2 (rowsum_s(G) x - G.P) in X's dtype, plus two scratch buffers for spx_bank_bwd, both opaque to the caller:
+ *   g_out  spx_bwd_scratch_bytes(): G as fp16 MFMA fragments with one power-of-two scale per 128-pixel tile;
+ *   a_out  spx_bwd_head_scratch_bytes(): what d_W = dLogits^T . A needs - for heads of at most 32 rows the product itself,
+ *          formed in this kernel as one fp32 partial per (panel, tile, 32-prototype block); for wider heads the activations
+ *          as block-scaled int16 MFMA fragments.
+ * Replaces autograd through model_multiscale.py:255-281,324-330,243-244.  d_dist / d_act / d_logits may be NULL (treated as
+ * 0); dx may be NULL (X frozen); g_out / a_out may be NULL when the bank / head are frozen. */
 int spx_dist_bwd(const spx_plan* plan, const void* x, int32_t x_dtype, int32_t B, int32_t HW,
                  const void* packed_bank, const void* packed_bankT, const float* packed_p2,
                  const void* packed_headT,
@@ -251,42 +253,19 @@ int spx_dist_bwd_group(const spx_plan* plan, const void* x, int32_t x_dtype, int
                        const float* d_logits, float* d_units, void* dx, void* g_out, void* a_out,
                        float epsilon, int32_t act_fn, void* stream);
 
-/* Bytes of the g_out (and of the a_out) scratch of spx_dist_bwd. */
+/* Bytes of the g_out and of the a_out scratch of spx_dist_bwd. */
 size_t spx_bwd_scratch_bytes(const spx_plan* plan, int32_t B, int32_t HW);
+size_t spx_bwd_head_scratch_bytes(const spx_plan* plan, int32_t B, int32_t HW);
 
-/* Backward, parameter side: d_bank [P, Cs] = 2 (p colsum(G) - G^T X) and d_W [K, P] = dLogits^T A,
- * as a pixel-split MFMA reduction with per-workgroup fp32 partial slabs summed in a fixed order
- * (no float atomics: replicas stay bit-identical).  workspace: spx_bank_bwd_workspace_bytes().
- * d_bank / d_W may be NULL. */
+/* Backward, parameter side: d_bank [P, Cs] = 2 (p colsum(G) - G^T X) as a pixel-split MFMA reduction with per-workgroup
+ * fp32 partial slabs, and d_W [K, P] = dLogits^T A from spx_dist_bwd's a_out (the tile partials of a head of at most 32 rows
+ * are summed; for a wider head the product is formed here from the activation fragments and d_logits, which may be NULL
+ * otherwise).  Every sum runs in a fixed order (no float atomics: replicas stay bit-identical).
+ * workspace: spx_bank_bwd_workspace_bytes().  d_bank / d_W may be NULL. */
 size_t spx_bank_bwd_workspace_bytes(const spx_plan* plan, int32_t B, int32_t HW);
 int spx_bank_bwd(const spx_plan* plan, const void* x, int32_t x_dtype, int32_t B, int32_t HW,
                  const float* bank, const void* g_in, const void* a_in, const float* d_logits,
                  float* d_bank, float* d_W, void* workspace, void* stream);
-
-/* Fused backward (one persistent kernel, one workgroup per compute unit, for banks of a single panel: one scale of at most
- * 192 prototypes and 256 channels, a head of at most 32 rows - spx_bwd_fused_supported() says whether a plan qualifies):
- * dX AND d_bank from one pass over the pixel tiles.  G never leaves the chip (fp16 with one power-of-two scale per tile, in
- * LDS), X is fetched from HBM once per tile, and the d_bank partial sums stay in registers for the whole launch (one fp32
- * slab per workgroup, summed in a fixed order: run-to-run identical).  Replaces spx_dist_bwd + the d_bank half of
- * spx_bank_bwd, i.e. autograd through model_multiscale.py:255-281, :324-330, :243-244.
- *   packed_bankT16  spx_pack_bankT16(): fp16 fragments of -2 bank^T (spx_packed_bankT16_bytes())
- *   bank            fp32 [P, Cs] (the p * colsum(G) term of d_bank)
- *   d_dist / d_logits may be NULL; labels_cls / proto_key / J / d_class_distances: the class-gathered distance gradient of
- *                   spx_dist_bwd_cls instead of d_dist (labels_cls NULL = off)
- *   dx              X's dtype, NULL = X frozen;   d_bank [P, Cs] fp32, NULL = bank frozen (workspace then unused)
- *   a_out           the activation blob for spx_bank_bwd(d_W) (spx_bwd_scratch_bytes()), NULL = head frozen
- *   workspace       spx_bwd_fused_workspace_bytes() */
-int32_t spx_bwd_fused_supported(const spx_plan* plan);
-size_t spx_packed_bankT16_bytes(const spx_plan* plan);
-int spx_pack_bankT16(const spx_plan* plan, const float* bank, void* packed_bankT16, void* stream);
-size_t spx_bwd_fused_workspace_bytes(const spx_plan* plan, int32_t B, int32_t HW);
-int spx_dist_bwd_fused(const spx_plan* plan, const void* x, int32_t x_dtype, int32_t B, int32_t HW,
-                       const void* packed_bank, const void* packed_bankT16, const float* packed_p2,
-                       const void* packed_headT, const float* bank,
-                       const float* d_dist, const int32_t* labels_cls, const uint32_t* proto_key, int32_t J,
-                       const float* d_class_distances, const float* d_logits,
-                       void* dx, void* a_out, float* d_bank, void* workspace,
-                       float epsilon, int32_t act_fn, void* stream);
 
 /* Class-masked per-prototype argmin over the latent grid (prototype push).
  * Replaces the one_hot / matmul / masked add / two min() reductions of

@@ -15,7 +15,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libspx_hip.so")
 SPX_MAX_PANELS = 64
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 
 class SpxError(RuntimeError):
@@ -80,13 +80,9 @@ SIGNATURES = {
     "spx_dist_fwd_group": (C.c_int, [_PP, _V, _I, _I, _I, _V, _V, _V, _V, _I, _V, _V, _V, _V, _F, _I, _V]),
     "spx_dist_bwd_group": (C.c_int, [_PP, _V, _I, _I, _I, _V, _V, _V, _V, _V, _I, _V, _V, _V, _V, _V, _V, _V, _V, _F, _I, _V]),
     "spx_bwd_scratch_bytes": (C.c_size_t, [_PP, _I, _I]),
+    "spx_bwd_head_scratch_bytes": (C.c_size_t, [_PP, _I, _I]),
     "spx_bank_bwd_workspace_bytes": (C.c_size_t, [_PP, _I, _I]),
     "spx_bank_bwd": (C.c_int, [_PP, _V, _I, _I, _I, _V, _V, _V, _V, _V, _V, _V, _V]),
-    "spx_bwd_fused_supported": (_I, [_PP]),
-    "spx_packed_bankT16_bytes": (C.c_size_t, [_PP]),
-    "spx_pack_bankT16": (C.c_int, [_PP, _V, _V, _V]),
-    "spx_bwd_fused_workspace_bytes": (C.c_size_t, [_PP, _I, _I]),
-    "spx_dist_bwd_fused": (C.c_int, [_PP, _V, _I, _I, _I, _V, _V, _V, _V, _V, _V, _V, _V, _I, _V, _V, _V, _V, _V, _V, _F, _I, _V]),
     "spx_push_argmin": (C.c_int, [_V, _V, _V, _I, _I, _I, _I, _I, _F, _V, _V, _V, _V]),
     "spx_dist_push_min": (C.c_int, [_PP, _V, _I, _I, _I, _V, _V, _V, _I, _I, _V, _F, _V, _V, _V, _V]),
     "spx_argmin_images": (C.c_int, [_V, _I, _I, _V, _V]),
@@ -128,7 +124,8 @@ def load() -> C.CDLL:
             f"{LIB_PATH} is missing: build it with `python -m scaleprotoseg_amd.build` "
             "(hipcc --offload-arch=gfx950).  scaleprotoseg_amd has no CPU fallback."
         )
-    lib = C.CDLL(LIB_PATH)
+    # development A/B only (tools/ab_variants.sh): another build of the SAME library; never a different backend
+    lib = C.CDLL(os.environ.get("SPX_LIB_OVERRIDE") or LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res

@@ -11,8 +11,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libspx_hip.so")
 SOURCES = ["spx_api.hip", "spx_fwd_npb2.hip", "spx_fwd_npb4.hip", "spx_fwd_npb6.hip", "spx_bwd_npb2.hip", "spx_bwd_npb4.hip",
-           "spx_bwd_npb6.hip", "spx_bwdf.hip", "spx_bank.hip", "spx_pack.hip", "spx_push.hip", "spx_eval.hip", "spx_kld.hip", "spx_ce.hip", "spx_gemm.hip"]
-HEADERS = ["spx_common.h", "spx_args.h", "spx_mainloop.h", "spx_fwd_impl.h", "spx_bwd_impl.h", "spx_bwdf_impl.h", os.path.join("..", "..", "include", "spx_hip.h")]
+           "spx_bwd_npb6.hip", "spx_bank.hip", "spx_pack.hip", "spx_push.hip", "spx_eval.hip", "spx_kld.hip", "spx_ce.hip", "spx_gemm.hip"]
+HEADERS = ["spx_common.h", "spx_args.h", "spx_mainloop.h", "spx_fwd_impl.h", "spx_bwd_impl.h", os.path.join("..", "..", "include", "spx_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off"]
 FLAGS += os.environ.get("SPX_EXTRA_HIPCC_FLAGS", "").split()
 

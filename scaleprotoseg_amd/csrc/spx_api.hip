@@ -87,16 +87,6 @@ hipError_t spx_launch_bwd(const SpxBwdArgs& a, int x_dtype, hipStream_t s) {
     return a.plan.npb == 2 ? spx_launch_bwd_npb2(a, x_dtype, s) : a.plan.npb == 4 ? spx_launch_bwd_npb4(a, x_dtype, s) : spx_launch_bwd_npb6(a, x_dtype, s);
 }
 
-// fused persistent backward (spx_bwdf.hip)
-struct SpxBwdFArgs;
-bool spx_bwdf_supported(const spx_plan& pl);
-int spx_bwdf_grid(int B, int HW);
-hipError_t spx_launch_pack_bankT16(const spx_plan& pl, const float* bank, void* out, hipStream_t s);
-int spx_bwdf_run(const spx_plan& pl, const void* x, int x_dtype, int B, int HW, const void* packed_bank, const void* packed_bankT16,
-                 const float* p2, const void* packed_headT, const float* d_dist, const int32_t* labels, const uint32_t* proto_key,
-                 int J, const float* d_cls, const float* d_logits, void* dx, void* a_out, float* workspace, float eps, int act_fn,
-                 int grid, hipStream_t s, unsigned long long* dbg);
-
 extern "C" {
 
 int spx_version(void) { return SPX_ABI_VERSION; }
@@ -151,6 +141,11 @@ int spx_make_plan(int32_t P, int32_t K, int32_t S, int32_t Cs, const int32_t* lo
 }
 
 size_t spx_bwd_scratch_bytes(const spx_plan* pl, int32_t B, int32_t HW) { return spx_bwd_scratch_elems(*pl, B, HW) * 2; }
+size_t spx_bwd_head_scratch_bytes(const spx_plan* pl, int32_t B, int32_t HW) {
+    if (pl->ncb != 1) return spx_bwd_scratch_elems(*pl, B, HW) * 2;              /* the activation blob */
+    const size_t tiles = (size_t)B * ((HW + SPX_TILE_PX - 1) / SPX_TILE_PX);
+    return spx_dw_partial_bytes(pl->npanels, tiles, pl->npb, pl->num_classes) + 16;   /* d_W tile partials + the head scale */
+}
 
 size_t spx_packed_bank_bytes(const spx_plan* pl) {
     return (size_t)pl->npanels * pl->npb * 32 * (((pl->channels_per_scale + 31) / 32) * 32) * 2;
@@ -554,7 +549,8 @@ int spx_bank_bwd(const spx_plan* pl, const void* x, int32_t x_dtype, int32_t B, 
     if (!x || !bank || !workspace) return fail("spx_bank_bwd: NULL operand");
     if (x_dtype != 0 && x_dtype != 1) return fail("spx_bank_bwd: x_dtype %d", x_dtype);
     if (d_bank && !g_in) return fail("spx_bank_bwd: d_bank requested without G");
-    if (d_W && (!a_in || !d_logits)) return fail("spx_bank_bwd: d_W requested without activations / d_logits");
+    if (d_W && !a_in) return fail("spx_bank_bwd: d_W requested without the head-gradient scratch of spx_dist_bwd");
+    if (d_W && pl->ncb > 1 && !d_logits) return fail("spx_bank_bwd: d_W of a head wider than 32 rows needs d_logits");
     if (pl->channels_per_scale > 256) return fail("spx_bank_bwd: Cs %d > 256 not supported", pl->channels_per_scale);
     SpxBankBwdArgs a;
     a.plan = *pl;
@@ -571,58 +567,6 @@ int spx_bank_bwd(const spx_plan* pl, const void* x, int32_t x_dtype, int32_t B, 
     a.vec_ok = x_vec_ok(x, x_dtype, HW);
     a.nsplit = spx_bank_bwd_nsplit(*pl, B, HW);
     return hip_status(spx_launch_bank_bwd(a, x_dtype, (hipStream_t)stream), "spx_bank_bwd");
-}
-
-// ---- fused persistent backward (spx_bwdf_impl.h) ----
-int32_t spx_bwd_fused_supported(const spx_plan* pl) { return (pl && !check_plan(pl) && spx_bwdf_supported(*pl)) ? 1 : 0; }
-size_t spx_packed_bankT16_bytes(const spx_plan* pl) { return (size_t)((pl->channels_per_scale + 31) / 32) * pl->npb * 2 * 1024; }
-int spx_pack_bankT16(const spx_plan* pl, const float* bank, void* out, void* stream) {
-    if (check_plan(pl)) return 1;
-    if (!spx_bwdf_supported(*pl)) return fail("spx_pack_bankT16: the fused backward does not carry this plan");
-    if (!bank || !out) return fail("spx_pack_bankT16: NULL buffer");
-    return hip_status(spx_launch_pack_bankT16(*pl, bank, out, (hipStream_t)stream), "spx_pack_bankT16");
-}
-size_t spx_bwd_fused_workspace_bytes(const spx_plan* pl, int32_t B, int32_t HW) {
-    const int ws = ((pl->channels_per_scale + 31) / 32) * 32 + pl->ncb * 32 + 32;
-    return (size_t)spx_bwdf_grid(B, HW) * pl->npb * 32 * ws * sizeof(float);
-}
-int spx_dist_bwd_fused(const spx_plan* pl, const void* x, int32_t x_dtype, int32_t B, int32_t HW, const void* packed_bank,
-                       const void* packed_bankT16, const float* packed_p2, const void* packed_headT, const float* bank,
-                       const float* d_dist, const int32_t* labels_cls, const uint32_t* proto_key, int32_t J,
-                       const float* d_class_distances, const float* d_logits, void* dx, void* a_out, float* d_bank,
-                       void* workspace, float epsilon, int32_t act_fn, void* stream) {
-    if (check_plan(pl)) return 1;
-    if (!spx_bwdf_supported(*pl)) return fail("spx_dist_bwd_fused: the fused backward does not carry this plan (one panel of 6 blocks, one class block)");
-    if (!x || !packed_bank || !packed_p2) return fail("spx_dist_bwd_fused: NULL operand");
-    if (x_dtype != 0 && x_dtype != 1) return fail("spx_dist_bwd_fused: x_dtype %d", x_dtype);
-    if (B < 1 || HW < 1) return fail("spx_dist_bwd_fused: empty input");
-    if (act_fn != 0 && act_fn != 1) return fail("spx_dist_bwd_fused: act_fn %d", act_fn);
-    if (dx && !packed_bankT16) return fail("spx_dist_bwd_fused: dx requested without the packed bank^T");
-    if (d_logits && !packed_headT) return fail("spx_dist_bwd_fused: d_logits given without packed head^T");
-    if (d_bank && (!workspace || !bank)) return fail("spx_dist_bwd_fused: d_bank requested without bank / workspace");
-    if (labels_cls && d_dist) return fail("spx_dist_bwd_fused: class-gathered and P-wide distance gradients are exclusive");
-    if (labels_cls && check_cls("spx_dist_bwd_fused", labels_cls, proto_key, J, HW)) return 1;
-    if ((long long)pl->num_prototypes * HW >= (1LL << 29)) return fail("spx_dist_bwd_fused: P*HW too large for 32-bit offsets");
-    if ((long long)pl->channels_per_scale * HW * (x_dtype ? 4 : 2) >= (1LL << 32)) return fail("spx_dist_bwd_fused: one image of features exceeds 4 GiB");
-    const int grid = spx_bwdf_grid(B, HW);
-    const bool gather = labels_cls && d_class_distances;
-    if (spx_bwdf_run(*pl, x, x_dtype, B, HW, packed_bank, packed_bankT16, packed_p2, packed_headT, d_dist, gather ? labels_cls : nullptr,
-                     proto_key, J, gather ? d_class_distances : nullptr, d_logits, dx, a_out, d_bank ? (float*)workspace : nullptr,
-                     epsilon, act_fn, grid, (hipStream_t)stream, g_dbg))
-        return fail("spx_dist_bwd_fused: launch failed: %s", hipGetErrorString(hipGetLastError()));
-    if (!d_bank) return 0;
-    SpxBankBwdArgs r;
-    memset(&r, 0, sizeof(r));
-    r.plan = *pl;
-    r.x = x;
-    r.bank = bank;
-    r.d_bank = d_bank;
-    r.d_W = nullptr;
-    r.workspace = (float*)workspace;
-    r.B = B;
-    r.HW = HW;
-    r.nsplit = grid;
-    return hip_status(spx_launch_bank_reduce(r, (hipStream_t)stream), "spx_dist_bwd_fused (slab reduction)");
 }
 
 int spx_push_argmin(const float* distances, const int32_t* labels, const float* class_identity, int32_t B, int32_t P,

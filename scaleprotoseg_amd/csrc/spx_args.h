@@ -72,7 +72,7 @@ struct SpxBwdArgs {
     float* ce_dlogits_out;      // [B*HW, K] written for the parameter kernel (may be NULL)
     void* dx;
     uint16_t* g_out;
-    uint16_t* a_out;
+    uint16_t* a_out;            // head-gradient scratch (spx_common.h): fp32 d_W tile partials (one class block) or the activation blob
     int B, HW, vec_ok;
     int tile_first, tiles_launch;   // this launch covers tiles [tile_first, tile_first + tiles_launch) of every image
     int tile_mul;                   // see SpxFwdArgs
@@ -85,7 +85,7 @@ struct SpxBankBwdArgs {
     const void* x;
     const float* bank;
     const uint16_t* g_in;
-    const uint16_t* a_in;
+    const uint16_t* a_in;       // kernel 1's head-gradient scratch
     const float* d_logits;
     float* d_bank;
     float* d_W;
@@ -106,7 +106,6 @@ int spx_tile_mul(int tiles_launch, long long plane_bytes);
 hipError_t spx_launch_fwd(const SpxFwdArgs& a, int x_dtype, hipStream_t s);        // a.labels != NULL: class-gathered variant
 hipError_t spx_launch_bwd(const SpxBwdArgs& a, int x_dtype, hipStream_t s);
 hipError_t spx_launch_bank_bwd(const SpxBankBwdArgs& a, int x_dtype, hipStream_t s);
-hipError_t spx_launch_bank_reduce(const SpxBankBwdArgs& a, hipStream_t s);
 int spx_bank_bwd_nsplit(const spx_plan& pl, int B, int HW);
 size_t spx_bwd_scratch_elems(const spx_plan& pl, int B, int HW);
 size_t spx_bank_bwd_ws_floats(const spx_plan& pl, int nsplit);

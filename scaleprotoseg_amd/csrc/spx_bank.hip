@@ -194,8 +194,6 @@ __global__ __launch_bounds__(SPX_BK_THREADS, 2) void spx_bank_bwd_kernel(const S
         gsc_off[i] = off < FBYTES ? (uint32_t)(((frag >> 1) * 64 + rr + 32 * hh) * 4) : SPX_OOB;
     }
     const size_t blob_total = (size_t)pl.npanels * ntiles * 4 * NPB * 2 * 1024;
-    // activation blob format (kernel 1 wrote the word behind the blobs)
-    const uint32_t a_fmt = (DO_W && a.a_in) ? *(const uint32_t*)((const char*)a.a_in + spx_ablob_fmt_offset(blob_total)) : SPX_ABLOB_FP16;
     constexpr int LPT = (SPX_BK_PX * 32 * NCB + SPX_BK_THREADS - 1) / SPX_BK_THREADS;   // dLogits elements per thread (upper bound)
     const int piece = tid % PPR, prow = tid / PPR;   // X staging: piece of 8 px, row within a pass of RPP rows
 
@@ -285,46 +283,20 @@ __global__ __launch_bounds__(SPX_BK_THREADS, 2) void spx_bank_bwd_kernel(const S
             if (off < FBYTES) {
                 if (DO_P) *(u32x4*)(Gs + off) = st.gr[i];
                 if (DO_W) {
-                    // the activation blob is fp16: split every element into bf16 hi + lo HERE, with the whole workgroup
-                    // and in the blob's own lane order (the split is elementwise), so the waves of the head product
-                    // only read fragments
-                    const f16x8 hv = __builtin_bit_cast(f16x8, st.ar[i]);
+                    // the activation blob holds block-scaled int16 codes: every element becomes a bf16 hi + lo pair HERE, with
+                    // the whole workgroup and in the blob's own lane order (the split is elementwise), so the waves of the
+                    // head product only read fragments
                     u32x4 ahw, alw;
-                    // launch-uniform branches on the format word kernel 1 wrote
-                    if (SPX_ABLOB_FORMAT == 2 && a_fmt == SPX_ABLOB_I16) {
-                        const float asc = __builtin_amdgcn_ldexpf(1.0f / SPX_ABLOB_I16_ONE, (int)((st.exw[i] >> 8) & 0xffu) - 128);
+                    const float asc = __builtin_amdgcn_ldexpf(1.0f / SPX_ABLOB_I16_ONE, (int)((st.exw[i] >> 8) & 0xffu) - 128);
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            f32x2 v;
-                            v[0] = (float)(short)(st.ar[i][j] & 0xffffu);            // 15 bits + sign: hi + lo is exact
-                            v[1] = (float)((int)st.ar[i][j] >> 16);
-                            uint32_t hi, lo;
-                            split_bf16x2(v * asc, hi, lo);
-                            ahw[j] = hi;
-                            alw[j] = lo;
-                        }
-                    } else if (SPX_ABLOB_FORMAT == 1 && a_fmt == SPX_ABLOB_E4M12) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            f32x2 v;
-                            v[0] = ablob_unpack(st.ar[i][j] & 0xffffu);             // e4m12: hi + lo is exact
-                            v[1] = ablob_unpack(st.ar[i][j] >> 16);
-                            uint32_t hi, lo;
-                            split_bf16x2(v, hi, lo);
-                            ahw[j] = hi;
-                            alw[j] = lo;
-                        }
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            f32x2 v;
-                            v[0] = (float)hv[2 * j];
-                            v[1] = (float)hv[2 * j + 1];
-                            uint32_t hi, lo;
-                            split_bf16x2(v, hi, lo);
-                            ahw[j] = hi;
-                            alw[j] = lo;
-                        }
+                    for (int j = 0; j < 4; ++j) {
+                        f32x2 v;
+                        v[0] = (float)(short)(st.ar[i][j] & 0xffffu);            // 15 bits + sign: hi + lo is exact
+                        v[1] = (float)((int)st.ar[i][j] >> 16);
+                        uint32_t hi, lo;
+                        split_bf16x2(v * asc, hi, lo);
+                        ahw[j] = hi;
+                        alw[j] = lo;
                     }
                     *(u32x4*)(As + off) = ahw;
                     *(u32x4*)(As2 + off) = alw;
@@ -667,10 +639,44 @@ __global__ __launch_bounds__(SPX_RED_ELEMS * SPX_RED_PARTS) void spx_bank_reduce
     if (is_p) {
         a.d_bank[(size_t)p * Cs + col] = 2.0f * (a.bank[(size_t)p * Cs + col] * ct - st);
     } else {
-        // kernel 1's activation blob holds a / ln 2 (scaled int16, fp16) or a / (16 ln 2) (e4m12, the log activation)
+        // the head scale kernel 1 left behind its tile partials / its activation blob (spx_common.h)
         const size_t ntl = (size_t)a.B * ((a.HW + SPX_TILE_PX - 1) / SPX_TILE_PX);
-        const uint32_t fmt = *(const uint32_t*)((const char*)a.a_in + spx_ablob_fmt_offset(ntl * pl.npanels * 4 * pl.npb * 2 * 1024));
-        a.d_W[(size_t)(col - Cs) * P + p] = (fmt == SPX_ABLOB_E4M12 ? 0.69314718056f * SPX_ABLOB_SCALE : 0.69314718056f) * st;
+        const size_t off = pl.ncb == 1 ? spx_dw_partial_bytes(pl.npanels, ntl, pl.npb, K) : spx_ablob_scale_offset(ntl * pl.npanels * 4 * pl.npb * 2 * 1024);
+        a.d_W[(size_t)(col - Cs) * P + p] = *(const float*)((const char*)a.a_in + off) * st;
+    }
+}
+
+// d_W of the heads with one class block, level 1: kernel 1 left one fp32 partial [block][K][32 prototypes] per (panel, tile)
+// (spx_bwd_impl.h, "d_W stage").  Workgroup (j, q) adds the partials of tiles j, j + nsplit, ... of panel q - a fixed set in
+// a fixed order (eight independent partial sums per output, combined pairwise) - into the d_W columns of slab j, which the
+// parameter kernel leaves alone for these heads; kernel 3 then sums the slabs as it does for d_bank.  A streaming read of
+// 128 K bytes per block and tile (north star: 239 MB).
+__global__ __launch_bounds__(256) void spx_dw_reduce_kernel(const SpxBankBwdArgs a) {
+    const spx_plan& pl = a.plan;
+    const int j = blockIdx.x, q = blockIdx.y;
+    const int K = pl.num_classes, NPB = pl.npb;
+    const int nchb = (pl.channels_per_scale + 31) / 32;
+    const int rows = NPB * 32, ws = spx_bk_wstride(pl);
+    const long long ntiles = (long long)a.B * ((a.HW + SPX_TILE_PX - 1) / SPX_TILE_PX);
+    const int nvb = (pl.panel_np[q] + 31) >> 5;                  // blocks of the panel holding >= 1 real prototype
+    const int nvec = nvb * K * 8;                                // 16-B vectors of a partial's valid blocks (they are contiguous)
+    const size_t tstride = (size_t)NPB * K * 32;                 // floats per (panel, tile)
+    const float* const base = (const float*)a.a_in + (size_t)q * ntiles * tstride;
+    float* const slab = a.workspace + ((size_t)j * pl.npanels + q) * rows * ws;
+    for (int v = threadIdx.x; v < nvec; v += 256) {
+        f32x4 s[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        long long t = j;
+        for (; t + 7ll * a.nsplit < ntiles; t += 8ll * a.nsplit) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s[u] += *(const f32x4*)(base + (size_t)(t + (long long)u * a.nsplit) * tstride + (size_t)v * 4);
+        }
+        for (int u = 0; t < ntiles; t += a.nsplit, ++u) s[u] += *(const f32x4*)(base + (size_t)t * tstride + (size_t)v * 4);
+        const f32x4 tot = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+        const int pb = v / (K * 8), rem = v - pb * (K * 8), cls = rem >> 3, p4 = rem & 7;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) slab[(size_t)(pb * 32 + p4 * 4 + e) * ws + nchb * 32 + cls] = tot[e];
     }
 }
 
@@ -709,8 +715,10 @@ static hipError_t launch_bank_pw(const SpxBankBwdArgs& a, int x_dtype, dim3 grid
 }
 template <int NPB, int NCB>
 static hipError_t launch_bank_x(const SpxBankBwdArgs& a, int x_dtype, dim3 grid, hipStream_t s) {
-    if constexpr (NCB < 5) {
-        // d_W alone (the fused backward of spx_bwdf_impl.h has already produced d_bank): its own instance, no G / X staging
+    if constexpr (NCB == 1) {
+        // one class block: d_W comes from kernel 1's tile partials (spx_dw_reduce_kernel), this kernel carries d_bank only
+        return a.d_bank ? launch_bank_pw<NPB, NCB, true, false>(a, x_dtype, grid, s) : hipSuccess;
+    } else if constexpr (NCB < 5) {
         if (!a.d_bank) return launch_bank_pw<NPB, NCB, false, true>(a, x_dtype, grid, s);
         return launch_bank_pw<NPB, NCB, true, true>(a, x_dtype, grid, s);
     } else {
@@ -731,15 +739,6 @@ static hipError_t spx_launch_bank_part(const SpxBankBwdArgs& a, int x_dtype, hip
     return pl.npb == 2 ? launch_bank_x<2, 5>(a, x_dtype, grid, s) : pl.npb == 4 ? launch_bank_x<4, 5>(a, x_dtype, grid, s) : launch_bank_x<6, 5>(a, x_dtype, grid, s);
 }
 
-// the fixed-order slab sum alone (the fused backward of spx_bwdf_impl.h writes its own slabs: a.nsplit of them)
-hipError_t spx_launch_bank_reduce(const SpxBankBwdArgs& a, hipStream_t s) {
-    const spx_plan& pl = a.plan;
-    const long long n = (long long)pl.npanels * pl.npb * 32 * (pl.channels_per_scale + pl.num_classes);
-    hipLaunchKernelGGL(spx_bank_reduce_kernel, dim3((unsigned)((n + SPX_RED_ELEMS - 1) / SPX_RED_ELEMS)),
-                       dim3(SPX_RED_ELEMS * SPX_RED_PARTS), 0, s, a);
-    return hipGetLastError();
-}
-
 hipError_t spx_launch_bank_bwd(const SpxBankBwdArgs& a0, int x_dtype, hipStream_t s) {
     SpxBankBwdArgs a = a0;
     const spx_plan& pl = a.plan;
@@ -757,6 +756,10 @@ hipError_t spx_launch_bank_bwd(const SpxBankBwdArgs& a0, int x_dtype, hipStream_
         e = spx_launch_bank_part(a, x_dtype, s);
     }
     if (e != hipSuccess) return e;
+    if (pl.ncb == 1 && a.d_W) {
+        hipLaunchKernelGGL(spx_dw_reduce_kernel, dim3((unsigned)a.nsplit, (unsigned)pl.npanels), dim3(256), 0, s, a);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+    }
     const long long n = (long long)pl.npanels * rows * (pl.channels_per_scale + pl.num_classes);
     hipLaunchKernelGGL(spx_bank_reduce_kernel, dim3((unsigned)((n + SPX_RED_ELEMS - 1) / SPX_RED_ELEMS)),
                        dim3(SPX_RED_ELEMS * SPX_RED_PARTS), 0, s, a);

@@ -11,14 +11,17 @@
 // Kernel 1 (pixel side, spx_bwd_kernel): same tiling and main loop as the forward (the x.p tile is
 // recomputed with identical arithmetic, so the relu mask is the forward's bit for bit — cheaper than
 // re-reading the fp32 distance map: 2*P*C flop/px on the matrix pipe vs 4*P bytes/px of HBM).
-//   phase 1: G and a in accumulator layout (lane = pixel), packed to bf16 MFMA B-fragments; the fragments
-//            are dumped verbatim ("blobs": 1 KiB per 32 px x 16 prototypes, one 16-B store per lane) for
-//            kernel 2, and kept in registers for
+//   phase 1: G and a in accumulator layout (lane = pixel).  G is packed to fp16 MFMA B-fragments, dumped verbatim
+//            ("blobs": 1 KiB per 32 px x 16 prototypes, one 16-B store per lane) for kernel 2, and kept in registers for
+//            phase 2.  The activations feed d_W = dLogits^T . a: for heads of one class block (K <= 32) right here - the
+//            "d_W stage": a block's activations are turned through LDS so that the PIXEL becomes the MFMA k, and the
+//            workgroup leaves one fp32 [K][32] partial per prototype block and tile (summed in a fixed order by
+//            spx_dw_reduce_kernel / kernel 3); for wider heads as a 16-bit blob for kernel 2 (spx_common.h).
 //   phase 2: dX^T[ch x px] = P^T . G with the G fragments as B operand (accumulator -> operand, no LDS) and
 //            the P^T fragments streamed through LDS; the result is transposed through LDS so that X is read
 //            and dX written in whole 256-B pixel rows.
-// Kernel 2 (parameter side, spx_bank_bwd_kernel): pixel-split MFMA reduction G^T.X and a^T.dLogits; the blobs
-// are laid out [pixel][prototype] in LDS and read back with ds_read_b64_tr_b16 (pixel becomes the MFMA k).
+// Kernel 2 (parameter side, spx_bank_bwd_kernel): pixel-split MFMA reduction G^T.X (and a^T.dLogits for the wide heads);
+// the blobs are laid out [pixel][prototype] in LDS and read back with ds_read_b64_tr_b16 (pixel becomes the MFMA k).
 // Per-workgroup fp32 partial slabs, summed in a fixed order by kernel 3 (no float atomics).
 #pragma once
 #include "spx_args.h"
@@ -36,29 +39,41 @@
 #define SPX_T_BYTES (32 * SPX_T_ROW)
 
 // LDS carve of the pixel kernel (two workgroups per CU need <= 80 KiB each):
-//   region 0: main loop: 2 stages            | phase 2: 2 P^T stages (NPB * 2 KiB each) + transpose tile 0
+//   region 0: main loop: 2 stages | phase 1: the d_W stage's images (+ the dAct turn scratch) | phase 2: 2 P^T stages
+//             (NPB * 2 KiB each) + transpose tile 0
 //   region 1: head^T fragments (phase 1 only) | phase 2: transpose tile 1
 //   |p|^2 of the panel, rowsum(G) of the tile
+// d_W stage (one class block): [dL image 16 KiB][activation image(s) 16 KiB each][dAct scratch], see the kernel.
+#define SPX_DW_IMG 16384                  // one image: 4 waves x 2 cells x (hi, lo) x 1 KiB
+#define SPX_DACT_SC 4352                  // per wave: 32 x 33 floats + pad
+template <int NCB, bool DACT>
+__host__ __device__ constexpr int spx_bwd_dw_nabuf() { return DACT ? 1 : 2; }
+template <int NCB, bool DACT>
+__host__ __device__ constexpr int spx_bwd_phase1_bytes() {
+    return (NCB == 1 ? (1 + spx_bwd_dw_nabuf<NCB, DACT>()) * SPX_DW_IMG : 0) + (DACT ? 4 * SPX_DACT_SC : 0);
+}
 template <int NPB>
 __host__ __device__ constexpr int spx_bwd_bt_bytes() { return NPB * 2 * 1024; }
 template <int NPB, int NCB>
 __host__ __device__ constexpr int spx_bwd_head_lds_bytes() { return NCB * NPB <= 6 ? NPB * NCB * 2 * 2048 : 0; }   // <= 24 KiB
-template <int NPB>
+template <int NPB, int NCB, bool DACT>
 __host__ __device__ constexpr int spx_bwd_region0_bytes() {
     constexpr int a = 2 * spx_stage_bytes(NPB);
     constexpr int b = 2 * spx_bwd_bt_bytes<NPB>() + SPX_T_BYTES;
-    return a > b ? a : b;
+    constexpr int c = spx_bwd_phase1_bytes<NCB, DACT>();
+    return (a > b ? a : b) > c ? (a > b ? a : b) : c;
 }
 template <int NPB, int NCB>
 __host__ __device__ constexpr int spx_bwd_region1_bytes() {
     constexpr int h = spx_bwd_head_lds_bytes<NPB, NCB>();
     return h > SPX_T_BYTES ? h : SPX_T_BYTES;
 }
-template <int NPB, int NCB>
+template <int NPB, int NCB, bool DACT>
 __host__ __device__ constexpr int spx_bwd_lds_bytes() {
-    return spx_bwd_region0_bytes<NPB>() + spx_bwd_region1_bytes<NPB, NCB>() + 3 * NPB * 32 * 4 + SPX_TILE_PX * 4 + 32;   // + |p|^2, class keys, slot plane offsets, rowsum(G)
+    return spx_bwd_region0_bytes<NPB, NCB, DACT>() + spx_bwd_region1_bytes<NPB, NCB>() + 3 * NPB * 32 * 4 + SPX_TILE_PX * 4 + 32;   // + |p|^2, class keys, slot plane offsets, rowsum(G)
 }
-static_assert(spx_bwd_lds_bytes<6, 1>() <= 80 * 1024, "pixel kernel must fit two workgroups per CU");
+static_assert(spx_bwd_lds_bytes<6, 1, false>() <= 80 * 1024 && spx_bwd_lds_bytes<6, 1, true>() <= 80 * 1024,
+              "pixel kernel must fit two workgroups per CU");
 // bf16 elements of one G (or a) scratch: [panel][tile][wave][pb][s2] fragments of 512 elements
 
 // ------------------------------------------------------------------------------------------------
@@ -101,12 +116,19 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
     constexpr int chunk_bytes = NPB * 2 * 1024;
     constexpr int head_lds = spx_bwd_head_lds_bytes<NPB, NCB>();
     const int nchunks = (Cs + SPX_KC - 1) / SPX_KC;
-    char* const hlds = smem + spx_bwd_region0_bytes<NPB>();
+    char* const hlds = smem + spx_bwd_region0_bytes<NPB, NCB, DACT>();
     float* const p2s = (float*)(hlds + spx_bwd_region1_bytes<NPB, NCB>());
     uint32_t* const keys = (uint32_t*)(p2s + NPB * 32);    // GATHER: (class << 16) | slot per padded prototype row
     uint32_t* const koff = keys + NPB * 32;                // GATHER: byte offset of the row's slot plane (slot * HW * 4)
     float* const rss = p2s + 3 * NPB * 32;
     float* const gmaxs = rss + SPX_TILE_PX;                // [4] wave maxima of |G| (the tile's fp16 scale)
+    // d_W stage (one class block, see the epilogue): dL image, activation image(s), then the dAct turn scratch
+    constexpr bool DW = NCB == 1;
+    constexpr int NABUF = spx_bwd_dw_nabuf<NCB, DACT>();
+    char* const l_img = smem;
+    char* const a_img = smem + SPX_DW_IMG;
+    char* const dact_sc = smem + (DW ? (1 + NABUF) * SPX_DW_IMG : 0);
+    const bool want_dw = DW && a.a_out != nullptr;          // workgroup-uniform
 
     const int px = px0 + 32 * wave + r;
     const bool px_ok = px < a.HW;
@@ -369,16 +391,31 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
         const size_t tile_g = (size_t)b * tiles_per_img + tile_i;
         const size_t blob0 = (((size_t)panel * ntiles + tile_g) * 4) * NPB * 2 * 1024;   // bytes
         const spx_rsrc gr = make_rsrc(a.g_out ? (const char*)a.g_out + blob0 : nullptr);
-        const spx_rsrc ar = make_rsrc(a.a_out ? (const char*)a.a_out + blob0 : nullptr);
-        // block exponents of the G blob: one word per (lane, block) behind the blobs, [panel][tile][wave][block][lane]
         const size_t blob_total = (size_t)pl.npanels * ntiles * 4 * NPB * 2 * 1024;
-        // ... the same words behind the activation blob (SPX_ABLOB_FORMAT 2; the parameter kernel reads whichever scratch it is given);
-        // the format word sits behind them
-        const spx_rsrc asr = make_rsrc(a.a_out ? (const char*)a.a_out + blob_total + blob0 / 8 : nullptr);
-        constexpr uint32_t ABLOB_FMT_LOG = SPX_ABLOB_FORMAT == 2 ? SPX_ABLOB_I16 : (SPX_ABLOB_FORMAT == 1 ? SPX_ABLOB_E4M12 : SPX_ABLOB_FP16);
-        constexpr uint32_t ABLOB_FMT_LIN = SPX_ABLOB_FORMAT == 2 ? SPX_ABLOB_I16 : SPX_ABLOB_FP16;
-        if (a.a_out && blockIdx.x == 0 && blockIdx.y == 0 && panel == 0 && tid == 0)
-            *(uint32_t*)((char*)a.a_out + spx_ablob_fmt_offset(blob_total)) = act_is_log ? ABLOB_FMT_LOG : ABLOB_FMT_LIN;
+        // wide heads: the activation blob, its block exponents (one word per (lane, block), [panel][tile][wave][block][lane])
+        // behind the blobs, the head scale behind those
+        const bool want_ab = !DW && a.a_out != nullptr;
+        const spx_rsrc ar = make_rsrc(want_ab ? (const char*)a.a_out + blob0 : nullptr);
+        const spx_rsrc asr = make_rsrc(want_ab ? (const char*)a.a_out + blob_total + blob0 / 8 : nullptr);
+        if (a.a_out && blockIdx.x == 0 && blockIdx.y == 0 && panel == 0 && tid == 0) {
+            // the head scale (spx_common.h): the d_W stage's partials carry a / ln 2 times c1 dLogits, the blob a / ln 2
+            if (DW) *(float*)((char*)a.a_out + spx_dw_partial_bytes(pl.npanels, ntiles, NPB, K)) = 0.69314718056f / act_c1;
+            else *(float*)((char*)a.a_out + spx_ablob_scale_offset(blob_total)) = 0.69314718056f;
+        }
+        // ---- d_W stage, set-up (one class block): the wave's dLogits fragments (split bf16, pre-scaled by c1) as a
+        // [pixel][class] image, cell-major: cell = 16 classes x 32 pixels of ONE wave x (hi | lo) = 1 KiB with 32-B pixel rows,
+        // so that ds_read_b64_tr_b16 hands a lane 8 PIXELS of its class (the pixel becomes the MFMA k).  Rows are permuted
+        // (bit 2 flipped where bit 3 is set): the two row groups a transposed read touches per 32-lane half, 8 rows apart,
+        // then fall on disjoint banks.  The stages are idle from here to phase 2; rebuilt per panel (they are not in between).
+        const int rperm = r ^ (((r >> 3) & 1) << 2);
+        if (want_dw) {
+            char* const lw = l_img + wave * 4096 + rperm * 32 + h * 16;
+#pragma unroll
+            for (int c = 0; c < (DW ? 2 : 0); ++c) {
+                *(bf16x8*)(lw + c * 2048) = dlhi[c];
+                *(bf16x8*)(lw + c * 2048 + 1024) = dllo[c];
+            }
+        }
 
         // ---- phase 1: G, a — a ROLLED loop over the panel's 32-prototype blocks.  The block being processed is
         // always acc[0]; acc is rotated after each block and the block's G enters a register queue, so the body is
@@ -437,10 +474,10 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
         // gout = its G (fp32, accumulator layout)
         auto block = [&](int pb, auto slot_c, float (&ddc)[16], float (&ddnext)[16], f32x16& gout) {
             constexpr int SLOT = decltype(slot_c)::value;
-            u32x4 anew[2];     // the activation blob: 16-bit codes of a / ln 2 (scaled int16 / e4m12 / fp16, see spx_common.h), packed in pairs
+            u32x4 anew[2];     // wide heads: the activation blob, int16 codes of a / ln 2 packed in pairs (spx_common.h)
             // G leaves the block as fp32 (it is packed to fp16 with ONE power-of-two scale per tile once the tile's largest |G|
             // is known, see below); the activation blob's block exponent travels in one word per (lane, block) behind the blob:
-            // bits 8-15 = exponent of the activation scale + 128 (bits 0-7: unused since the G scale became per tile, 128)
+            // bits 8-15 = exponent of the activation scale + 128 (bits 0-7: 128)
             int ex_a = 0;
 #pragma unroll
             for (int j = 0; j < 16; ++j) gout[j] = 0.0f;
@@ -476,7 +513,7 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
                     // loaded with a prototype column per lane (two 128-B row pieces per instruction, all 16 loads in
                     // flight), turned through the wave's LDS scratch into the accumulator layout (pixel per lane)
                     const spx_rsrc dar = make_rsrc_pred(a.d_act + (size_t)b * a.HW * P + p0 + pb * 32);
-                    float* const sc = (float*)(smem + wave * 4352);     // 32 x 33 floats + pad; the stages are idle in phase 1
+                    float* const sc = (float*)(dact_sc + wave * SPX_DACT_SC);     // 32 x 33 floats + pad; the stages are idle in phase 1
                     const int col = lane & 31;
                     const bool col_ok = pb * 32 + col < np;
                     float dv[16];
@@ -541,7 +578,7 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
                     for (int i = 0; i < 8; ++i) {
 #pragma unroll
                         for (int e = 0; e < 2; ++e)
-                            av[i][e] = fmaxf(-1.44269504089f * relu_f32(dr[i][e]), -65504.0f);   // the blob is fp16: saturate, never inf
+                            av[i][e] = -1.44269504089f * relu_f32(dr[i][e]);
                         gv[i] = pair_of(ga, i) + pair_of(ddc, i);        // act' = -1 (folded into ga)
                     }
                 }
@@ -563,40 +600,111 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
                 }
 #pragma unroll
                 for (int i = 0; i < 16; ++i) gmax = fmaxf(gmax, __builtin_fabsf(gv[i >> 1][i & 1]));
-                // activation blob, SPX_ABLOB_FORMAT 2: amax = m * 2^ea, m in [0.5, 1): codes round(a * 2^-ea * 32767), |code| <= 32767
-                float ascale_dn = 1.0f;
-                if (SPX_ABLOB_FORMAT == 2) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    gout[2 * i] = gv[i][0];
+                    gout[2 * i + 1] = gv[i][1];
+                }
+                if (DW) {
+                    // d_W stage, operand: this block's a / ln 2 as an exact-to-2^-17 bf16 hi + lo pair into the activation image
+                    // (the dL image's cell layout; cell = 16 prototypes: registers 8 cell .. 8 cell + 7 of the lane, i.e. position
+                    // 8 h + j of the cell's 32-B row <-> prototype 8 (j >> 2) + 4 h + (j & 3) of the cell)
+                    if (want_dw) {
+                        char* const aw = a_img + (NABUF == 2 ? SLOT * SPX_DW_IMG : 0) + wave * 4096 + rperm * 32 + h * 16;
+#pragma unroll
+                        for (int cell = 0; cell < 2; ++cell) {
+                            u32x4 hw, lw;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                uint32_t hi, lo;
+                                split_bf16x2(av[4 * cell + i], hi, lo);
+                                hw[i] = hi;
+                                lw[i] = lo;
+                            }
+                            *(u32x4*)(aw + cell * 2048) = hw;
+                            *(u32x4*)(aw + cell * 2048 + 1024) = lw;
+                        }
+                    }
+                } else {
+                    // activation blob: amax = m * 2^ea, m in [0.5, 1): codes round(a * 2^-ea * 32767), |code| <= 32767
                     float amax = 0.0f;
 #pragma unroll
                     for (int i = 0; i < 16; ++i) amax = fmaxf(amax, __builtin_fabsf(av[i >> 1][i & 1]));
                     int ea = __builtin_amdgcn_frexp_expf(amax);
                     ea = ea < -100 ? -100 : (ea > 100 ? 100 : ea);
-                    ascale_dn = __builtin_amdgcn_ldexpf(1.0f, -ea);
+                    const float ascale_dn = __builtin_amdgcn_ldexpf(1.0f, -ea);
                     ex_a = ea;
-                }
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    gout[2 * i] = gv[i][0];
-                    gout[2 * i + 1] = gv[i][1];
-                    if (SPX_ABLOB_FORMAT == 2) {
+                    for (int i = 0; i < 8; ++i) {
                         const f32x2 an = av[i] * ascale_dn;                       // in [-1, 1]
                         anew[i >> 2][i & 3] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pknorm_i16(an[0], an[1]));
-                    } else if (SPX_ABLOB_FORMAT == 1 && act_is_log) {
-                        anew[i >> 2][i & 3] = ablob_pack(av[i][0]) | (ablob_pack(av[i][1]) << 16);
-                    } else {
-                        anew[i >> 2][i & 3] = pack_f16x2(av[i]);
                     }
                 }
             }
-            // activation fragment dump for kernel 2 (wholly padded blocks are written as zeros: kernel 2 reads them)
+            if (!DW) {
+                // activation fragment dump for kernel 2 (wholly padded blocks are written as zeros: kernel 2 reads them)
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                const uint32_t so = (uint32_t)(((wave * NPB + pb) * 2 + s2) * 1024);
-                const uint32_t vo = spx_blob_slot(r, h, s2) * 16u;
-                if (a.a_out) buf_store_b128_p<SPX_AUX_BLOB_ST>(anew[s2], ar, vo, so);
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const uint32_t so = (uint32_t)(((wave * NPB + pb) * 2 + s2) * 1024);
+                    const uint32_t vo = spx_blob_slot(r, h, s2) * 16u;
+                    if (want_ab) buf_store_b128_p<SPX_AUX_BLOB_ST>(anew[s2], ar, vo, so);
+                }
+                const float exw = __uint_as_float(128u | ((uint32_t)(ex_a + 128) << 8));
+                if (want_ab) buf_store_f32(exw, asr, (uint32_t)lane * 4u, (uint32_t)((wave * NPB + pb) * 256));
             }
-            const float exw = __uint_as_float(128u | ((uint32_t)(ex_a + 128) << 8));
-            if (SPX_ABLOB_FORMAT == 2 && a.a_out) buf_store_f32(exw, asr, (uint32_t)lane * 4u, (uint32_t)((wave * NPB + pb) * 256));
+        };
+        // ---- d_W stage, product: after the barrier every wave takes one 16 x 16 tile of the block's d_W^T [32 prototypes x 32
+        // classes] (wave w: prototype cell w & 1, class cell w >> 1) over ALL 128 pixels of the tile: 4 k-steps of 32 pixels
+        // (= the four waves' images) x 3 split-bf16 MFMAs (hi.hi, lo.hi, hi.lo), v_mfma_f32_16x16x32_bf16.  No cross-wave sum,
+        // no atomics: the tile's partial leaves as ONE 16-B store per lane, [class][32 prototypes] fp32 rows per block.
+        // BUF: which activation image (two images: block pb + 1 is written while slower waves still read block pb; with the
+        // dAct scratch in the way there is one image and a second barrier behind the reads).
+        auto dw_stage = [&](int pb, auto buf_c) {
+            constexpr int BUF = decltype(buf_c)::value;
+#ifdef SPX_DIAG_DW_NOSTAGE
+            return;                  // timing-only builds (results are wrong): no product, or no barrier in front of it
+#endif
+#ifndef SPX_DIAG_DW_NOBAR
+            __syncthreads();
+#endif
+            const int lane = spx_opaque((int)threadIdx.x) & 63;     // (see spx_opaque)
+            const int g = lane >> 4, li = lane & 15, qq = li >> 2, pp = li & 3;
+            // transposed-read rows of this lane: pixels 8 g + qq and 8 g + qq + 4 of the k-step, under the row permutation
+            const int row0 = 8 * g + qq + 4 * (g & 1), row1 = 8 * g + qq + 4 * (1 - (g & 1));
+            const int pg = wave & 1, cg = wave >> 1;
+            const char* const ab = a_img + (NABUF == 2 ? BUF * SPX_DW_IMG : 0) + pg * 2048 + pp * 8;
+            const char* const lb = l_img + cg * 2048 + pp * 8;
+            f32x4 dw;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dw[i] = 0.0f;
+            auto frag = [&](const char* p0) -> bf16x8 {
+                const bf16x4 t0 = __builtin_bit_cast(bf16x4, lds_tr_read(p0 + row0 * 32));
+                const bf16x4 t1 = __builtin_bit_cast(bf16x4, lds_tr_read(p0 + row1 * 32));
+                return __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7);
+            };
+#pragma unroll
+#ifdef SPX_DIAG_DW_ONEKS
+            for (int ks = 0; ks < 1; ++ks) {
+#else
+            for (int ks = 0; ks < 4; ++ks) {
+#endif
+                const bf16x8 ah = frag(ab + ks * 4096), al = frag(ab + ks * 4096 + 1024);
+                const bf16x8 lh = frag(lb + ks * 4096), ll = frag(lb + ks * 4096 + 1024);
+                dw = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, lh, dw, 0, 0, 0);
+                dw = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, lh, dw, 0, 0, 0);
+                dw = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, ll, dw, 0, 0, 0);
+            }
+            if (NABUF == 1) __syncthreads();
+            // accumulator row 4 g + i <-> position 4 g + i of the prototype cell <-> prototype 8 (g & 1) + 4 (g >> 1) + i
+            // (the grouping tail builds its dUnits fragments in ACCUMULATOR row order: position li of a class cell is then
+            // unit 8 ((li >> 2) & 1) + 4 (li >> 3) + (li & 3) of the cell, as for the prototype cells)
+            const int cls = 16 * cg + (a.packed_tailT ? 8 * ((li >> 2) & 1) + 4 * (li >> 3) + (li & 3) : li);
+            const spx_rsrc dwr = make_rsrc_pred((char*)a.a_out + ((((size_t)panel * ntiles + tile_g) * NPB + pb) * K) * 128);
+            const uint32_t vo = cls < K ? (uint32_t)(cls * 128 + (16 * pg + 8 * (g & 1) + 4 * (g >> 1)) * 4) : SPX_OOB;
+#ifdef SPX_DIAG_DW_NOSTORE
+            if (dw[0] == 1.2345f)
+#endif
+            buf_store_b128(__builtin_bit_cast(u32x4, dw), dwr, vo, 0);
         };
         // ROLLED loop, two blocks per iteration from the static slots 0 and 1 (static dDist buffers too), then one
         // rotation by two: the next pair moves to the front, the pair's G (fp32) enters the two vacated slots.  NPB / 2
@@ -605,7 +713,9 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
         for (int pb = 0; pb < NPB; pb += 2) {
             f32x16 gA, gB;
             block(pb, std::integral_constant<int, 0>{}, ddA, ddB, gA);
+            if (DW && want_dw && pb < nv) dw_stage(pb, std::integral_constant<int, 0>{});
             block(pb + 1, std::integral_constant<int, 1>{}, ddB, ddA, gB);
+            if (DW && want_dw && pb + 1 < nv) dw_stage(pb + 1, std::integral_constant<int, 1>{});
 #pragma unroll
             for (int i = 0; i + 2 < NPB; ++i) acc[i] = acc[i + 2];
             acc[NPB - 2] = gA;
@@ -866,9 +976,9 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
 template <int NPB, int NCB, bool GATHER, bool DACT>
 static hipError_t launch_bwd_gd(const SpxBwdArgs& a, int x_dtype, dim3 grid, hipStream_t s) {
 #ifdef SPX_DIAG_BWD_LDS_EXTRA
-    constexpr size_t lds = (size_t)spx_bwd_lds_bytes<NPB, NCB>() + SPX_DIAG_BWD_LDS_EXTRA;   // experiment: force one workgroup per CU
+    constexpr size_t lds = (size_t)spx_bwd_lds_bytes<NPB, NCB, DACT>() + SPX_DIAG_BWD_LDS_EXTRA;   // experiment: force one workgroup per CU
 #else
-    constexpr size_t lds = (size_t)spx_bwd_lds_bytes<NPB, NCB>();
+    constexpr size_t lds = (size_t)spx_bwd_lds_bytes<NPB, NCB, DACT>();
 #endif
     if (x_dtype == 1) {
         if (a.vec_ok == 2) hipLaunchKernelGGL((spx_bwd_kernel<NPB, NCB, true, 2, GATHER, DACT>), grid, dim3(256), lds, s, a);

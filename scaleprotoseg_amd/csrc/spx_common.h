@@ -190,47 +190,23 @@ __device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
-// Activation blob of the backward (kernel 1 -> kernel 2): 16 bits per (pixel, prototype), read by the d_W product only,
-// where what counts is the ABSOLUTE error of each entry (d_W = sum_px dLogits * a).  Three formats (SPX_ABLOB_FORMAT):
-//   0  fp16 of a / ln 2: 11 significant bits PER ELEMENT; d_W peaks at 1.1e-3 .. 1.7e-3 of max|d_W| in a handful of toy
-//      configurations of the fuzz (few pixels, large activations).
-//   1  "log" activations as a 16-bit float with a 4-bit exponent and a 12-bit mantissa (a / (16 ln 2) in [0, 1); 13
-//      significant bits; "linear" activations stay fp16): d_W peak 3.9e-4; +3 VALU per element in kernel 1 (+0.05 ms).
-//   2  (default) int16 codes scaled per (pixel, 32-prototype block) by a power of two - the same device the G blob uses: the
-//      block's largest |a| keeps 15 bits, every entry an absolute error of 2^-16 of that maximum; works for both
-//      activations (signed).  +1 VALU per element in kernel 1 (one v_max3 per pair, one packed multiply, one
-//      v_cvt_pknorm_i16_f32 per pair), one more float per (lane, block) in the side array behind the blob.
-// The format word sits behind the scales (last 16 bytes of the scratch); kernels 2 and 3 read it.
-#ifndef SPX_ABLOB_FORMAT
-#ifdef SPX_ABLOB_USE_E4M12
-#define SPX_ABLOB_FORMAT (SPX_ABLOB_USE_E4M12 ? 1 : 0)
-#else
-#define SPX_ABLOB_FORMAT 2
-#endif
-#endif
-#define SPX_ABLOB_FP16 0u
-#define SPX_ABLOB_E4M12 1u
-#define SPX_ABLOB_I16 2u
-#define SPX_ABLOB_SCALE 16.0f
+// Head-gradient scratch of the backward (kernel 1 -> kernels 2 / 3), opaque to the caller (spx_bwd_head_scratch_bytes):
+//   one class block (K <= 32):  d_W is formed INSIDE kernel 1 (spx_bwd_impl.h, "d_W stage"): per (panel, tile, prototype block)
+//       an fp32 partial [K][32 prototypes] of sum_px (a / ln 2) * (c1 dLogits) over the tile's 128 pixels - 128 K bytes per
+//       block and tile instead of the 16-bit activation blob's 8 KiB;
+//   wider heads (K > 32: the partial would be larger than the blob): the activations cross as 16-bit MFMA fragment blobs of
+//       a / ln 2 - int16 codes scaled per (pixel, 32-prototype block) by a power of two (the block's largest |a| keeps 15 bits:
+//       absolute error 2^-16 of that maximum; the exponent words follow the blobs) - and kernel 2 forms d_W from them.
+// In both forms ONE float behind the data (the "head scale") is what the fixed-order reduction multiplies its sums by:
+// ln 2 / c1 resp. ln 2 (c1 = the constant factor of act'(d) that kernel 1 folds into its dLogits operand).
 #define SPX_ABLOB_I16_ONE 32767.0f
-// bytes from the start of a blob scratch to its format word: [blobs | scales (blobs / 8) | format word]
-__host__ __device__ inline size_t spx_ablob_fmt_offset(size_t blob_total) { return blob_total + blob_total / 8; }
-// ... and behind the format word (16 bytes) the exponents of the G blob: one int32 per (panel, tile), G16 = G * 2^e
+// bytes from the start of a blob scratch to the head scale: [blobs | block exponents (blobs / 8) | scale word (16 B)]
+__host__ __device__ inline size_t spx_ablob_scale_offset(size_t blob_total) { return blob_total + blob_total / 8; }
+// ... and behind that word the exponents of the G blob: one int32 per (panel, tile), G16 = G * 2^e
 __host__ __device__ inline size_t spx_gexp_offset(size_t blob_total) { return blob_total + blob_total / 8 + 16; }
-// 3 VALU per element: integer add (rounding, re-bias and the 1/16 scale - four exponent steps - in one constant),
-// arithmetic shift, clamp
-__device__ __forceinline__ uint32_t ablob_pack(float a_over_ln2) {
-    static_assert(SPX_ABLOB_SCALE == 16.0f, "the scale is folded into the exponent re-bias below");
-    int t = (int)__float_as_uint(a_over_ln2) + (int)(0x400u - (115u << 23));
-    t >>= 11;                                                       // < 0 for values below 2^-16 (and for 0)
-    t = t < 0 ? 0 : t;                                              // the compiler folds the two clamps into v_med3_i32
-    return (uint32_t)(t > 65535 ? 65535 : t);
-}
-// 1 VALU per element beside the 16-bit extract.  Code 0 decodes to 2^-16 (a / ln 2 = 2.4e-4) instead of 0: entries that
-// small only come from padded prototype rows (dropped by the reduction kernel), pixels past the image (their d_logits are
-// 0) or activations below 2.4e-4, where the absolute error is what the format promises anyway.
-__device__ __forceinline__ float ablob_unpack(uint32_t u) {                             // = a / (16 ln 2)
-    return __uint_as_float((u << 11) + (111u << 23));
+// bytes of the d_W tile partials of a plan with one class block: [panel][tile][block][K][32] fp32 (+ 16 B: the head scale)
+__host__ __device__ inline size_t spx_dw_partial_bytes(int npanels, size_t ntiles, int npb, int K) {
+    return (size_t)npanels * ntiles * npb * K * 128;
 }
 
 // fp32 -> (hi, lo) bf16 pair with hi + lo == x to ~2^-17 relative.

@@ -301,15 +301,6 @@ def wide_linear(a: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
     return _WideLinearFn.apply(a, w)
 
 
-# The fused persistent backward (spx_dist_bwd_fused: dX and d_bank from one kernel, G never in HBM) for the banks it
-# carries.  It moves ~40 % fewer HBM bytes than the two-kernel backward but does not yet run faster on MI355X (DESIGN.md
-# section 3 has the phase clocks), so it is opt-in: SPX_FUSED_BWD=1 or functional.FUSED_BACKWARD = True.  The parity tests
-# run both.
-import os as _os
-
-FUSED_BACKWARD = _os.environ.get("SPX_FUSED_BWD", "0") == "1"
-
-
 class _Packs:
     """Device buffers holding the MFMA-ordered operands of one forward."""
 
@@ -324,11 +315,6 @@ class _Packs:
         self.p2 = torch.empty(lib.spx_packed_p2_bytes(pp) // 4, dtype=torch.float32, device=dev)
         s = _lib.stream_ptr()
         _lib.check(lib.spx_pack_bank(pp, _lib.ptr(bank2d), _lib.ptr(self.bank), _lib.ptr(self.bankT), _lib.ptr(self.p2), s))
-        # the fused backward (one panel banks) takes -2 bank^T as fp16 fragments
-        self.bankT16 = None
-        if need_bwd and FUSED_BACKWARD and lib.spx_bwd_fused_supported(pp):
-            self.bankT16 = torch.empty(lib.spx_packed_bankT16_bytes(pp), **u8)
-            _lib.check(lib.spx_pack_bankT16(pp, _lib.ptr(bank2d), _lib.ptr(self.bankT16), s))
         self.head = self.headT = None
         if head is not None:
             self.head = torch.empty(lib.spx_packed_head_bytes(pp), **u8)
@@ -374,7 +360,7 @@ def _cached_packs(plan_key, plan, bank, head, tail, bank2d, head2d, tail2d, need
         # a captured step is replayed after its parameters have been edited in place (the static-buffer protocol of HIP graphs):
         # the pack kernels must be part of the graph
         return _Packs(plan, bank2d, head2d, need_bwd, tail2d)
-    key = (plan_key, _tensor_key(bank), _tensor_key(head), _tensor_key(tail), bool(need_bwd), FUSED_BACKWARD)
+    key = (plan_key, _tensor_key(bank), _tensor_key(head), _tensor_key(tail), bool(need_bwd))
     hit = _PACK_CACHE.get(key)
     if hit is not None:
         refs, packs = hit
@@ -563,42 +549,12 @@ class _ProtoHeadFn(torch.autograd.Function):
                 ce = _lib.SpxCe(labels=_lib.ptr(ce_labels), lse=_lib.ptr(lse), logits=_lib.ptr(ce_logits),
                                 coef=_lib.ptr(coef), d_logits_out=_lib.ptr(d_logits_ce))
         dx = torch.empty_like(x) if need_x else None
-        g_scr = torch.empty(scr, dtype=torch.uint8, device=dev) if (need_bank and not (
-            packs.bankT16 is not None and ctx.tail2d is None and ce is None and ga is None)) else None
-        a_scr = torch.empty(scr, dtype=torch.uint8, device=dev) if need_head else None
+        g_scr = torch.empty(scr, dtype=torch.uint8, device=dev) if need_bank else None
+        a_scr = torch.empty(lib.spx_bwd_head_scratch_bytes(pp, B, HW), dtype=torch.uint8, device=dev) if need_head else None
         tail2d, d_units, d_tail = ctx.tail2d, None, None
         if tail2d is not None and gl is None and ce is None:
             raise SpxError("backward through the fused group tail without a logits gradient")
-        fused = (packs.bankT16 is not None and tail2d is None and ce is None and ga is None)
         d_bank = d_head = None
-        if fused:
-            # one persistent kernel: dX and d_bank; the activation blob feeds spx_bank_bwd for d_LastLayer
-            g = ctx.gather
-            if need_bank:
-                d_bank = torch.empty((P, Cs), dtype=torch.float32, device=dev)
-                ws_f = torch.empty(lib.spx_bwd_fused_workspace_bytes(pp, B, HW) // 4, dtype=torch.float32, device=dev)
-            with _timed("spx_dist_bwd"):
-                _lib.check(
-                    lib.spx_dist_bwd_fused(
-                        pp, _lib.ptr(x), xd, B, HW, _lib.ptr(packs.bank), _lib.ptr(packs.bankT16), _lib.ptr(packs.p2),
-                        _lib.ptr(packs.headT) if gl is not None else None, _lib.ptr(bank2d),
-                        _lib.ptr(gd) if g is None else None, _lib.ptr(g.labels) if g is not None else None,
-                        _lib.ptr(g.keys) if g is not None else None, g.width if g is not None else 0,
-                        _lib.ptr(gd) if g is not None else None, _lib.ptr(gl), _lib.ptr(dx), _lib.ptr(a_scr),
-                        _lib.ptr(d_bank), _lib.ptr(ws_f) if need_bank else None, ctx.epsilon, ACT_FN[ctx.act_fn], s,
-                    )
-                )
-            if need_head:
-                ws = torch.empty(lib.spx_bank_bwd_workspace_bytes(pp, B, HW) // 4, dtype=torch.float32, device=dev)
-                d_head = torch.empty((K, P), dtype=torch.float32, device=dev)
-                with _timed("spx_bank_bwd"):
-                    _lib.check(lib.spx_bank_bwd(pp, _lib.ptr(x), xd, B, HW, _lib.ptr(bank2d), None, _lib.ptr(a_scr),
-                                                _lib.ptr(gl), None, _lib.ptr(d_head), _lib.ptr(ws), s))
-            if d_bank is not None:
-                d_bank = d_bank.reshape(ctx.bank_shape)
-            if ctx.needs_input_grad[2] and d_head is None and head2d is not None:
-                d_head = torch.zeros_like(head2d)
-            return dx, d_bank, d_head, None, None, None, None, None, None, None, None
         with _timed("spx_dist_bwd"):
             if tail2d is not None and ce is not None:
                 d_units = torch.empty((B * HW, K), dtype=torch.float32, device=dev)
