@@ -2,6 +2,7 @@
 // G / a fragment blobs consumed here).
 #include "spx_args.h"
 #include "spx_common.h"
+#include <type_traits>
 
 // ------------------------------------------------------------------------------------------------
 // kernel 2: parameter side   S[q][row][col] = sum_px Gq[row][px] * Xs[col][px]   (+ a^T.dLogits, colsum G)
@@ -580,6 +581,273 @@ __global__ __launch_bounds__(SPX_BK_THREADS, 2) void spx_bank_bwd_kernel(const S
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// kernel 2, LDS-DMA form (spx_bank_dma_kernel): the d_bank product for bf16 features whose pixel count is a multiple of 64,
+// scales wider than 64 channels, no d_W duty (heads of one class block: d_W comes from kernel 1's tile partials).
+//
+// What bounds this product is how X is FETCHED (timing-only builds of this kernel, round 4, north star, the 1.07 GB X stream
+// alone): as the 64-B row pieces of a 32-pixel chunk 0.43 ms (2.5 TB/s), as 128-B pieces 0.28 ms, as 256-B pieces 0.22 ms;
+// the 0.8 GB of G fragments (contiguous) 0.19 ms; the MFMA phase with its operand reads 0.41 ms.  The register-staged kernel
+// above reads 64-B pieces (two chunks of loads in flight is all its 256 registers hold, and its LDS stage is one chunk).
+// Here NO operand passes through registers on its way in: everything arrives by LDS-DMA (buffer_load ... lds, 1 KiB per wave
+// instruction).  X comes in UNITS of 64 pixels - 128-B row pieces, whole cache lines - into a ring of three 32-KiB images;
+// the G fragments (verbatim) per 32-pixel chunk into a ring of four; a step = one chunk = the MFMA phase of the register-
+// staged kernel.  Per step a wave issues its pieces of the G chunk three steps ahead and of half an X unit two units ahead,
+// waits with a counted vmcnt for everything issued three or more steps ago (the pieces of the last two steps stay in flight),
+// and the one barrier per step publishes every wave's pieces and frees the slots of the step before.  X becomes fp16 (the G
+// plane's MFMA type; exact for bf16 values; round toward zero saturates instead of overflowing) while its B fragments are
+// read, not in a commit pass.  An LDS-DMA writes lane-linear, so the X image is plain [row][128 B]; its bank swizzle (16-B
+// piece p of row r at position p ^ ((r >> 1) & 7): conflict-free ds_read_b128 of one piece index by 32 rows) is applied on
+// the SOURCE address.  Same wave roles, accumulators, exponent handling, slab layout and fixed summation order as above.
+// ------------------------------------------------------------------------------------------------
+#define SPX_BD_GSLOTS 4
+#define SPX_BD_XSLOTS 3
+#define SPX_BD_XUNIT (256 * 128)
+template <int NPB>
+__host__ __device__ constexpr int spx_bd_lds_bytes() {
+    // G ring, X ring, per G slot the piece that carries the tile's fp16 exponent, the landing pad of dropped pieces
+    return SPX_BD_GSLOTS * NPB * 2 * 1024 + SPX_BD_XSLOTS * SPX_BD_XUNIT + (SPX_BD_GSLOTS + 1) * 1024;
+}
+
+template <int NPB>
+__global__ __launch_bounds__(SPX_BK_THREADS, 2) void spx_bank_dma_kernel(const SpxBankBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const spx_plan& pl = a.plan;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int q = blockIdx.y, split = blockIdx.x;
+    const int Cs = pl.channels_per_scale;
+    const int C = pl.num_scales * Cs;
+    const int nchb = (Cs + 31) / 32;
+    constexpr int rows = NPB * 32;
+    constexpr int GB = NPB * 2 * 1024;
+    constexpr int NGP = NPB * 2 + 1;                   // 1-KiB pieces of a G chunk: its fragments + the exponent piece
+    constexpr int PWG = (NGP + 7) / 8;                 // ... per wave (the surplus ones are dropped loads)
+    constexpr int PW = PWG + 2;                        // + this wave's two 8-row pieces of half an X unit: DMAs per wave and step
+    char* const gring = smem;
+    char* const xring = smem + SPX_BD_GSLOTS * GB;
+    char* const epad = xring + SPX_BD_XSLOTS * SPX_BD_XUNIT;   // [G slot][1 KiB]: word 0 = the fp16 exponent of the chunk's kernel-1 tile
+    char* const trash = epad + SPX_BD_GSLOTS * 1024;
+    const int ch0 = pl.panel_ch0[q];
+    const int tiles_per_img = (a.HW + SPX_TILE_PX - 1) / SPX_TILE_PX;
+    const size_t ntiles = (size_t)a.B * tiles_per_img;
+    const int nui = a.nci_launch;                      // 64-px units per image (the launcher counts exactly those)
+    const long long total = (long long)a.B * nui;
+    const long long cstep = a.nslabs;
+    const long long u_begin = split;
+    const int n_units = u_begin < total ? (int)((total - u_begin + cstep - 1) / cstep) : 0;
+    const int n_steps = 2 * n_units;
+    const size_t blob_total = (size_t)pl.npanels * ntiles * 4 * NPB * 2 * 1024;
+    const int32_t* const gexp = (const int32_t*)((const char*)a.g_in + spx_gexp_offset(blob_total)) + (size_t)q * ntiles;
+
+    // wave roles (as in spx_bank_bwd_kernel)
+    const int cpair = wave & 3;
+    constexpr int PH = NPB / 2;
+    const int pb0 = (wave >> 2) * PH;
+    const int cs_first = wave >> 2;
+    auto cs_owner = [&](int i) { return i == 0 ? cs_first : i + 1; };
+    f32x16 accp[PH][2];
+    float csum[PH];
+    int e_acc = 0;
+    bool have_e = false;
+#pragma unroll
+    for (int i = 0; i < PH; ++i) {
+        csum[i] = 0.0f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) accp[i][t][e] = 0.0f;
+    }
+    // rows past the scale's channels are never written by a DMA: they stay zero for the whole launch
+    for (int o = tid * 16; o < spx_bd_lds_bytes<NPB>(); o += SPX_BK_THREADS * 16) *(u32x4*)(smem + o) = u32x4{0u, 0u, 0u, 0u};
+    __syncthreads();
+
+    // buffer_load_dwordx4 ... lds through inline asm: hipcc then keeps its own wait-count bookkeeping out of it (through the
+    // builtin it waits vmcnt(0) in front of LDS reads it cannot tell apart from the DMA's target); ordering is this kernel's:
+    // counted vmcnt + barrier below.  Descriptor as make_rsrc_pred builds it; M0 = the LDS byte address of the piece.
+    auto dma = [&](const char* base, uint32_t vo, char* dst) {
+        const uint64_t ba = (uint64_t)base;
+        u32x4 rs;
+        rs[0] = __builtin_amdgcn_readfirstlane((uint32_t)ba);
+        rs[1] = __builtin_amdgcn_readfirstlane((uint32_t)(ba >> 32) & 0xffffu);
+        rs[2] = 0x80000000u;
+        rs[3] = 0x00020000u;
+        const uint32_t la = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)dst);
+        uint32_t keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "s"(la), "v"(vo), "s"(rs) : "memory");
+    };
+    // a cursor over this workgroup's units u_begin, u_begin + cstep, ...: (image, unit in image), advanced without a division;
+    // past the walk's end it stays on the last unit (those pieces land in slots nobody reads any more)
+    struct Cursor {
+        int k, b, ui;
+    };
+    const int step_b = (int)(cstep / nui), step_ui = (int)(cstep - (long long)step_b * nui);
+    auto advance = [&](Cursor& c) {
+        ++c.k;
+        if (c.k < n_units) {
+            c.b += step_b;
+            c.ui += step_ui;
+            if (c.ui >= nui) {
+                c.ui -= nui;
+                ++c.b;
+            }
+        }
+    };
+    Cursor cg, cx;
+    cg.k = cx.k = 0;
+    cg.b = cx.b = (int)(u_begin / nui);
+    cg.ui = cx.ui = (int)(u_begin - (long long)cg.b * nui);
+    // the G chunk (unit cursor cg, half e) into G slot gs: fragments of kernel-1 wave 2 (ui & 1) + e of tile ui >> 1, and the
+    // tile's exponent (an ordinary load of it would make hipcc drain every DMA in flight at its use: lane 0 fetches 16 bytes
+    // from the tile's word on - the scratch is padded behind the array -, the other lanes drop)
+    auto issue_g = [&](int gs, int e) {
+        const size_t tile_g = (size_t)cg.b * tiles_per_img + (cg.ui >> 1);
+        const char* const gsrc = (const char*)a.g_in + ((((size_t)q * ntiles + tile_g) * 4 + 2 * (cg.ui & 1) + e) * NPB * 2) * 1024;
+#pragma unroll
+        for (int i = 0; i < PWG; ++i) {
+            const int p = wave + 8 * i;                 // wave-uniform
+            const bool is_g = p < NPB * 2, is_e = p == NPB * 2;
+            dma(is_g ? gsrc + (size_t)p * 1024 : (const char*)(gexp + tile_g),
+                is_g ? (uint32_t)lane * 16u : ((is_e && lane == 0) ? 0u : SPX_OOB),
+                is_g ? gring + gs * GB + p * 1024 : (is_e ? epad + gs * 1024 : trash));
+        }
+    };
+    // half e of the X unit (cursor cx) into X slot xs: 16 pieces of 8 rows x 128 B, two per wave.  Lane l <-> row 8 p + (l >> 3),
+    // position l & 7 of the row's eight 16-B pieces; the piece it fetches is the one that belongs there under the swizzle.
+    auto issue_x = [&](int xs, int e) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int p = 16 * e + wave + 8 * i;        // piece of the unit: rows 8 p .. 8 p + 7
+            const int row = 8 * p + (lane >> 3);
+            const int px = cx.ui * 64 + 8 * ((lane & 7) ^ ((row >> 1) & 7));
+            dma((const char*)a.x + ((size_t)cx.b * C + ch0 + 8 * p) * a.HW * 2,
+                (row < Cs && px + 8 <= a.HW) ? ((uint32_t)(lane >> 3) * (uint32_t)a.HW + (uint32_t)px) * 2u : SPX_OOB,
+                xring + xs * SPX_BD_XUNIT + p * 1024);
+        }
+    };
+
+    const int tg = lane >> 4, tli = lane & 15, tqq = tli >> 2, tpp = tli & 3;
+    const int ts2 = tg & 1, tkh = tg >> 1;
+    // the MFMA phase of one 32-pixel chunk: G slot gs, half e of X slot xs
+    auto compute = [&](int gs, int xs, int e) {
+        const char* const Gs = gring + gs * GB;
+        const char* const Xs = xring + xs * SPX_BD_XUNIT;
+        // bring the accumulators to the units of the chunk about to be added (see chunk_scale above)
+        const int e_c = __builtin_amdgcn_readfirstlane(*(const int32_t*)(epad + gs * 1024));
+        if (have_e && e_c - e_acc > 80) return;
+        if (!have_e || e_c != e_acc) {
+            const float ratio = have_e ? __builtin_amdgcn_ldexpf(1.0f, e_c - e_acc) : 1.0f;
+#pragma unroll
+            for (int i = 0; i < PH; ++i) {
+                csum[i] *= ratio;
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) accp[i][t][k] *= ratio;
+            }
+            e_acc = e_c;
+            have_e = true;
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int pxa = ks * 16 + 8 * tkh + tqq;
+            const int fo0 = spx_blob_slot(pxa, tpp & 1, ts2) * 16 + 8 * (tpp >> 1);
+            const int fo1 = spx_blob_slot(pxa + 4, tpp & 1, ts2) * 16 + 8 * (tpp >> 1);
+            f16x8 xb[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const u32x4 raw = *(const u32x4*)(Xs + ((2 * cpair + t) * 32 + r) * 128 + (((4 * e + 2 * ks + h) ^ ((r >> 1) & 7)) * 16));
+                u32x4 w;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    w[k] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(__uint_as_float(raw[k] << 16), __uint_as_float(raw[k] & 0xffff0000u)));
+                xb[t] = __builtin_bit_cast(f16x8, w);
+            }
+#pragma unroll
+            for (int i = 0; i < PH; ++i) {
+                const int fb = ((pb0 + i) * 2 + ts2) * 1024;
+                const s16x4 g0 = lds_tr_read(Gs + fb + fo0);
+                const s16x4 g1 = lds_tr_read(Gs + fb + fo1);
+                const f16x8 gf = __builtin_bit_cast(f16x8, __builtin_shufflevector(g0, g1, 0, 1, 2, 3, 4, 5, 6, 7));
+                if (cpair == cs_owner(i)) {
+                    f16x2 one2;
+                    one2[0] = (_Float16)1.0f;
+                    one2[1] = (_Float16)1.0f;
+                    float s8 = csum[i];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        f16x2 pr;                   // (element by element: see bank_part above)
+                        pr[0] = gf[2 * k];
+                        pr[1] = gf[2 * k + 1];
+                        s8 = __builtin_amdgcn_fdot2(pr, one2, s8, false);
+                    }
+                    csum[i] = s8;
+                }
+#pragma unroll
+                for (int t = 0; t < 2; ++t) accp[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gf, xb[t], accp[i][t], 0, 0, 0);
+            }
+        }
+    };
+    if (n_steps > 0) {
+        // run-in: the first unit whole, then the G chunks of steps 1 and 2 and the second unit (issue order = what the first
+        // counted wait lets stay in flight)
+        issue_g(0, 0);
+        issue_x(0, 0);
+        issue_x(0, 1);
+        issue_g(1, 1);
+        advance(cg);
+        issue_g(2, 0);
+        advance(cx);
+        issue_x(1, 0);
+        issue_x(1, 1);
+        // cg: unit 1, its half 1 goes next (step 0 issues the chunk of step 3); cx: unit 2 next
+        advance(cx);
+        int gs = 0, xs = 0;
+        for (int s = 0; s < n_steps; ++s) {
+            const int e = s & 1;
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PW) : "memory");   // own pieces of steps <= s - ... landed (two steps' worth stay in flight)
+            __builtin_amdgcn_s_waitcnt(0xc07f);        // lgkmcnt(0): this wave's LDS reads of the step before are done
+            __builtin_amdgcn_s_barrier();
+            // the chunk of step s + 3 (half (s + 3) & 1 = 1 - e of the G cursor's unit) and half e of the unit two ahead
+            issue_g((gs + 3) & 3, 1 - e);
+            if (e == 0) advance(cg);                    // (step s + 4 starts the next unit)
+            issue_x(xs >= 1 ? xs - 1 : 2, e);           // X slot (j + 2) % 3 = (xs + 2) % 3
+            if (e == 1) advance(cx);
+#ifndef SPX_DIAG_BD_NOCOMPUTE
+            compute(gs, xs, e);
+#endif
+            gs = (gs + 1) & 3;
+            if (e == 1) xs = xs == 2 ? 0 : xs + 1;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the run-ahead pieces of the walk's end: landed before the LDS is released
+    }
+
+    // ---- write this workgroup's partial slab (layout of spx_bank_bwd_kernel) ----
+    if (!a.d_bank) return;
+    const int ws = spx_bk_wstride(pl);
+    float* slab = a.workspace + ((size_t)(a.slab_first + split) * pl.npanels + q) * rows * ws;
+    const float sinv_acc = have_e ? __builtin_amdgcn_ldexpf(1.0f, -e_acc) : 0.0f;
+#pragma unroll
+    for (int i = 0; i < PH; ++i) {
+        const int pb = pb0 + i;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int chb = 2 * cpair + t;
+            if (chb < nchb) {
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg)
+                    slab[(size_t)(pb * 32 + acc_row(reg, h)) * ws + chb * 32 + r] = accp[i][t][reg] * sinv_acc;
+            }
+        }
+        if (cpair == cs_owner(i)) {
+            const float s = csum[i] + __shfl_xor(csum[i], 32);
+            if (h == 0) slab[(size_t)(pb * 32 + r) * ws + nchb * 32 + pl.ncb * 32] = s * sinv_acc;
+        }
+    }
+}
+
 // kernel 3: fixed-order sum of the slabs, + the p * colsum(G) term.  Four independent partial sums per output
 // (slab j goes to partial j & 3) keep several loads in flight per thread; the order is fixed, so results are
 // run-to-run identical.
@@ -717,7 +985,14 @@ template <int NPB, int NCB>
 static hipError_t launch_bank_x(const SpxBankBwdArgs& a, int x_dtype, dim3 grid, hipStream_t s) {
     if constexpr (NCB == 1) {
         // one class block: d_W comes from kernel 1's tile partials (spx_dw_reduce_kernel), this kernel carries d_bank only
-        return a.d_bank ? launch_bank_pw<NPB, NCB, true, false>(a, x_dtype, grid, s) : hipSuccess;
+        if (!a.d_bank) return hipSuccess;
+        if (x_dtype == 0 && a.vec_ok == 1 && a.HW % 64 == 0 && a.plan.channels_per_scale > 64) {
+            constexpr size_t lds = (size_t)spx_bd_lds_bytes<NPB>();
+            static_assert(lds <= SPX_LDS_LIMIT, "bank kernel LDS");
+            hipLaunchKernelGGL((spx_bank_dma_kernel<NPB>), grid, dim3(SPX_BK_THREADS), lds, s, a);
+            return hipGetLastError();
+        }
+        return launch_bank_pw<NPB, NCB, true, false>(a, x_dtype, grid, s);
     } else if constexpr (NCB < 5) {
         if (!a.d_bank) return launch_bank_pw<NPB, NCB, false, true>(a, x_dtype, grid, s);
         return launch_bank_pw<NPB, NCB, true, true>(a, x_dtype, grid, s);

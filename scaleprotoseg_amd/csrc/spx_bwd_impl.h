@@ -661,38 +661,34 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
         // dAct scratch in the way there is one image and a second barrier behind the reads).
         auto dw_stage = [&](int pb, auto buf_c) {
             constexpr int BUF = decltype(buf_c)::value;
-#ifdef SPX_DIAG_DW_NOSTAGE
-            return;                  // timing-only builds (results are wrong): no product, or no barrier in front of it
-#endif
-#ifndef SPX_DIAG_DW_NOBAR
             __syncthreads();
-#endif
             const int lane = spx_opaque((int)threadIdx.x) & 63;     // (see spx_opaque)
             const int g = lane >> 4, li = lane & 15, qq = li >> 2, pp = li & 3;
-            // transposed-read rows of this lane: pixels 8 g + qq and 8 g + qq + 4 of the k-step, under the row permutation
-            const int row0 = 8 * g + qq + 4 * (g & 1), row1 = 8 * g + qq + 4 * (1 - (g & 1));
             const int pg = wave & 1, cg = wave >> 1;
-            const char* const ab = a_img + (NABUF == 2 ? BUF * SPX_DW_IMG : 0) + pg * 2048 + pp * 8;
-            const char* const lb = l_img + cg * 2048 + pp * 8;
-            f32x4 dw;
+            const bool live = 16 * cg < K;                          // wave-uniform: the class cell holds a real class
+            // (two accumulators: the hi.hi chain and the two correction terms run side by side, summed once)
+            f32x4 dw, dw2;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) dw[i] = 0.0f;
-            auto frag = [&](const char* p0) -> bf16x8 {
-                const bf16x4 t0 = __builtin_bit_cast(bf16x4, lds_tr_read(p0 + row0 * 32));
-                const bf16x4 t1 = __builtin_bit_cast(bf16x4, lds_tr_read(p0 + row1 * 32));
-                return __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7);
-            };
+            for (int i = 0; i < 4; ++i) dw[i] = dw2[i] = 0.0f;
+            if (live) {
+                // transposed-read rows of this lane: pixels 8 g + qq and 8 g + qq + 4 of the k-step, under the row permutation
+                const int row0 = 8 * g + qq + 4 * (g & 1), row1 = 8 * g + qq + 4 * (1 - (g & 1));
+                const char* const ab = a_img + (NABUF == 2 ? BUF * SPX_DW_IMG : 0) + pg * 2048 + pp * 8;
+                const char* const lb = l_img + cg * 2048 + pp * 8;
+                auto frag = [&](const char* p0) -> bf16x8 {
+                    const bf16x4 t0 = __builtin_bit_cast(bf16x4, lds_tr_read(p0 + row0 * 32));
+                    const bf16x4 t1 = __builtin_bit_cast(bf16x4, lds_tr_read(p0 + row1 * 32));
+                    return __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7);
+                };
 #pragma unroll
-#ifdef SPX_DIAG_DW_ONEKS
-            for (int ks = 0; ks < 1; ++ks) {
-#else
-            for (int ks = 0; ks < 4; ++ks) {
-#endif
-                const bf16x8 ah = frag(ab + ks * 4096), al = frag(ab + ks * 4096 + 1024);
-                const bf16x8 lh = frag(lb + ks * 4096), ll = frag(lb + ks * 4096 + 1024);
-                dw = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, lh, dw, 0, 0, 0);
-                dw = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, lh, dw, 0, 0, 0);
-                dw = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, ll, dw, 0, 0, 0);
+                for (int ks = 0; ks < 4; ++ks) {
+                    const bf16x8 ah = frag(ab + ks * 4096), al = frag(ab + ks * 4096 + 1024);
+                    const bf16x8 lh = frag(lb + ks * 4096), ll = frag(lb + ks * 4096 + 1024);
+                    dw = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, lh, dw, 0, 0, 0);
+                    dw2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, lh, dw2, 0, 0, 0);
+                    dw2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, ll, dw2, 0, 0, 0);
+                }
+                dw += dw2;
             }
             if (NABUF == 1) __syncthreads();
             // accumulator row 4 g + i <-> position 4 g + i of the prototype cell <-> prototype 8 (g & 1) + 4 (g >> 1) + i
@@ -701,9 +697,6 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
             const int cls = 16 * cg + (a.packed_tailT ? 8 * ((li >> 2) & 1) + 4 * (li >> 3) + (li & 3) : li);
             const spx_rsrc dwr = make_rsrc_pred((char*)a.a_out + ((((size_t)panel * ntiles + tile_g) * NPB + pb) * K) * 128);
             const uint32_t vo = cls < K ? (uint32_t)(cls * 128 + (16 * pg + 8 * (g & 1) + 4 * (g >> 1)) * 4) : SPX_OOB;
-#ifdef SPX_DIAG_DW_NOSTORE
-            if (dw[0] == 1.2345f)
-#endif
             buf_store_b128(__builtin_bit_cast(u32x4, dw), dwr, vo, 0);
         };
         // ROLLED loop, two blocks per iteration from the static slots 0 and 1 (static dDist buffers too), then one

@@ -144,6 +144,10 @@ BWD_SHAPES = [
     (1, 1, 64, 210, 21, 13, 11),
     (1, 2, 16, 16, 3, 5, 7),
     (1, 4, 64, 1800, 150, 5, 8),
+    # bf16 features, H*W a multiple of 64, scales wider than 64 channels, one class block: the LDS-DMA parameter kernel
+    (2, 1, 96, 100, 7, 8, 24),       # 3 units per image (the last tile half empty), 96 channels (zero rows), 4-block panel
+    (1, 2, 128, 600, 19, 16, 40),    # two scales x two panels of 150
+    (3, 1, 80, 40, 5, 8, 8),         # one unit per image, 2-block panel
 ]
 
 
