@@ -35,7 +35,7 @@ extern "C" {
 #endif
 
 #define SPX_MAX_PANELS 64   /* (scale, <=192-prototype block) work units per pixel tile */
-#define SPX_ABI_VERSION 12
+#define SPX_ABI_VERSION 13
 
 /* How the prototype bank is cut into MFMA panels.  Filled by spx_make_plan(). */
 typedef struct spx_plan {
@@ -224,8 +224,8 @@ int spx_dist_bwd_group_ce(const spx_plan* plan, const void* x, int32_t x_dtype, 
                           const void* packed_bank, const void* packed_bankT, const float* packed_p2,
                           const void* packed_headT_units, const void* packed_tailT, int32_t K2,
                           const float* group_activations, const float* d_dist, const float* d_act,
-                          const spx_ce* ce, float* d_units, void* dx, void* g_out, void* a_out,
-                          float epsilon, int32_t act_fn, void* stream);
+                          const spx_ce* ce, const float* d_group_activations, float* d_units, void* dx, void* g_out,
+                          void* a_out, float epsilon, int32_t act_fn, void* stream);
 
 /* Grouping head with its tail fused (segmentation/model/model_multiscale_group.py:283-308, run_last_layer):
  *   units = act . Wd^T   (Wd = the dense [U = G*K', P] form of the per-class group_projection matrices, packed with
@@ -235,8 +235,12 @@ int spx_dist_bwd_group_ce(const spx_plan* plan, const void* x, int32_t x_dtype, 
  * spx_pack_headT_units is spx_pack_head's transposed output with the unit index in accumulator order (the
  * backward builds its dUnits operand in registers): spx_packed_headT_bytes().
  * Forward: logits [B*HW, K2]; group_activations [B*HW, U] = g (optional output, required by the backward).
- * Backward: d_logits [B*HW, K2] in; d_units [B*HW, U] = (d_logits . W_g) * g out (the d_logits operand of
- * spx_bank_bwd, which then yields d_Wd); d_W_g = d_logits^T . g is a [K2, U] product left to the caller. */
+ * Backward: d_logits [B*HW, K2] in, optionally d_group_activations [B*HW, U] (a gradient on g itself: KLDLossGroup on
+ * compute_group's list, segmentation/model/module_multiscale_group_train.py:242-262; NULL = none); d_units [B*HW, U] =
+ * (d_logits . W_g + d_group_activations) * g out (the d_logits operand of spx_bank_bwd, which then yields d_Wd);
+ * d_W_g = d_logits^T . g is a [K2, U] product left to the caller.
+ * spx_exp / spx_exp_bwd: y = exp(x) and dx = g * y over n fp32 elements - the same g for heads the fused kernels do not
+ * carry, and for compute_group() on activations that did not come out of the fused forward. */
 size_t spx_packed_tail_bytes(const spx_plan* plan);
 int spx_pack_group_tail(const spx_plan* plan, const float* Wg, int32_t K2, void* packed_tail, void* packed_tailT,
                         void* stream);
@@ -250,8 +254,10 @@ int spx_dist_bwd_group(const spx_plan* plan, const void* x, int32_t x_dtype, int
                        const void* packed_bank, const void* packed_bankT, const float* packed_p2,
                        const void* packed_headT_units, const void* packed_tailT, int32_t K2,
                        const float* group_activations, const float* d_dist, const float* d_act,
-                       const float* d_logits, float* d_units, void* dx, void* g_out, void* a_out,
-                       float epsilon, int32_t act_fn, void* stream);
+                       const float* d_logits, const float* d_group_activations, float* d_units, void* dx, void* g_out,
+                       void* a_out, float epsilon, int32_t act_fn, void* stream);
+int spx_exp(const float* x, float* y, int64_t n, void* stream);
+int spx_exp_bwd(const float* g, const float* y, float* dx, int64_t n, void* stream);
 
 /* Bytes of the g_out and of the a_out scratch of spx_dist_bwd. */
 size_t spx_bwd_scratch_bytes(const spx_plan* plan, int32_t B, int32_t HW);

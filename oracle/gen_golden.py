@@ -219,6 +219,49 @@ def case_group_phase(msg, ms, name, *, B, S, Cs, K, P, H, W, G):
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
 
 
+def case_group_train_step(msg, ms, lossmod, name, *, B, S, Cs, K, P, H, W, G):
+    """The group-phase training step's call pattern (module_multiscale_group_train.py:222-262): forward with activations and
+    distances -> compute_group(activations) -> cross entropy on the logits + KLDLossGroup on the group activations
+    (+ a linear term on the distances, standing in for the other distance-side losses)."""
+    torch.manual_seed(SEED + 5)
+    old = _make_proto_phase(ms, P=P, Cs=Cs, S=S, K=K)
+    net = msg.PPNetMultiScale(
+        features=_Backbone(Cs * S), img_size=64, prototype_shape=(P, Cs, 1, 1), proto_layer_rf_info=[], num_classes=K,
+        init_weights=True, add_on_layers_type="deeplab_simple", patch_classification=True, num_scales=S, num_groups=G,
+    )
+    net.load_state_dict(old.state_dict(), strict=False)
+    with torch.no_grad():
+        net.last_layer_group.weight.add_(0.05 * torch.randn_like(net.last_layer_group.weight))
+    conv = _bf16r(torch.sigmoid(torch.randn(B, S * Cs, H, W)))
+    target = torch.randint(0, K + 1, (B, H, W))
+    g_dist = torch.randn(B, P, H, W) * 1e-3
+    w_kld = 0.25
+
+    x = conv.clone().requires_grad_(True)
+    logits, dist, act = net.forward_from_conv_features(x, return_activations=True, return_distances=True)
+    groups = net.compute_group(act)
+    ce = lossmod.PixelWiseCrossEntropyLoss(ignore_index=-1)(predicted_logits=logits, target_labels=target)
+    kld = lossmod.KLDLossGroup(net.prototype_class_identity, net.group_class_identity, G)(
+        list_group_activation=groups, target_labels=target)
+    loss = ce + w_kld * kld + (dist * g_dist).sum()
+    net.zero_grad()
+    loss.backward()
+    out = dict(
+        conv=_np(conv), prototype_vectors=_np(net.prototype_vectors), class_identity=_np(net.prototype_class_identity),
+        group_class_identity=_np(net.group_class_identity),
+        scale_ranges=np.array([net.scale_num_prototypes[s] for s in range(S)], dtype=np.int64),
+        num_scales=np.int64(S), num_groups=np.int64(G), last_layer_group_weight=_np(net.last_layer_group.weight),
+        target=target.numpy().astype(np.int64), g_dist=_np(g_dist), w_kld=np.float32(w_kld),
+        logits=_np(logits), group_cat=_np(torch.cat(groups, dim=-1)), ce=_np(ce), kld=_np(kld), loss=_np(loss),
+        d_conv=_np(x.grad), d_prototypes=_np(net.prototype_vectors.grad),
+        d_last_layer_group=_np(net.last_layer_group.weight.grad),
+    )
+    for i, gp in enumerate(net.group_projection):
+        out[f"group_w_{i}"] = _np(gp.weight)
+        out[f"d_group_w_{i}"] = _np(gp.weight.grad)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+
+
 def case_single_scale(m1, name, *, B, Cs, K, P, H, W):
     torch.manual_seed(SEED + 2)
     net = m1.PPNet(
@@ -438,6 +481,7 @@ def main():
     case_proto_phase(ms, "proto_floor", B=1, S=2, Cs=16, K=3, P=16, H=4, W=5)
     case_proto_phase(ms, "proto_s1_wide", B=1, S=1, Cs=256, K=19, P=190, H=6, W=7)
     case_group_phase(msg, ms, "group_ms_small", B=2, S=4, Cs=16, K=5, P=40, H=9, W=11, G=3)
+    case_group_train_step(msg, ms, lossmod, "group_train_step", B=2, S=4, Cs=16, K=5, P=40, H=9, W=11, G=3)
     case_single_scale(m1, "ppnet_single", B=2, Cs=32, K=5, P=20, H=7, W=9)
     case_push(push, dsmod, ms, "push_argmin")
     case_misc(ms, utils, "misc")

@@ -15,7 +15,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libspx_hip.so")
 SPX_MAX_PANELS = 64
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 
 class SpxError(RuntimeError):
@@ -78,7 +78,7 @@ SIGNATURES = {
     "spx_pack_group_tail": (C.c_int, [_PP, _V, _I, _V, _V, _V]),
     "spx_pack_headT_units": (C.c_int, [_PP, _V, _V, _V]),
     "spx_dist_fwd_group": (C.c_int, [_PP, _V, _I, _I, _I, _V, _V, _V, _V, _I, _V, _V, _V, _V, _F, _I, _V]),
-    "spx_dist_bwd_group": (C.c_int, [_PP, _V, _I, _I, _I, _V, _V, _V, _V, _V, _I, _V, _V, _V, _V, _V, _V, _V, _V, _F, _I, _V]),
+    "spx_dist_bwd_group": (C.c_int, [_PP, _V, _I, _I, _I, _V, _V, _V, _V, _V, _I, _V, _V, _V, _V, _V, _V, _V, _V, _V, _F, _I, _V]),
     "spx_bwd_scratch_bytes": (C.c_size_t, [_PP, _I, _I]),
     "spx_bwd_head_scratch_bytes": (C.c_size_t, [_PP, _I, _I]),
     "spx_bank_bwd_workspace_bytes": (C.c_size_t, [_PP, _I, _I]),
@@ -98,7 +98,9 @@ SIGNATURES = {
     "spx_dist_fwd_ws": (C.c_int, [_PP, _V, _I, _I, _I, _V, _V, _V, _V, _V, _I, _V, _V, _V, _V, _V, _F, _I, _V]),
     "spx_group_tail_workspace_bytes": (C.c_size_t, [_PP, _I, _I]),
     "spx_dist_fwd_group_ws": (C.c_int, [_PP, _V, _I, _I, _I, _V, _V, _V, _V, _I, _V, _V, _V, _V, _PCE, _V, _F, _I, _V]),
-    "spx_dist_bwd_group_ce": (C.c_int, [_PP, _V, _I, _I, _I, _V, _V, _V, _V, _V, _I, _V, _V, _V, _PCE, _V, _V, _V, _V, _F, _I, _V]),
+    "spx_dist_bwd_group_ce": (C.c_int, [_PP, _V, _I, _I, _I, _V, _V, _V, _V, _V, _I, _V, _V, _V, _PCE, _V, _V, _V, _V, _V, _F, _I, _V]),
+    "spx_exp": (C.c_int, [_V, _V, C.c_int64, _V]),
+    "spx_exp_bwd": (C.c_int, [_V, _V, _V, C.c_int64, _V]),
     "spx_pixel_outer_workspace_bytes": (C.c_size_t, [C.c_int64, _I, _I]),
     "spx_pixel_outer": (C.c_int, [_V, _V, C.c_int64, _I, _I, _V, _V, _V]),
     "spx_rows_gemm_workspace_bytes": (C.c_size_t, [_I, _I, _I, _I]),

@@ -185,7 +185,7 @@ int spx_pack_headT_units(const spx_plan* pl, const float* W, void* packed_headT_
 }
 
 struct SpxTailFwd { const void* packed_tail; int32_t K2; float* gact; };
-struct SpxTailBwd { const void* packed_tailT; int32_t K2; const float* gact; float* d_units; };
+struct SpxTailBwd { const void* packed_tailT; int32_t K2; const float* gact; float* d_units; const float* d_gact; };
 
 static int dist_fwd_impl(const spx_plan* pl, const void* x, int32_t x_dtype, int32_t B, int32_t HW,
                          const void* packed_bank, const float* packed_p2, const void* packed_head, float* distances,
@@ -344,7 +344,7 @@ static int dist_bwd_impl(const spx_plan* pl, const void* x, int32_t x_dtype, int
                          const void* packed_headT, const float* d_dist, const int32_t* labels,
                          const uint32_t* proto_key, int32_t J, const float* d_cls_dist, const float* d_act,
                          const float* d_logits, void* dx, void* g_out, void* a_out, float epsilon, int32_t act_fn,
-                         void* stream, SpxTailBwd tail = SpxTailBwd{nullptr, 0, nullptr, nullptr}, const spx_ce* ce = nullptr) {
+                         void* stream, SpxTailBwd tail = SpxTailBwd{nullptr, 0, nullptr, nullptr, nullptr}, const spx_ce* ce = nullptr) {
     if (check_plan(pl)) return 1;
     if (!x || !packed_bank || !packed_p2) return fail("spx_dist_bwd: NULL operand");
     if (x_dtype != 0 && x_dtype != 1) return fail("spx_dist_bwd: x_dtype %d", x_dtype);
@@ -375,6 +375,7 @@ static int dist_bwd_impl(const spx_plan* pl, const void* x, int32_t x_dtype, int
     a.packed_tailT = (const char*)tail.packed_tailT;
     a.gact = tail.gact;
     a.d_units = tail.d_units;
+    a.d_gact = tail.d_gact;
     a.K2 = tail.K2;
     a.ce_labels = ce ? ce->labels : nullptr;
     a.ce_logits = ce ? ce->logits : nullptr;
@@ -406,28 +407,29 @@ int spx_dist_bwd_group(const spx_plan* pl, const void* x, int32_t x_dtype, int32
                        const void* packed_bank, const void* packed_bankT, const float* packed_p2,
                        const void* packed_headT_units, const void* packed_tailT, int32_t K2,
                        const float* group_activations, const float* d_dist, const float* d_act,
-                       const float* d_logits, float* d_units, void* dx, void* g_out, void* a_out, float epsilon,
-                       int32_t act_fn, void* stream) {
+                       const float* d_logits, const float* d_group_activations, float* d_units, void* dx, void* g_out,
+                       void* a_out, float epsilon, int32_t act_fn, void* stream) {
     if (!packed_headT_units || !packed_tailT || !group_activations || !d_logits || !d_units)
         return fail("spx_dist_bwd_group: NULL tail operand");
     if (K2 < 1 || K2 > 32) return fail("spx_dist_bwd_group: %d classes (at most 32)", K2);
     return dist_bwd_impl(pl, x, x_dtype, B, HW, packed_bank, packed_bankT, packed_p2, packed_headT_units, d_dist,
                          nullptr, nullptr, 0, nullptr, d_act, d_logits, dx, g_out, a_out, epsilon, act_fn, stream,
-                         SpxTailBwd{packed_tailT, K2, group_activations, d_units});
+                         SpxTailBwd{packed_tailT, K2, group_activations, d_units, d_group_activations});
 }
 
 int spx_dist_bwd_group_ce(const spx_plan* pl, const void* x, int32_t x_dtype, int32_t B, int32_t HW,
                           const void* packed_bank, const void* packed_bankT, const float* packed_p2,
                           const void* packed_headT_units, const void* packed_tailT, int32_t K2,
                           const float* group_activations, const float* d_dist, const float* d_act, const spx_ce* ce,
-                          float* d_units, void* dx, void* g_out, void* a_out, float epsilon, int32_t act_fn, void* stream) {
+                          const float* d_group_activations, float* d_units, void* dx, void* g_out, void* a_out, float epsilon,
+                          int32_t act_fn, void* stream) {
     if (!ce) return fail("spx_dist_bwd_group_ce: NULL ce");
     if (!packed_headT_units || !packed_tailT || !group_activations || !d_units)
         return fail("spx_dist_bwd_group_ce: NULL tail operand");
     if (K2 < 1 || K2 > 32) return fail("spx_dist_bwd_group_ce: %d classes (at most 32)", K2);
     return dist_bwd_impl(pl, x, x_dtype, B, HW, packed_bank, packed_bankT, packed_p2, packed_headT_units, d_dist,
                          nullptr, nullptr, 0, nullptr, d_act, nullptr, dx, g_out, a_out, epsilon, act_fn, stream,
-                         SpxTailBwd{packed_tailT, K2, group_activations, d_units}, ce);
+                         SpxTailBwd{packed_tailT, K2, group_activations, d_units, d_group_activations}, ce);
 }
 
 int spx_dist_bwd_cls(const spx_plan* pl, const void* x, int32_t x_dtype, int32_t B, int32_t HW,
@@ -493,7 +495,7 @@ int spx_dist_bwd_ce(const spx_plan* pl, const void* x, int32_t x_dtype, int32_t 
     return dist_bwd_impl(pl, x, x_dtype, B, HW, packed_bank, packed_bankT, packed_p2, packed_headT, d_dist,
                          (labels_cls && d_class_distances) ? labels_cls : nullptr, proto_key, labels_cls ? J : 0,
                          labels_cls ? d_class_distances : nullptr, d_act, nullptr, dx, g_out, a_out, epsilon, act_fn, stream,
-                         SpxTailBwd{nullptr, 0, nullptr, nullptr}, ce);
+                         SpxTailBwd{nullptr, 0, nullptr, nullptr, nullptr}, ce);
 }
 
 size_t spx_pixel_outer_workspace_bytes(int64_t M, int32_t n1, int32_t n2) {
@@ -522,6 +524,15 @@ int spx_rows_gemm(const float* A, int64_t ras, int64_t kas, const float* B, int6
     if (spx_gemm_workspace(M, N, K, flags) && !workspace) return fail("spx_rows_gemm: workspace needed (spx_rows_gemm_workspace_bytes)");
     return hip_status(spx_launch_gemm(A, ras, kas, B, rbs, kbs, C, ldc, M, N, K, flags, E, lde, (float*)workspace, (hipStream_t)stream),
                       "spx_rows_gemm");
+}
+
+int spx_exp(const float* x, float* y, int64_t n, void* stream) {
+    if (!x || !y || n < 1 || (n + 255) / 256 > 0x7fffffffLL) return fail("spx_exp: bad arguments");
+    return hip_status(spx_launch_exp(x, nullptr, nullptr, y, n, (hipStream_t)stream), "spx_exp");
+}
+int spx_exp_bwd(const float* g, const float* y, float* dx, int64_t n, void* stream) {
+    if (!g || !y || !dx || n < 1 || (n + 255) / 256 > 0x7fffffffLL) return fail("spx_exp_bwd: bad arguments");
+    return hip_status(spx_launch_exp(nullptr, g, y, dx, n, (hipStream_t)stream), "spx_exp_bwd");
 }
 
 int spx_ce_fwd(const float* logits, const int32_t* labels, int64_t M, int32_t K, float* lse, int32_t* pred, float* partials,

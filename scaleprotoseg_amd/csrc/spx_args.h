@@ -61,6 +61,7 @@ struct SpxBwdArgs {
     const char* packed_tailT;   // W_g^T A-fragments; NULL = no tail
     const float* gact;          // [B*HW, U] exp(units) of the forward
     float* d_units;             // [B*HW, U] written for the parameter kernel
+    const float* d_gact;        // [B*HW, U] gradient on g = exp(units) itself (may be NULL)
     int K2;
     int ngroups;                // scale-parallel launch (see SpxFwdArgs); 1 = off
     int32_t group_first[SPX_MAX_PANELS + 1];
@@ -135,6 +136,7 @@ hipError_t spx_launch_ce_fwd(const float* logits, const int32_t* labels, long lo
                              float* partials, hipStream_t s);
 hipError_t spx_launch_ce_bwd(const float* logits, const float* lse, const int32_t* labels, const float* coef, long long M, int K,
                              float* d_logits, hipStream_t s);
+hipError_t spx_launch_exp(const float* x, const float* g, const float* y, float* out, long long n, hipStream_t s);
 hipError_t spx_launch_kld_lse(const uint32_t* keys, const uint64_t* ssum_fx, int n, float* lse, const uint32_t* range_keys, int HW,
                               double* scale_out, hipStream_t s);
 hipError_t spx_launch_kld_gram_loss(const int64_t* a_fx, const double* scale, const uint32_t* counts, const uint8_t* pair_ok, int nseg, int K,

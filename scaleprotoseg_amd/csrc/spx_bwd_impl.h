@@ -244,6 +244,10 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
         const spx_rsrc ttr = make_rsrc(a.packed_tailT);
         const spx_rsrc gir = make_rsrc_pred(a.gact + (size_t)b * a.HW * K);
         const spx_rsrc dur = make_rsrc_pred(a.d_units + (size_t)b * a.HW * K);
+        // a gradient that arrives on the group activations themselves (KLDLossGroup on compute_group's list,
+        // module_multiscale_group_train.py:242-262): dUnits = (W_g^T . dLogits + dG) * g.  Plain per-lane loads: the step that
+        // carries this term runs on crops, and the coalescing scratch is taken by g / dUnits.
+        const spx_rsrc dgr = make_rsrc_pred(a.d_gact ? a.d_gact + (size_t)b * a.HW * K : nullptr);
         const uint32_t voff_u = px_ok ? ((uint32_t)px * (uint32_t)K + (uint32_t)(4 * h)) * 4u : SPX_OOB;     // [px][unit]
         if (BLK) block_fetch(a.gact + (size_t)b * a.HW * K, K);       // g of the wave's pixels; dUnits overwrite it in place
 #pragma unroll
@@ -267,6 +271,7 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
 #ifdef SPX_DIAG_NO_UNIT_IO
                 dg[reg] *= 1.0f;             // timing-only build: prices the [px][unit] loads / stores (results are wrong)
 #else
+                if (a.d_gact) dg[reg] += buf_load_f32(dgr, u < K ? voff_u : SPX_OOB, so);     // (wave-uniform branch)
                 if (BLK) {
                     const float gval = u < K ? bsc[r * K + u] : 0.0f;     // zeros past the image: dropped loads
                     dg[reg] *= gval;

@@ -254,3 +254,17 @@ hipError_t spx_launch_ce_bwd(const float* logits, const float* lse, const int32_
     hipLaunchKernelGGL(spx_ce_bwd_kernel, dim3(grid), dim3(SPX_CE_THREADS), 0, s, logits, lse, labels, coef, M, K, d_logits);
     return hipGetLastError();
 }
+
+// g = exp(units) of the grouping head as a stand-alone elementwise kernel (compute_group on activations that did not come
+// out of the fused forward, and the heads wider than the fused kernels; segmentation/model/model_multiscale_group.py:283-303):
+// forward out = exp(x); backward (g, y given) out = g * y.
+__global__ __launch_bounds__(SPX_CE_THREADS) void spx_exp_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                               const float* __restrict__ y, float* __restrict__ out, long long n) {
+    const long long i = (long long)blockIdx.x * SPX_CE_THREADS + threadIdx.x;
+    if (i >= n) return;
+    out[i] = g ? g[i] * y[i] : expf(x[i]);
+}
+hipError_t spx_launch_exp(const float* x, const float* g, const float* y, float* out, long long n, hipStream_t s) {
+    hipLaunchKernelGGL(spx_exp_kernel, dim3((unsigned)((n + SPX_CE_THREADS - 1) / SPX_CE_THREADS)), dim3(SPX_CE_THREADS), 0, s, x, g, y, out, n);
+    return hipGetLastError();
+}

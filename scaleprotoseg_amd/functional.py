@@ -289,6 +289,35 @@ class _WideGroupTailFn(torch.autograd.Function):
         return du, dwg
 
 
+class _ExpFn(torch.autograd.Function):
+    """g = exp(units) as a HIP elementwise kernel pair (spx_exp / spx_exp_bwd): the group activations of compute_group
+    (segmentation/model/model_multiscale_group.py:299-300) outside the fused forward."""
+
+    @staticmethod
+    def forward(ctx, x):
+        lib = _lib.load()
+        x = x.contiguous().float()
+        y = torch.empty_like(x)
+        _lib.check(lib.spx_exp(_lib.ptr(x), _lib.ptr(y), x.numel(), _lib.stream_ptr()))
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        (y,) = ctx.saved_tensors
+        g = g.contiguous().float()
+        dx = torch.empty_like(y)
+        _lib.check(lib.spx_exp_bwd(_lib.ptr(g), _lib.ptr(y), _lib.ptr(dx), y.numel(), _lib.stream_ptr()))
+        return dx
+
+
+def group_exp(units: torch.Tensor) -> torch.Tensor:
+    if not units.is_cuda:
+        raise SpxError("scaleprotoseg_amd runs on an AMD GPU only; there is no CPU fallback")
+    return _ExpFn.apply(units)
+
+
 def wide_group_tail(units: torch.Tensor, wg: torch.Tensor) -> torch.Tensor:
     if not units.is_cuda:
         raise SpxError("scaleprotoseg_amd runs on an AMD GPU only; there is no CPU fallback")
@@ -500,7 +529,7 @@ class _ProtoHeadFn(torch.autograd.Function):
         ctx.save_for_backward(x, bank2d, head2d, logits if ce_state is not None else None)
         ctx.bank_shape = tuple(bank.shape)
         outs = tuple(t if t is not None else x.new_empty(0) for t in (logits, dist, act))
-        extra = gact if tail2d is not None else x.new_empty(0)     # exp(units): an output for the caller, no gradient path
+        extra = gact if tail2d is not None else x.new_empty(0)     # exp(units): compute_group's list; a gradient on it enters the backward's dUnits
         ce_loss, ce_pred = x.new_empty(0), x.new_empty(0)
         ctx.ce_state = ctx.ce_count = None
         if ce_state is not None:
@@ -508,12 +537,12 @@ class _ProtoHeadFn(torch.autograd.Function):
             ce_loss = tot[0] / tot[1]                               # 0 / 0 = nan when every pixel is ignored, as torch's mean
             ce_pred = ce_state[2]
             ctx.ce_state, ctx.ce_count = ce_state, tot[1]
-        ctx.mark_non_differentiable(*([o for o, h in zip(outs, ctx.have) if not h] + [extra, ce_pred]
+        ctx.mark_non_differentiable(*([o for o, h in zip(outs, ctx.have) if not h] + ([extra] if tail2d is None else []) + [ce_pred]
                                       + ([ce_loss] if ce_state is None else [])))
         return outs + (extra, ce_loss, ce_pred)
 
     @staticmethod
-    def backward(ctx, g_logits, g_dist, g_act, _g_gact=None, g_ce=None, _g_pred=None):
+    def backward(ctx, g_logits, g_dist, g_act, g_gact=None, g_ce=None, _g_pred=None):
         lib = _lib.load()
         x, bank2d, head2d, ce_logits = ctx.saved_tensors
         layout, plan, packs = ctx.layout, ctx.plan, ctx.packs
@@ -531,7 +560,7 @@ class _ProtoHeadFn(torch.autograd.Function):
         xd = _x_dtype_code(x)
         scr = lib.spx_bwd_scratch_bytes(pp, B, HW)
         with_ce = ctx.ce_state is not None and g_ce is not None
-        need_head = need_head and (gl is not None or with_ce)
+        need_head = need_head and (gl is not None or with_ce or (ctx.tail2d is not None and g_gact is not None))
         s = _lib.stream_ptr()
         ce = d_logits_ce = None
         if with_ce:
@@ -552,8 +581,11 @@ class _ProtoHeadFn(torch.autograd.Function):
         g_scr = torch.empty(scr, dtype=torch.uint8, device=dev) if need_bank else None
         a_scr = torch.empty(lib.spx_bwd_head_scratch_bytes(pp, B, HW), dtype=torch.uint8, device=dev) if need_head else None
         tail2d, d_units, d_tail = ctx.tail2d, None, None
+        gg = g_gact.contiguous().float() if (tail2d is not None and g_gact is not None) else None
         if tail2d is not None and gl is None and ce is None:
-            raise SpxError("backward through the fused group tail without a logits gradient")
+            if gg is None:
+                raise SpxError("backward through the fused group tail without a logits gradient")
+            gl = torch.zeros((B * HW, int(tail2d.shape[0])), dtype=torch.float32, device=dev)   # only the group activations carry one
         d_bank = d_head = None
         with _timed("spx_dist_bwd"):
             if tail2d is not None and ce is not None:
@@ -562,7 +594,7 @@ class _ProtoHeadFn(torch.autograd.Function):
                     lib.spx_dist_bwd_group_ce(
                         pp, _lib.ptr(x), xd, B, HW, _lib.ptr(packs.bank), _lib.ptr(packs.bankT), _lib.ptr(packs.p2),
                         _lib.ptr(packs.headT), _lib.ptr(packs.tailT), int(tail2d.shape[0]), _lib.ptr(ctx.gact),
-                        _lib.ptr(gd), _lib.ptr(ga), C.byref(ce), _lib.ptr(d_units), _lib.ptr(dx), _lib.ptr(g_scr),
+                        _lib.ptr(gd), _lib.ptr(ga), C.byref(ce), _lib.ptr(gg), _lib.ptr(d_units), _lib.ptr(dx), _lib.ptr(g_scr),
                         _lib.ptr(a_scr), ctx.epsilon, ACT_FN[ctx.act_fn], s,
                     )
                 )
@@ -572,7 +604,7 @@ class _ProtoHeadFn(torch.autograd.Function):
                     lib.spx_dist_bwd_group(
                         pp, _lib.ptr(x), xd, B, HW, _lib.ptr(packs.bank), _lib.ptr(packs.bankT), _lib.ptr(packs.p2),
                         _lib.ptr(packs.headT), _lib.ptr(packs.tailT), int(tail2d.shape[0]), _lib.ptr(ctx.gact),
-                        _lib.ptr(gd), _lib.ptr(ga), _lib.ptr(gl), _lib.ptr(d_units), _lib.ptr(dx), _lib.ptr(g_scr),
+                        _lib.ptr(gd), _lib.ptr(ga), _lib.ptr(gl), _lib.ptr(gg), _lib.ptr(d_units), _lib.ptr(dx), _lib.ptr(g_scr),
                         _lib.ptr(a_scr), ctx.epsilon, ACT_FN[ctx.act_fn], s,
                     )
                 )
@@ -662,11 +694,12 @@ def proto_head_forward(
     if ce_labels is not None:
         # fused cross entropy: a 4th entry (loss, argmax prediction per pixel); the loss is
         # differentiable through the same backward as the logits
-        return (logits, dist if (want_distances or class_gather is not None) else None,
-                act if want_activations else None, FusedCrossEntropy(ce_loss, ce_pred, ce_labels))
+        out = (logits, dist if (want_distances or class_gather is not None) else None,
+               act if want_activations else None, FusedCrossEntropy(ce_loss, ce_pred, ce_labels))
+        return out + (gact,) if group_tail is not None else out
     if group_tail is not None:
         # fused grouping head (model_multiscale_group.py:283-308): logits = exp(act . head^T) . group_tail^T;
-        # the 4th entry is exp(act . head^T) [B*H*W, U] (cat of compute_group's list), not differentiable here
+        # the last entry is exp(act . head^T) [B*H*W, U] (cat of compute_group's list); a gradient on it joins dUnits
         return logits, (dist if want_distances else None), (act if want_activations else None), gact
     return (
         logits if head is not None else None,

@@ -252,7 +252,9 @@ class PPNetMultiScale(_PrototypeBankMixin, nn.Module):
             self._initialize_weights()
 
     def run_last_layer(self, prototype_activations: torch.Tensor) -> torch.Tensor:
-        return self.last_layer(prototype_activations)  # :243-244 (callers outside the fused path)
+        """last_layer on given activations (model_multiscale.py:243-244; callers outside the fused path): the fp32 MFMA
+        product kernel."""
+        return wide_linear(prototype_activations, self.last_layer.weight)
 
     def forward_from_conv_features(
         self, conv_features, return_activations: bool = False, return_distances: bool = False, target_labels=None,

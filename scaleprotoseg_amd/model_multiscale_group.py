@@ -18,7 +18,7 @@ from typing import Any, List, Optional, Tuple
 import torch
 import torch.nn as nn
 
-from .functional import (MAX_FUSED_HEAD_ROWS, MAX_FUSED_TAIL_CLASSES, SpxError, cross_entropy_from_logits,
+from .functional import (MAX_FUSED_HEAD_ROWS, MAX_FUSED_TAIL_CLASSES, SpxError, cross_entropy_from_logits, group_exp,
                          proto_head_forward, wide_group_tail, wide_linear)
 from .model_multiscale import _PrototypeBankMixin, _build_add_on, _first_add_on_channels
 from .utils import projection_simplex_sort
@@ -118,18 +118,35 @@ class PPNetMultiScale(_PrototypeBankMixin, nn.Module):
         vals = torch.cat([gp.weight.reshape(-1) for gp in self.group_projection])
         return torch.zeros(ng, self.num_prototypes, device=dev, dtype=vals.dtype).index_put((rows, cols), vals)
 
+    def _group_units(self, prototype_activations: torch.Tensor):
+        """(units, g) behind ``prototype_activations``: what the forward that produced this very tensor left on it (the
+        kernels' own unit product / group activations, still attached to the autograd graph), else the dense unit product
+        act . Wd^T on the fp32 MFMA product kernels.  One of the two is None."""
+        tag = getattr(prototype_activations, "spx_group", None)
+        if tag is not None and tag[0] == prototype_activations._version:
+            return tag[1], tag[2]
+        if prototype_activations.dim() != 2 or prototype_activations.shape[1] != self.num_prototypes:
+            raise SpxError(f"prototype activations must be [M, {self.num_prototypes}], got {tuple(prototype_activations.shape)}")
+        return wide_linear(prototype_activations, self._dense_group_matrix()), None
+
     def compute_group(self, prototype_activations: torch.Tensor) -> List[torch.Tensor]:
-        """List of per-class group activations exp(act[:, idx_k] @ W_k^T) (model_multiscale_group.py:283-303).
-        Stand-alone form for callers (the KLD-group loss); the forward uses the fused dense product."""
-        ident = self.prototype_class_identity
-        outs = []
-        for j, k in enumerate(self._present_classes()):
-            idx = torch.nonzero(ident[:, k]).flatten().to(prototype_activations.device)
-            outs.append(torch.exp(self.group_projection[j](prototype_activations[:, idx])))
-        return outs
+        """List of per-class group activations exp(act[:, idx_k] @ W_k^T) (model_multiscale_group.py:283-303), as column
+        blocks of the dense form exp(act . Wd^T): for the activations a forward of this module returned, views of the
+        [M, U] tensor the fused kernel wrote (a gradient on them enters its backward as part of dUnits - the path
+        KLDLossGroup takes, module_multiscale_group_train.py:242-262); for any other activations the same product on the
+        fp32 MFMA kernels followed by the exp kernel.  No per-class gathers, no host syncs."""
+        units, g = self._group_units(prototype_activations)
+        if g is None:
+            g = group_exp(units)
+        return list(torch.split(g, [int(gp.weight.shape[0]) for gp in self.group_projection], dim=1))
 
     def run_last_layer(self, prototype_activations: torch.Tensor) -> torch.Tensor:
-        return self.last_layer_group(torch.cat(self.compute_group(prototype_activations), dim=-1))  # :305-308
+        """last_layer_group(cat(compute_group(act))) (model_multiscale_group.py:305-308): exp fused into the product kernel's
+        operand staging."""
+        units, g = self._group_units(prototype_activations)
+        if units is None:
+            return wide_linear(g, self.last_layer_group.weight)
+        return wide_group_tail(units, self.last_layer_group.weight)
 
     # ---- forward ------------------------------------------------------------------------------------
     def forward_from_conv_features(
@@ -153,7 +170,9 @@ class PPNetMultiScale(_PrototypeBankMixin, nn.Module):
             _, dist, _ = proto_head_forward(conv_features, self.prototype_vectors, None, self._layout(1), want_distances=True,
                                             epsilon=self.epsilon, activation="log")
             act = self.prototype_activation_function(dist).permute(0, 2, 3, 1).reshape(B * H * W, -1)
-            logits = wide_group_tail(wide_linear(act, wd), self.last_layer_group.weight).reshape(B, H, W, -1)
+            units = wide_linear(act, wd)
+            act.spx_group = (act._version, units, None)
+            logits = wide_group_tail(units, self.last_layer_group.weight).reshape(B, H, W, -1)
             if return_activations and not return_distances:
                 return logits, act
             if return_activations and return_distances:
@@ -177,19 +196,25 @@ class PPNetMultiScale(_PrototypeBankMixin, nn.Module):
             logits, dist, act = out[:3]
             if ce_labels is not None:
                 fused_ce = out[3]
+            if act is not None:
+                act.spx_group = (act._version, None, out[-1])        # exp(units) [M, U], written by the kernel
         elif rows <= MAX_FUSED_HEAD_ROWS:
             # up to 160 units but more than 32 classes: the unit product stays in the kernel, the tail is the fp32 MFMA product kernel (exp fused into its operand staging)
             units, dist, act = proto_head_forward(
                 conv_features, self.prototype_vectors, wd, self._layout(rows), want_activations=return_activations, **kw,
             )
             logits = wide_group_tail(units, wg)
+            if act is not None:
+                act.spx_group = (act._version, units, None)
         else:
             # group_scaleproto_ade.gin (150 classes x 3 groups = 450 units) / _coco.gin (546): the kernel hands out the
             # [pixel][P] activations once, both products are the fp32 MFMA product kernels (csrc/spx_gemm.hip) on them
             _, dist, act = proto_head_forward(
                 conv_features, self.prototype_vectors, None, self._layout(1), want_activations=True, **kw,
             )
-            logits = wide_group_tail(wide_linear(act, wd), wg)
+            units = wide_linear(act, wd)
+            act.spx_group = (act._version, units, None)
+            logits = wide_group_tail(units, wg)
         if ce_labels is not None and fused_ce is None:
             fused_ce = cross_entropy_from_logits(logits, ce_labels)       # heads the fused kernels do not carry
         logits = logits.reshape(B, H, W, -1)

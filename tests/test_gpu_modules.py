@@ -217,6 +217,43 @@ def _group_net(g, dev):
     return net.to(dev)
 
 
+def test_group_train_step_call_pattern_matches_reference(golden):
+    """The group-phase trainer's step (module_multiscale_group_train.py:222-262): forward(return_activations, return_distances)
+    -> compute_group(activations) -> cross entropy on the logits + KLDLossGroup on the list (+ a term on the distances),
+    against the reference's own run of the same step (oracle/gen_golden.py::case_group_train_step): loss values and EVERY
+    gradient.  compute_group hands out views of the group activations the fused kernel wrote; the KLD gradient on them
+    reaches the kernels' backward as part of dUnits."""
+    import scaleprotoseg_amd as spx
+
+    dev = _dev()
+    g = golden("group_train_step")
+    net = _group_net(g, dev)
+    K, G = g["class_identity"].shape[1], int(g["num_groups"])
+    conv = torch.from_numpy(g["conv"]).to(dev).requires_grad_(True)
+    target = torch.from_numpy(g["target"]).to(dev)
+    logits, dist, act = net.forward_from_conv_features(conv, return_activations=True, return_distances=True)
+    groups = net.compute_group(act)
+    assert isinstance(groups, list) and len(groups) == len(net.group_projection) and all(t.shape == (act.shape[0], G) for t in groups)
+    ref_cat = torch.from_numpy(g["group_cat"])
+    assert ((torch.cat(groups, dim=-1).detach().cpu() - ref_cat).abs() <= 2e-4 * (1 + ref_cat.abs())).all()
+    ce = spx.PixelWiseCrossEntropyLoss(ignore_index=-1)(predicted_logits=logits, target_labels=target)
+    kld = spx.KLDLossGroup(net.prototype_class_identity, net.group_class_identity, G)(list_group_activation=groups, target_labels=target)
+    assert abs(ce.item() - float(g["ce"])) <= 1e-5 * max(1.0, abs(float(g["ce"])))
+    assert abs(kld.item() - float(g["kld"])) <= 2e-4 * max(1.0, abs(float(g["kld"])))
+    loss = ce + float(g["w_kld"]) * kld + (dist * torch.from_numpy(g["g_dist"]).to(dev)).sum()
+    loss.backward()
+    _grad_close(conv.grad, g["d_conv"], "dX")
+    _grad_close(net.prototype_vectors.grad, g["d_prototypes"], "dPrototypes")
+    _grad_close(net.last_layer_group.weight.grad, g["d_last_layer_group"], "dLastLayerGroup")
+    scale = max(np.abs(g[f"d_group_w_{i}"]).max() for i in range(len(net.group_projection)))
+    for i, gp in enumerate(net.group_projection):
+        err = (gp.weight.grad.cpu() - torch.from_numpy(g[f"d_group_w_{i}"])).abs().max().item()
+        assert err <= GRAD_TOL * scale, f"d group_projection[{i}]: {err:.3e} vs {scale:.3e}"
+    # the same list from activations that did NOT come out of the forward (no attachment): the product kernels + exp kernel
+    groups2 = net.compute_group(act.detach().clone())
+    assert ((torch.cat(groups2, dim=-1).cpu() - ref_cat).abs() <= 2e-4 * (1 + ref_cat.abs())).all()
+
+
 def test_group_module_forward_backward_matches_reference(golden):
     dev = _dev()
     g = golden("group_ms_small")

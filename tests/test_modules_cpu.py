@@ -94,10 +94,15 @@ def test_group_phase_surface(golden):
         assert (w >= 0).all() and torch.allclose(w.sum(1), torch.ones(G), atol=1e-5)
     gi = net.group_class_identity.t()
     assert torch.equal(net.last_layer_group.weight.detach(), gi + net.incorrect_strength * (1 - gi))
-    # dense form of the grouping head == per-class gather + linear (compute_group), on CPU tensors
+    # dense form of the grouping head == the reference's per-class gather + linear (compute_group, restated by the oracle)
+    from oracle import ppnet_oracle as O
+
     act = torch.rand(7, P)
     dense = torch.exp(act @ net._dense_group_matrix().t())
-    np.testing.assert_allclose(dense.detach().numpy(), torch.cat(net.compute_group(act), dim=-1).detach().numpy(), rtol=1e-5, atol=1e-6)
+    ref = torch.cat(O.compute_group(act, net.prototype_class_identity, [gp.weight.detach() for gp in net.group_projection]), dim=-1)
+    np.testing.assert_allclose(dense.detach().numpy(), ref.numpy(), rtol=1e-5, atol=1e-6)
+    with pytest.raises(Exception):        # the method itself runs on the HIP kernels only: no CPU fallback
+        net.compute_group(act)
 
 
 def test_single_scale_ppnet(golden):
