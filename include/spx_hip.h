@@ -35,7 +35,7 @@ extern "C" {
 #endif
 
 #define SPX_MAX_PANELS 64   /* (scale, <=192-prototype block) work units per pixel tile */
-#define SPX_ABI_VERSION 13
+#define SPX_ABI_VERSION 14
 
 /* How the prototype bank is cut into MFMA panels.  Filled by spx_make_plan(). */
 typedef struct spx_plan {
@@ -96,12 +96,15 @@ int spx_dist_fwd(const spx_plan* plan, const void* x, int32_t x_dtype, int32_t B
  *          formed in this kernel as one fp32 partial per (panel, tile, 32-prototype block); for wider heads the activations
  *          as block-scaled int16 MFMA fragments.
  * Replaces autograd through model_multiscale.py:255-281,324-330,243-244.  d_dist / d_act / d_logits may be NULL (treated as
- * 0); dx may be NULL (X frozen); g_out / a_out may be NULL when the bank / head are frozen. */
+ * 0); dx may be NULL (X frozen); g_out / a_out may be NULL when the bank / head are frozen.
+ *   dx_acc spx_bwd_dx_scratch_bytes() (0 for most plans -> NULL): a scale of more than 192 prototypes is walked as several
+ *          panels, each adding its share of dX; with bf16 features that sum runs in this fp32 scratch and dX is rounded
+ *          once (NULL: the partial sums pass through the bf16 dX, one rounding per panel). */
 int spx_dist_bwd(const spx_plan* plan, const void* x, int32_t x_dtype, int32_t B, int32_t HW,
                  const void* packed_bank, const void* packed_bankT, const float* packed_p2,
                  const void* packed_headT,
                  const float* d_dist, const float* d_act, const float* d_logits,
-                 void* dx, void* g_out, void* a_out,
+                 void* dx, void* dx_acc, void* g_out, void* a_out,
                  float epsilon, int32_t act_fn, void* stream);
 
 /* Class-gathered variants: instead of the P-wide distance map, every pixel keeps only the
@@ -124,7 +127,7 @@ int spx_dist_bwd_cls(const spx_plan* plan, const void* x, int32_t x_dtype, int32
                      const void* packed_headT,
                      const int32_t* labels, const uint32_t* proto_key, int32_t J,
                      const float* d_class_distances, const float* d_act, const float* d_logits,
-                     void* dx, void* g_out, void* a_out,
+                     void* dx, void* dx_acc, void* g_out, void* a_out,
                      float epsilon, int32_t act_fn, void* stream);
 
 /* Scale-parallel forward for pixel grids that do not fill the chip (the reference trains on crops: 10 x 65 x 65 latent
@@ -181,7 +184,7 @@ int spx_dist_bwd_ce(const spx_plan* plan, const void* x, int32_t x_dtype, int32_
                     const void* packed_headT,
                     const int32_t* labels_cls, const uint32_t* proto_key, int32_t J,
                     const float* d_dist, const float* d_class_distances, const float* d_act, const spx_ce* ce,
-                    void* dx, void* g_out, void* a_out,
+                    void* dx, void* dx_acc, void* g_out, void* a_out,
                     float epsilon, int32_t act_fn, void* stream);
 int spx_ce_fwd(const float* logits, const int32_t* labels, int64_t M, int32_t K, float* lse, int32_t* pred,
                float* partials, void* stream);
@@ -224,7 +227,7 @@ int spx_dist_bwd_group_ce(const spx_plan* plan, const void* x, int32_t x_dtype, 
                           const void* packed_bank, const void* packed_bankT, const float* packed_p2,
                           const void* packed_headT_units, const void* packed_tailT, int32_t K2,
                           const float* group_activations, const float* d_dist, const float* d_act,
-                          const spx_ce* ce, const float* d_group_activations, float* d_units, void* dx, void* g_out,
+                          const spx_ce* ce, const float* d_group_activations, float* d_units, void* dx, void* dx_acc, void* g_out,
                           void* a_out, float epsilon, int32_t act_fn, void* stream);
 
 /* Grouping head with its tail fused (segmentation/model/model_multiscale_group.py:283-308, run_last_layer):
@@ -254,7 +257,7 @@ int spx_dist_bwd_group(const spx_plan* plan, const void* x, int32_t x_dtype, int
                        const void* packed_bank, const void* packed_bankT, const float* packed_p2,
                        const void* packed_headT_units, const void* packed_tailT, int32_t K2,
                        const float* group_activations, const float* d_dist, const float* d_act,
-                       const float* d_logits, const float* d_group_activations, float* d_units, void* dx, void* g_out,
+                       const float* d_logits, const float* d_group_activations, float* d_units, void* dx, void* dx_acc, void* g_out,
                        void* a_out, float epsilon, int32_t act_fn, void* stream);
 int spx_exp(const float* x, float* y, int64_t n, void* stream);
 int spx_exp_bwd(const float* g, const float* y, float* dx, int64_t n, void* stream);
@@ -262,6 +265,7 @@ int spx_exp_bwd(const float* g, const float* y, float* dx, int64_t n, void* stre
 /* Bytes of the g_out and of the a_out scratch of spx_dist_bwd. */
 size_t spx_bwd_scratch_bytes(const spx_plan* plan, int32_t B, int32_t HW);
 size_t spx_bwd_head_scratch_bytes(const spx_plan* plan, int32_t B, int32_t HW);
+size_t spx_bwd_dx_scratch_bytes(const spx_plan* plan, int32_t x_dtype, int32_t B, int32_t HW);
 
 /* Backward, parameter side: d_bank [P, Cs] = 2 (p colsum(G) - G^T X) as a pixel-split MFMA reduction with per-workgroup
  * fp32 partial slabs, and d_W [K, P] = dLogits^T A from spx_dist_bwd's a_out (the tile partials of a head of at most 32 rows

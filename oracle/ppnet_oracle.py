@@ -389,6 +389,46 @@ def upsample_argext(src: torch.Tensor, size: Tuple[int, int], largest: bool = Fa
     return idx, val, up
 
 
+def upsample_bilinear_restated(src: torch.Tensor, size: Tuple[int, int]) -> torch.Tensor:
+    """The arithmetic of torch's CPU ``upsample_bilinear2d`` (align_corners=False, fp32, contiguous NCHW:
+    aten/src/ATen/native/cpu/UpSampleKernel.cpp, ``Interpolate<2>`` + ``HelperInterpLinear``) written out operation by
+    operation, with the fused multiply-adds the shipped x86 builds contract it to - pinned here against
+    ``F.interpolate`` bit for bit (tests/test_oracle_golden.py), so the HIP kernel can be held to it bit for bit:
+        s  = fma(scale, dst + 0.5, -0.5) clamped at 0;  i0 = floor(s);  l1 = s - i0;  l0 = 1 - l1
+        t0 = fma(v00, lx0, v01 * lx1);  t1 = fma(v10, lx0, v11 * lx1);  out = fma(t0, ly0, t1 * ly1)
+    (an fma is emulated as a float64 product + sum rounded once to float32: the product of two float32 is exact in
+    float64 and the 29 spare bits make the double rounding unobservable for these magnitudes)."""
+    import numpy as np
+
+    f32 = np.float32
+    x = src.detach().cpu().numpy().astype(f32)
+    N, C, h, w = x.shape
+    H, W = int(size[0]), int(size[1])
+
+    def fma(a, b, c):
+        return (np.asarray(a, np.float64) * np.asarray(b, np.float64) + np.asarray(c, np.float64)).astype(f32)
+
+    def index(n_out, n_in):
+        scale = f32(n_in) / f32(n_out)
+        d = (np.arange(n_out).astype(f32) + f32(0.5)).astype(f32)
+        s = np.maximum(fma(np.full_like(d, scale), d, np.full_like(d, -0.5)), f32(0)).astype(f32)
+        i0 = np.minimum(s.astype(np.int64), n_in - 1)
+        i1 = i0 + (i0 < n_in - 1)
+        l1 = (s - i0.astype(f32)).astype(f32)
+        return i0, i1, (f32(1) - l1).astype(f32), l1
+
+    y0, y1, ly0, ly1 = index(H, h)
+    x0, x1, lx0, lx1 = index(W, w)
+    v00, v01 = x[:, :, y0][:, :, :, x0], x[:, :, y0][:, :, :, x1]
+    v10, v11 = x[:, :, y1][:, :, :, x0], x[:, :, y1][:, :, :, x1]
+    shp = v00.shape
+    LX0, LX1 = np.broadcast_to(lx0[None, None, None, :], shp), np.broadcast_to(lx1[None, None, None, :], shp)
+    LY0, LY1 = np.broadcast_to(ly0[None, None, :, None], shp), np.broadcast_to(ly1[None, None, :, None], shp)
+    t0 = fma(v00, LX0, (v01 * LX1).astype(f32))
+    t1 = fma(v10, LX0, (v11 * LX1).astype(f32))
+    return torch.from_numpy(fma(t0, LY0, (t1 * LY1).astype(f32)))
+
+
 # --------------------------------------------------------------------------- #
 # helpers used by tests / bench
 # --------------------------------------------------------------------------- #

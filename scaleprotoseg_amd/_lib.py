@@ -15,7 +15,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libspx_hip.so")
 SPX_MAX_PANELS = 64
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 
 class SpxError(RuntimeError):
@@ -71,16 +71,17 @@ SIGNATURES = {
     "spx_pack_bank": (C.c_int, [_PP, _V, _V, _V, _V, _V]),
     "spx_pack_head": (C.c_int, [_PP, _V, _V, _V, _V]),
     "spx_dist_fwd": (C.c_int, [_PP, _V, _I, _I, _I, _V, _V, _V, _V, _V, _V, _F, _I, _V]),
-    "spx_dist_bwd": (C.c_int, [_PP, _V, _I, _I, _I, _V, _V, _V, _V, _V, _V, _V, _V, _V, _V, _F, _I, _V]),
+    "spx_dist_bwd": (C.c_int, [_PP, _V, _I, _I, _I, _V, _V, _V, _V, _V, _V, _V, _V, _V, _V, _V, _F, _I, _V]),
     "spx_dist_fwd_cls": (C.c_int, [_PP, _V, _I, _I, _I, _V, _V, _V, _V, _V, _I, _V, _V, _V, _F, _I, _V]),
-    "spx_dist_bwd_cls": (C.c_int, [_PP, _V, _I, _I, _I, _V, _V, _V, _V, _V, _V, _I, _V, _V, _V, _V, _V, _V, _F, _I, _V]),
+    "spx_dist_bwd_cls": (C.c_int, [_PP, _V, _I, _I, _I, _V, _V, _V, _V, _V, _V, _I, _V, _V, _V, _V, _V, _V, _V, _F, _I, _V]),
     "spx_packed_tail_bytes": (C.c_size_t, [_PP]),
     "spx_pack_group_tail": (C.c_int, [_PP, _V, _I, _V, _V, _V]),
     "spx_pack_headT_units": (C.c_int, [_PP, _V, _V, _V]),
     "spx_dist_fwd_group": (C.c_int, [_PP, _V, _I, _I, _I, _V, _V, _V, _V, _I, _V, _V, _V, _V, _F, _I, _V]),
-    "spx_dist_bwd_group": (C.c_int, [_PP, _V, _I, _I, _I, _V, _V, _V, _V, _V, _I, _V, _V, _V, _V, _V, _V, _V, _V, _V, _F, _I, _V]),
+    "spx_dist_bwd_group": (C.c_int, [_PP, _V, _I, _I, _I, _V, _V, _V, _V, _V, _I, _V, _V, _V, _V, _V, _V, _V, _V, _V, _V, _F, _I, _V]),
     "spx_bwd_scratch_bytes": (C.c_size_t, [_PP, _I, _I]),
     "spx_bwd_head_scratch_bytes": (C.c_size_t, [_PP, _I, _I]),
+    "spx_bwd_dx_scratch_bytes": (C.c_size_t, [_PP, _I, _I, _I]),
     "spx_bank_bwd_workspace_bytes": (C.c_size_t, [_PP, _I, _I]),
     "spx_bank_bwd": (C.c_int, [_PP, _V, _I, _I, _I, _V, _V, _V, _V, _V, _V, _V, _V]),
     "spx_push_argmin": (C.c_int, [_V, _V, _V, _I, _I, _I, _I, _I, _F, _V, _V, _V, _V]),
@@ -98,7 +99,7 @@ SIGNATURES = {
     "spx_dist_fwd_ws": (C.c_int, [_PP, _V, _I, _I, _I, _V, _V, _V, _V, _V, _I, _V, _V, _V, _V, _V, _F, _I, _V]),
     "spx_group_tail_workspace_bytes": (C.c_size_t, [_PP, _I, _I]),
     "spx_dist_fwd_group_ws": (C.c_int, [_PP, _V, _I, _I, _I, _V, _V, _V, _V, _I, _V, _V, _V, _V, _PCE, _V, _F, _I, _V]),
-    "spx_dist_bwd_group_ce": (C.c_int, [_PP, _V, _I, _I, _I, _V, _V, _V, _V, _V, _I, _V, _V, _V, _PCE, _V, _V, _V, _V, _V, _F, _I, _V]),
+    "spx_dist_bwd_group_ce": (C.c_int, [_PP, _V, _I, _I, _I, _V, _V, _V, _V, _V, _I, _V, _V, _V, _PCE, _V, _V, _V, _V, _V, _V, _F, _I, _V]),
     "spx_exp": (C.c_int, [_V, _V, C.c_int64, _V]),
     "spx_exp_bwd": (C.c_int, [_V, _V, _V, C.c_int64, _V]),
     "spx_pixel_outer_workspace_bytes": (C.c_size_t, [C.c_int64, _I, _I]),
@@ -108,7 +109,7 @@ SIGNATURES = {
     "spx_ce_partials": (C.c_size_t, [_I, _I]),
     "spx_ce_partials_flat": (C.c_size_t, [C.c_int64]),
     "spx_dist_fwd_ce": (C.c_int, [_PP, _V, _I, _I, _I, _V, _V, _V, _V, _V, _I, _V, _V, _V, _V, _PCE, _F, _I, _V]),
-    "spx_dist_bwd_ce": (C.c_int, [_PP, _V, _I, _I, _I, _V, _V, _V, _V, _V, _V, _I, _V, _V, _V, _PCE, _V, _V, _V, _F, _I, _V]),
+    "spx_dist_bwd_ce": (C.c_int, [_PP, _V, _I, _I, _I, _V, _V, _V, _V, _V, _V, _I, _V, _V, _V, _PCE, _V, _V, _V, _V, _F, _I, _V]),
     "spx_ce_fwd": (C.c_int, [_V, _V, C.c_int64, _I, _V, _V, _V, _V]),
     "spx_ce_bwd": (C.c_int, [_V, _V, _V, _V, C.c_int64, _I, _V, _V]),
 }

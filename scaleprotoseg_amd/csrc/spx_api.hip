@@ -141,6 +141,13 @@ int spx_make_plan(int32_t P, int32_t K, int32_t S, int32_t Cs, const int32_t* lo
 }
 
 size_t spx_bwd_scratch_bytes(const spx_plan* pl, int32_t B, int32_t HW) { return spx_bwd_scratch_elems(*pl, B, HW) * 2; }
+size_t spx_bwd_dx_scratch_bytes(const spx_plan* pl, int32_t x_dtype, int32_t B, int32_t HW) {
+    if (x_dtype != 0) return 0;                                     /* fp32 features accumulate in dX itself */
+    for (int q = 1; q < pl->npanels; ++q)
+        if (pl->panel_ch0[q] == pl->panel_ch0[q - 1])               /* some scale spans several panels */
+            return (size_t)B * pl->num_scales * pl->channels_per_scale * (((size_t)HW + 3) / 4 * 4) * sizeof(float);
+    return 0;
+}
 size_t spx_bwd_head_scratch_bytes(const spx_plan* pl, int32_t B, int32_t HW) {
     if (pl->ncb != 1) return spx_bwd_scratch_elems(*pl, B, HW) * 2;              /* the activation blob */
     const size_t tiles = (size_t)B * ((HW + SPX_TILE_PX - 1) / SPX_TILE_PX);
@@ -343,7 +350,7 @@ static int dist_bwd_impl(const spx_plan* pl, const void* x, int32_t x_dtype, int
                          const void* packed_bank, const void* packed_bankT, const float* packed_p2,
                          const void* packed_headT, const float* d_dist, const int32_t* labels,
                          const uint32_t* proto_key, int32_t J, const float* d_cls_dist, const float* d_act,
-                         const float* d_logits, void* dx, void* g_out, void* a_out, float epsilon, int32_t act_fn,
+                         const float* d_logits, void* dx, void* dx_acc, void* g_out, void* a_out, float epsilon, int32_t act_fn,
                          void* stream, SpxTailBwd tail = SpxTailBwd{nullptr, 0, nullptr, nullptr, nullptr}, const spx_ce* ce = nullptr) {
     if (check_plan(pl)) return 1;
     if (!x || !packed_bank || !packed_p2) return fail("spx_dist_bwd: NULL operand");
@@ -383,6 +390,7 @@ static int dist_bwd_impl(const spx_plan* pl, const void* x, int32_t x_dtype, int
     a.ce_coef = ce ? ce->coef : nullptr;
     a.ce_dlogits_out = ce ? ce->d_logits_out : nullptr;
     a.dx = dx;
+    a.dx_acc = (float*)dx_acc;
     a.g_out = (uint16_t*)g_out;
     a.a_out = (uint16_t*)a_out;
     a.B = B;
@@ -397,23 +405,23 @@ static int dist_bwd_impl(const spx_plan* pl, const void* x, int32_t x_dtype, int
 
 int spx_dist_bwd(const spx_plan* pl, const void* x, int32_t x_dtype, int32_t B, int32_t HW, const void* packed_bank,
                  const void* packed_bankT, const float* packed_p2, const void* packed_headT, const float* d_dist,
-                 const float* d_act, const float* d_logits, void* dx, void* g_out, void* a_out, float epsilon,
+                 const float* d_act, const float* d_logits, void* dx, void* dx_acc, void* g_out, void* a_out, float epsilon,
                  int32_t act_fn, void* stream) {
     return dist_bwd_impl(pl, x, x_dtype, B, HW, packed_bank, packed_bankT, packed_p2, packed_headT, d_dist, nullptr,
-                         nullptr, 0, nullptr, d_act, d_logits, dx, g_out, a_out, epsilon, act_fn, stream);
+                         nullptr, 0, nullptr, d_act, d_logits, dx, dx_acc, g_out, a_out, epsilon, act_fn, stream);
 }
 
 int spx_dist_bwd_group(const spx_plan* pl, const void* x, int32_t x_dtype, int32_t B, int32_t HW,
                        const void* packed_bank, const void* packed_bankT, const float* packed_p2,
                        const void* packed_headT_units, const void* packed_tailT, int32_t K2,
                        const float* group_activations, const float* d_dist, const float* d_act,
-                       const float* d_logits, const float* d_group_activations, float* d_units, void* dx, void* g_out,
+                       const float* d_logits, const float* d_group_activations, float* d_units, void* dx, void* dx_acc, void* g_out,
                        void* a_out, float epsilon, int32_t act_fn, void* stream) {
     if (!packed_headT_units || !packed_tailT || !group_activations || !d_logits || !d_units)
         return fail("spx_dist_bwd_group: NULL tail operand");
     if (K2 < 1 || K2 > 32) return fail("spx_dist_bwd_group: %d classes (at most 32)", K2);
     return dist_bwd_impl(pl, x, x_dtype, B, HW, packed_bank, packed_bankT, packed_p2, packed_headT_units, d_dist,
-                         nullptr, nullptr, 0, nullptr, d_act, d_logits, dx, g_out, a_out, epsilon, act_fn, stream,
+                         nullptr, nullptr, 0, nullptr, d_act, d_logits, dx, dx_acc, g_out, a_out, epsilon, act_fn, stream,
                          SpxTailBwd{packed_tailT, K2, group_activations, d_units, d_group_activations});
 }
 
@@ -421,14 +429,14 @@ int spx_dist_bwd_group_ce(const spx_plan* pl, const void* x, int32_t x_dtype, in
                           const void* packed_bank, const void* packed_bankT, const float* packed_p2,
                           const void* packed_headT_units, const void* packed_tailT, int32_t K2,
                           const float* group_activations, const float* d_dist, const float* d_act, const spx_ce* ce,
-                          const float* d_group_activations, float* d_units, void* dx, void* g_out, void* a_out, float epsilon,
+                          const float* d_group_activations, float* d_units, void* dx, void* dx_acc, void* g_out, void* a_out, float epsilon,
                           int32_t act_fn, void* stream) {
     if (!ce) return fail("spx_dist_bwd_group_ce: NULL ce");
     if (!packed_headT_units || !packed_tailT || !group_activations || !d_units)
         return fail("spx_dist_bwd_group_ce: NULL tail operand");
     if (K2 < 1 || K2 > 32) return fail("spx_dist_bwd_group_ce: %d classes (at most 32)", K2);
     return dist_bwd_impl(pl, x, x_dtype, B, HW, packed_bank, packed_bankT, packed_p2, packed_headT_units, d_dist,
-                         nullptr, nullptr, 0, nullptr, d_act, nullptr, dx, g_out, a_out, epsilon, act_fn, stream,
+                         nullptr, nullptr, 0, nullptr, d_act, nullptr, dx, dx_acc, g_out, a_out, epsilon, act_fn, stream,
                          SpxTailBwd{packed_tailT, K2, group_activations, d_units, d_group_activations}, ce);
 }
 
@@ -436,11 +444,11 @@ int spx_dist_bwd_cls(const spx_plan* pl, const void* x, int32_t x_dtype, int32_t
                      const void* packed_bank, const void* packed_bankT, const float* packed_p2,
                      const void* packed_headT, const int32_t* labels, const uint32_t* proto_key, int32_t J,
                      const float* d_class_distances, const float* d_act, const float* d_logits, void* dx,
-                     void* g_out, void* a_out, float epsilon, int32_t act_fn, void* stream) {
+                     void* dx_acc, void* g_out, void* a_out, float epsilon, int32_t act_fn, void* stream) {
     if (check_cls("spx_dist_bwd_cls", labels, proto_key, J, HW)) return 1;
     // d_class_distances may be NULL (no gradient reaches the gathered distances)
     return dist_bwd_impl(pl, x, x_dtype, B, HW, packed_bank, packed_bankT, packed_p2, packed_headT, nullptr,
-                         d_class_distances ? labels : nullptr, proto_key, J, d_class_distances, d_act, d_logits, dx,
+                         d_class_distances ? labels : nullptr, proto_key, J, d_class_distances, d_act, d_logits, dx, dx_acc,
                          g_out, a_out, epsilon, act_fn, stream);
 }
 
@@ -487,14 +495,14 @@ int spx_dist_fwd_ce(const spx_plan* pl, const void* x, int32_t x_dtype, int32_t 
 int spx_dist_bwd_ce(const spx_plan* pl, const void* x, int32_t x_dtype, int32_t B, int32_t HW, const void* packed_bank,
                     const void* packed_bankT, const float* packed_p2, const void* packed_headT, const int32_t* labels_cls,
                     const uint32_t* proto_key, int32_t J, const float* d_dist, const float* d_class_distances,
-                    const float* d_act, const spx_ce* ce, void* dx, void* g_out, void* a_out, float epsilon,
+                    const float* d_act, const spx_ce* ce, void* dx, void* dx_acc, void* g_out, void* a_out, float epsilon,
                     int32_t act_fn, void* stream) {
     if (!ce) return fail("spx_dist_bwd_ce: NULL ce");
     if (labels_cls && check_cls("spx_dist_bwd_ce", labels_cls, proto_key, J, HW)) return 1;
     if (labels_cls && d_dist) return fail("spx_dist_bwd_ce: class-gathered and P-wide distance gradients are exclusive");
     return dist_bwd_impl(pl, x, x_dtype, B, HW, packed_bank, packed_bankT, packed_p2, packed_headT, d_dist,
                          (labels_cls && d_class_distances) ? labels_cls : nullptr, proto_key, labels_cls ? J : 0,
-                         labels_cls ? d_class_distances : nullptr, d_act, nullptr, dx, g_out, a_out, epsilon, act_fn, stream,
+                         labels_cls ? d_class_distances : nullptr, d_act, nullptr, dx, dx_acc, g_out, a_out, epsilon, act_fn, stream,
                          SpxTailBwd{nullptr, 0, nullptr, nullptr, nullptr}, ce);
 }
 

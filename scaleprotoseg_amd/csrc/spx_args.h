@@ -72,6 +72,7 @@ struct SpxBwdArgs {
     const float* ce_coef;       // device scalar
     float* ce_dlogits_out;      // [B*HW, K] written for the parameter kernel (may be NULL)
     void* dx;
+    float* dx_acc;              // fp32 [B][C][HW rounded up to 4]: partial dX of scales that span several panels (bf16 features); may be NULL
     uint16_t* g_out;
     uint16_t* a_out;            // head-gradient scratch (spx_common.h): fp32 d_W tile partials (one class block) or the activation blob
     int B, HW, vec_ok;

@@ -81,7 +81,9 @@ static_assert(spx_bwd_lds_bytes<6, 1, false>() <= 80 * 1024 && spx_bwd_lds_bytes
 // ------------------------------------------------------------------------------------------------
 // GATHER: the distance gradient arrives class-gathered ([B, HW, J], spx_dist_bwd_cls) instead of P-wide.
 // DACT: a gradient arrives on the [pixel][P] activations (kept out of the default instance).
-template <int NPB, int NCB, bool XF32, int VM, bool GATHER, bool DACT>
+// ACC: bf16 features and a scale that spans several panels: its partial dX is summed in the fp32 scratch a.dx_acc (its own
+// instances: as a run-time branch the code cost the default instance 0.02-0.035 ms - it sits at the register cliff).
+template <int NPB, int NCB, bool XF32, int VM, bool GATHER, bool DACT, bool ACC = false>
 __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBwdArgs a) {
     constexpr bool VEC = VM != 0, RAG = VM == 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -783,6 +785,12 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
         const float rs_tot = rs + __shfl_xor(rs, 32);
         if (h == 0) rss[32 * wave + r] = 2.0f * rs_tot;      // the finish below wants 2 rs (the P^T fragments carry -2 p)
         const bool first_of_scale = (panel == q_begin) || (pl.panel_ch0[panel - 1] != ch0);
+        // A scale of more than 192 prototypes spans several panels, each adding its share of dX.  With fp32 features the sum
+        // runs in dX itself; with bf16 features it runs in the caller's fp32 scratch a.dx_acc ([B][C][HW rounded up to 4]) and
+        // only the scale's LAST panel writes dX, rounded once (through the bf16 buffer it was one rounding per panel).
+        const bool last_of_scale = (panel + 1 == q_end) || (pl.panel_ch0[panel + 1] != ch0);
+        const bool acc32 = ACC && !XF32 && !(first_of_scale && last_of_scale);     // workgroup-uniform
+
         constexpr int BT = spx_bwd_bt_bytes<NPB>();
         char* const bt = smem;                               // 2 x BT  (P^T fragments of one channel block)
         char* const tt0 = smem + 2 * BT;                     // fp32 transpose tile 0
@@ -833,7 +841,7 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
                     const uint32_t vo = (ch_ok && (fpx + (v + 1) * PV <= a.HW)) ? fvo + 16u * v : SPX_OOB;
                     xw[v] = buf_load_b128(xir, vo, 0);
                     // first panel of a scale: nothing to accumulate onto (dropped load returns 0)
-                    pw[v] = buf_load_b128(dxr, first_of_scale ? SPX_OOB : vo, 0);
+                    pw[v] = buf_load_b128(dxr, (first_of_scale || acc32) ? SPX_OOB : vo, 0);
                 }
             }
         };
@@ -872,7 +880,7 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
                         pv[e] = first_of_scale ? 0.0f : buf_load_f32(dxr, vo, 0);
                     } else {
                         xv[e] = __uint_as_float((uint32_t)buf_load_u16(xir, vo, 0) << 16);
-                        pv[e] = first_of_scale ? 0.0f : __uint_as_float((uint32_t)buf_load_u16(dxr, vo, 0) << 16);
+                        pv[e] = (first_of_scale || acc32) ? 0.0f : __uint_as_float((uint32_t)buf_load_u16(dxr, vo, 0) << 16);
                     }
                 }
             }
@@ -893,6 +901,18 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
                     }
                 }
             }
+            if (acc32 && !first_of_scale) {        // the partial of the scale's earlier panels (fp32)
+                // (everything of this path is formed inside its branch: the default instance sits at the register cliff)
+                const uint32_t HWp = (HW + 3u) & ~3u;
+                const spx_rsrc d32r = make_rsrc_pred((char*)a.dx_acc + ((size_t)b * C + ch0 + chb * 32) * HWp * 4);
+                const uint32_t fvo32 = ((uint32_t)frow * HWp + (uint32_t)fpx) * 4u;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const u32x4 w = buf_load_b128(d32r, (ch_ok && (uint32_t)(fpx + 4 * v) < HWp) ? fvo32 + 16u * v : SPX_OOB, 0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) pv[4 * v + e] = __uint_as_float(w[e]);
+                }
+            }
             char* T = (chb & 1) ? tt1 : tt0;
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg)
@@ -907,7 +927,18 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
 #pragma unroll
                 for (int e = 0; e < 4; ++e) ov[4 * v + e] = __builtin_fmaf(sinv, __builtin_fmaf(rv[e], xv[4 * v + e], tv[e]), pv[4 * v + e]);   // (2 rs x - 2 P^T.G16) / scale
             }
-            if (use_vec) {
+            if (acc32 && !last_of_scale) {
+                const uint32_t HWp = (HW + 3u) & ~3u;
+                const spx_rsrc d32r = make_rsrc_pred((char*)a.dx_acc + ((size_t)b * C + ch0 + chb * 32) * HWp * 4);
+                const uint32_t fvo32 = ((uint32_t)frow * HWp + (uint32_t)fpx) * 4u;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    u32x4 w;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) w[e] = __float_as_uint(ov[4 * v + e]);
+                    buf_store_b128(w, d32r, (ch_ok && (uint32_t)(fpx + 4 * v) < HWp) ? fvo32 + 16u * v : SPX_OOB, 0);
+                }
+            } else if (use_vec) {
 #pragma unroll
                 for (int v = 0; v < NV; ++v) {
                     const bool ok = ch_ok && (fpx + (v + 1) * PV <= a.HW);
@@ -983,7 +1014,17 @@ static hipError_t launch_bwd_gd(const SpxBwdArgs& a, int x_dtype, dim3 grid, hip
         else if (a.vec_ok) hipLaunchKernelGGL((spx_bwd_kernel<NPB, NCB, true, 1, GATHER, DACT>), grid, dim3(256), lds, s, a);
         else hipLaunchKernelGGL((spx_bwd_kernel<NPB, NCB, true, 0, GATHER, DACT>), grid, dim3(256), lds, s, a);
     } else {
-        if (a.vec_ok == 2) hipLaunchKernelGGL((spx_bwd_kernel<NPB, NCB, false, 2, GATHER, DACT>), grid, dim3(256), lds, s, a);
+        bool acc = false;
+        if (a.dx_acc && a.dx) {
+            for (int q = 1; q < a.plan.npanels; ++q) acc |= a.plan.panel_ch0[q] == a.plan.panel_ch0[q - 1];
+        }
+        if (acc) {
+            if (a.vec_ok == 2) hipLaunchKernelGGL((spx_bwd_kernel<NPB, NCB, false, 2, GATHER, DACT, true>), grid, dim3(256), lds, s, a);
+            else if (a.vec_ok) hipLaunchKernelGGL((spx_bwd_kernel<NPB, NCB, false, 1, GATHER, DACT, true>), grid, dim3(256), lds, s, a);
+            else hipLaunchKernelGGL((spx_bwd_kernel<NPB, NCB, false, 0, GATHER, DACT, true>), grid, dim3(256), lds, s, a);
+        }
+        if (acc) {
+        } else if (a.vec_ok == 2) hipLaunchKernelGGL((spx_bwd_kernel<NPB, NCB, false, 2, GATHER, DACT>), grid, dim3(256), lds, s, a);
         else if (a.vec_ok) hipLaunchKernelGGL((spx_bwd_kernel<NPB, NCB, false, 1, GATHER, DACT>), grid, dim3(256), lds, s, a);
         else hipLaunchKernelGGL((spx_bwd_kernel<NPB, NCB, false, 0, GATHER, DACT>), grid, dim3(256), lds, s, a);
     }

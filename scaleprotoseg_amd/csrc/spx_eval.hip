@@ -7,8 +7,12 @@
 
 // torch's area_pixel_compute_source_index for align_corners = False (no explicit scale factor): scale = in / out,
 // src = scale * (dst + 0.5) - 0.5 clamped at 0; i0 = floor, i1 = min(i0 + 1, in - 1), lambda1 = src - i0.
+// The arithmetic is the CPU kernel's OPERATION BY OPERATION, fused multiply-adds where the shipped x86 builds have them
+// (aten/src/ATen/native/cpu/UpSampleKernel.cpp; restated and pinned bit for bit in oracle/ppnet_oracle.py::
+// upsample_bilinear_restated): the values, and with them the arg{min,max} indices, are bit-identical to the reference's
+// F.interpolate + min / max on the host (this library is compiled with -ffp-contract=off: every fma below is explicit).
 __device__ __forceinline__ void src_index(int dst, float scale, int in_size, int& i0, int& i1, float& l0, float& l1) {
-    float s = scale * ((float)dst + 0.5f) - 0.5f;
+    float s = __builtin_fmaf(scale, (float)dst + 0.5f, -0.5f);
     s = s < 0.0f ? 0.0f : s;
     i0 = (int)s;
     if (i0 > in_size - 1) i0 = in_size - 1;
@@ -36,8 +40,9 @@ __global__ __launch_bounds__(256) void spx_upsample_argext_kernel(const float* _
 #pragma unroll 4
     for (int c = 0; c < C; ++c) {
         const float* p = base + (size_t)c * hw;
-        // same expression tree as torch's upsample_bilinear2d: rows first, then the two rows blended
-        const float v = ly0 * (lx0 * p[o00] + lx1 * p[o01]) + ly1 * (lx0 * p[o10] + lx1 * p[o11]);
+        // rows first (t0, t1), then the two rows blended; in each blend the first product is fused, the second rounded
+        const float t0 = __builtin_fmaf(p[o00], lx0, p[o01] * lx1), t1 = __builtin_fmaf(p[o10], lx0, p[o11] * lx1);
+        const float v = __builtin_fmaf(t0, ly0, t1 * ly1);
         const bool better = take_max ? (v > best) : (v < best);
         if (c == 0 || better) {      // strict comparison: ties keep the lowest channel index
             best = v;

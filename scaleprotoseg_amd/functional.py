@@ -578,6 +578,9 @@ class _ProtoHeadFn(torch.autograd.Function):
                 ce = _lib.SpxCe(labels=_lib.ptr(ce_labels), lse=_lib.ptr(lse), logits=_lib.ptr(ce_logits),
                                 coef=_lib.ptr(coef), d_logits_out=_lib.ptr(d_logits_ce))
         dx = torch.empty_like(x) if need_x else None
+        # bf16 features and a scale of more than 192 prototypes (several panels): the panels' shares of dX are summed in fp32
+        n_acc = lib.spx_bwd_dx_scratch_bytes(pp, xd, B, HW) if need_x else 0
+        dx_acc = torch.empty(n_acc, dtype=torch.uint8, device=dev) if n_acc else None
         g_scr = torch.empty(scr, dtype=torch.uint8, device=dev) if need_bank else None
         a_scr = torch.empty(lib.spx_bwd_head_scratch_bytes(pp, B, HW), dtype=torch.uint8, device=dev) if need_head else None
         tail2d, d_units, d_tail = ctx.tail2d, None, None
@@ -594,7 +597,7 @@ class _ProtoHeadFn(torch.autograd.Function):
                     lib.spx_dist_bwd_group_ce(
                         pp, _lib.ptr(x), xd, B, HW, _lib.ptr(packs.bank), _lib.ptr(packs.bankT), _lib.ptr(packs.p2),
                         _lib.ptr(packs.headT), _lib.ptr(packs.tailT), int(tail2d.shape[0]), _lib.ptr(ctx.gact),
-                        _lib.ptr(gd), _lib.ptr(ga), C.byref(ce), _lib.ptr(gg), _lib.ptr(d_units), _lib.ptr(dx), _lib.ptr(g_scr),
+                        _lib.ptr(gd), _lib.ptr(ga), C.byref(ce), _lib.ptr(gg), _lib.ptr(d_units), _lib.ptr(dx), _lib.ptr(dx_acc), _lib.ptr(g_scr),
                         _lib.ptr(a_scr), ctx.epsilon, ACT_FN[ctx.act_fn], s,
                     )
                 )
@@ -604,7 +607,7 @@ class _ProtoHeadFn(torch.autograd.Function):
                     lib.spx_dist_bwd_group(
                         pp, _lib.ptr(x), xd, B, HW, _lib.ptr(packs.bank), _lib.ptr(packs.bankT), _lib.ptr(packs.p2),
                         _lib.ptr(packs.headT), _lib.ptr(packs.tailT), int(tail2d.shape[0]), _lib.ptr(ctx.gact),
-                        _lib.ptr(gd), _lib.ptr(ga), _lib.ptr(gl), _lib.ptr(gg), _lib.ptr(d_units), _lib.ptr(dx), _lib.ptr(g_scr),
+                        _lib.ptr(gd), _lib.ptr(ga), _lib.ptr(gl), _lib.ptr(gg), _lib.ptr(d_units), _lib.ptr(dx), _lib.ptr(dx_acc), _lib.ptr(g_scr),
                         _lib.ptr(a_scr), ctx.epsilon, ACT_FN[ctx.act_fn], s,
                     )
                 )
@@ -616,7 +619,7 @@ class _ProtoHeadFn(torch.autograd.Function):
                         _lib.ptr(packs.headT), _lib.ptr(g.labels) if g is not None else None,
                         _lib.ptr(g.keys) if g is not None else None, g.width if g is not None else 0,
                         _lib.ptr(gd) if g is None else None, _lib.ptr(gd) if g is not None else None, _lib.ptr(ga),
-                        C.byref(ce), _lib.ptr(dx), _lib.ptr(g_scr), _lib.ptr(a_scr), ctx.epsilon, ACT_FN[ctx.act_fn], s,
+                        C.byref(ce), _lib.ptr(dx), _lib.ptr(dx_acc), _lib.ptr(g_scr), _lib.ptr(a_scr), ctx.epsilon, ACT_FN[ctx.act_fn], s,
                     )
                 )
             elif ctx.gather is not None:
@@ -625,7 +628,7 @@ class _ProtoHeadFn(torch.autograd.Function):
                     lib.spx_dist_bwd_cls(
                         pp, _lib.ptr(x), xd, B, HW, _lib.ptr(packs.bank), _lib.ptr(packs.bankT), _lib.ptr(packs.p2),
                         _lib.ptr(packs.headT) if gl is not None else None, _lib.ptr(g.labels), _lib.ptr(g.keys),
-                        g.width, _lib.ptr(gd), _lib.ptr(ga), _lib.ptr(gl), _lib.ptr(dx), _lib.ptr(g_scr),
+                        g.width, _lib.ptr(gd), _lib.ptr(ga), _lib.ptr(gl), _lib.ptr(dx), _lib.ptr(dx_acc), _lib.ptr(g_scr),
                         _lib.ptr(a_scr), ctx.epsilon, ACT_FN[ctx.act_fn], s,
                     )
                 )
@@ -634,7 +637,7 @@ class _ProtoHeadFn(torch.autograd.Function):
                     lib.spx_dist_bwd(
                         pp, _lib.ptr(x), xd, B, HW, _lib.ptr(packs.bank), _lib.ptr(packs.bankT), _lib.ptr(packs.p2),
                         _lib.ptr(packs.headT) if gl is not None else None, _lib.ptr(gd), _lib.ptr(ga), _lib.ptr(gl),
-                        _lib.ptr(dx), _lib.ptr(g_scr), _lib.ptr(a_scr), ctx.epsilon, ACT_FN[ctx.act_fn], s,
+                        _lib.ptr(dx), _lib.ptr(dx_acc), _lib.ptr(g_scr), _lib.ptr(a_scr), ctx.epsilon, ACT_FN[ctx.act_fn], s,
                     )
                 )
         if ce is not None:

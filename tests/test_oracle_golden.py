@@ -156,3 +156,19 @@ def test_kld_loss_group_matches_reference(golden):
     assert abs(loss.item() - float(g["grp_loss"])) <= 1e-7
     for i, a in enumerate(acts):
         assert np.abs(a.grad.numpy() - g[f"grp_grad{i}"]).max() <= 1e-8
+
+
+@pytest.mark.parametrize("case", [(1, 3, 129, 257, 1024, 2048), (2, 19, 65, 65, 513, 513), (1, 7, 17, 33, 129, 257), (2, 5, 9, 11, 70, 90),
+                                  (1, 4, 33, 65, 256, 512)])
+def test_bilinear_restatement_is_the_host_kernel_bit_for_bit(case):
+    """The operation-by-operation restatement of torch's CPU upsample_bilinear2d that the eval kernel is held to
+    (segmentation/eval_valid_multiscale.py:229-234 calls F.interpolate) equals F.interpolate itself bit for bit - at the
+    reference's evaluation shapes (latent 129 x 257 -> 1024 x 2048, 65 x 65 -> 513 x 513) and the other maps large enough
+    for the host kernel's main loop instantiation (tiny maps take another one, contracted differently by its compiler:
+    there the GPU test falls back to a tolerance)."""
+    from oracle import ppnet_oracle as O
+
+    N, C, h, w, H, W = case
+    src = torch.rand(N, C, h, w, generator=torch.Generator().manual_seed(5)) * 10
+    up = torch.nn.functional.interpolate(src, size=(H, W), mode="bilinear", align_corners=False)
+    assert torch.equal(up, O.upsample_bilinear_restated(src, (H, W)))
