@@ -307,7 +307,10 @@ def main():
     g_dist = torch.randn(1, P, H, W, device=dev, generator=g) * 1e-3
     for name in filter(None, args.freeze.split(",")):
         {"x": x, "bank": bank, "head": head}[name].requires_grad_(False)
-    bucket = FlatGradBucket([p for p in (bank, head, tail) if p is not None and p.requires_grad] or [bank.requires_grad_(True)])
+    # the gradients live in ONE flat fp32 buffer (`.grad` = views of it): the N > 1 step all-reduces that buffer in place,
+    # with no gather / scatter copies around the collective
+    # (one GPU: no collective, the gradients stay ordinary `.grad` tensors)
+    bucket = FlatGradBucket([p for p in (bank, head, tail) if p is not None and p.requires_grad] or [bank.requires_grad_(True)], attach=world > 1)
 
     gather = None
     if "class_dist" in args.outputs.split(","):
@@ -322,11 +325,14 @@ def main():
 
     def step():
         x.grad = None
-        bank.grad = None
-        head.grad = None
+        if world > 1:
+            bucket.zero()                 # (not `.grad = None`: the views stay attached to the bucket)
+        else:
+            bank.grad = head.grad = None
+            if tail is not None:
+                tail.grad = None
         want_d = "dist" in args.outputs.split(",")
         if tail is not None:
-            tail.grad = None
             logits, dmap, _, _ = spx.proto_head_forward(x, bank, head, layout, want_distances=want_d, group_tail=tail)
         else:
             logits, dmap, _ = spx.proto_head_forward(x, bank, head, layout, want_distances=want_d, class_gather=gather)

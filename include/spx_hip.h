@@ -17,7 +17,9 @@
  *  - return 0 on success, non-zero on error; spx_last_error() gives the message
  *    of the last failing call of the calling thread;
  *  - tensors are dense, row-major, in the reference's layouts:
- *      features X   [B, C, H*W]      bf16 (x_dtype 0) or fp32 (x_dtype 1), C = S*Cs
+ *      features X   [B, C, H*W]      bf16 (x_dtype 0) or fp32 (x_dtype 1), C = S*Cs; the reference feeds a Sigmoid's
+ *                                    output (values in (0, 1)).  The prototype gradient's product runs in fp16: features are
+ *                                    taken exactly for 2^-14 <= |x| < 65520 and saturate at +-65504 beyond (never inf)
  *      bank         [P, Cs]          fp32   (prototype_vectors.view(P, Cs))
  *      distances    [B, P, H*W]      fp32
  *      activations  [B*H*W, P]       fp32   (NHWC pixel order)

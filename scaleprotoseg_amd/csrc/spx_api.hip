@@ -7,12 +7,19 @@
 #include "spx_args.h"
 
 static thread_local char g_err[512] = "";
-static unsigned long long* g_dbg = nullptr;   // diagnostic builds: see spx_set_debug_buffer
+#ifdef SPX_DIAG
+// diagnostic builds only (-DSPX_DIAG, never the product library: include/spx_hip.h promises no process-global state): the
+// buffer of the in-kernel phase clocks (SPX_DIAG_STAMPS) and overrides of the tile permutation / product-kernel tiling
+static unsigned long long* g_dbg = nullptr;
+static int g_tile_mul_req = 0;                 // 0 = automatic (below), 1 = identity, > 1 = that multiplier
+#else
+static constexpr unsigned long long* g_dbg = nullptr;
+static constexpr int g_tile_mul_req = 0;
+#endif
 
 // Block -> tile permutation of the pixel kernels: tile = (block * mul) mod tiles with mul coprime to the tile count, so that
 // the workgroups running at one time are spread over the whole pixel range instead of covering one contiguous stretch of every
-// feature plane (plane strides).  g_tile_mul_req <= 1: identity.
-static int g_tile_mul_req = 0;                 // 0 = automatic (below), 1 = identity, > 1 = that multiplier (experiments)
+// feature plane (plane strides).
 static int gcd_i(int a, int b) { while (b) { const int t = a % b; a = b; b = t; } return a; }
 int spx_tile_mul(int tiles_launch, long long plane_bytes) {
     // Automatic: only where the feature planes are a multiple of 1 MiB apart (power-of-two grids such as 1024 x 2048: plane
@@ -90,12 +97,11 @@ hipError_t spx_launch_bwd(const SpxBwdArgs& a, int x_dtype, hipStream_t s) {
 extern "C" {
 
 int spx_version(void) { return SPX_ABI_VERSION; }
-/* Not part of the product ABI (absent from spx_hip.h): profiling hook of SPX_DIAG_STAMPS builds. */
+#ifdef SPX_DIAG
 void spx_diag_set_debug_buffer(void* p) { g_dbg = (unsigned long long*)p; }
-/* Not part of the product ABI either: experiment switch for the block -> tile permutation (1 = identity). */
-void spx_diag_set_tile_mul(int m) { g_tile_mul_req = m; }
-/* ... and for the tile / split choice of spx_rows_gemm (0 = the shape-derived default). */
-void spx_diag_set_gemm(int wm, int splits) { spx_gemm_force(wm, splits); }
+void spx_diag_set_tile_mul(int m) { g_tile_mul_req = m; }       /* 1 = identity */
+void spx_diag_set_gemm(int wm, int splits) { spx_gemm_force(wm, splits); }     /* 0 = the shape-derived default */
+#endif
 const char* spx_last_error(void) { return g_err; }
 
 int spx_make_plan(int32_t P, int32_t K, int32_t S, int32_t Cs, const int32_t* lo, const int32_t* hi, spx_plan* out) {
@@ -621,9 +627,8 @@ static int kld_check(const char* who, const float* vals, const int32_t* labels, 
     if (!vals || !labels || !out) return fail("%s: NULL buffer", who);
     if (B < 1 || B > 65535 || HW < 1 || K < 1 || J < 1 || J > 16) return fail("%s: bad sizes (B=%d HW=%d K=%d J=%d; J <= 16)", who, B, HW, K, J);
     if ((long long)J * HW >= (1LL << 31)) return fail("%s: J*HW too large", who);
-    const long long JT = (J + 3) / 4 * 4;       // the gradient pass pads its table rows to a multiple of four slots
-    const long long lds = pairs ? (long long)K * JT * JT * 8 + (long long)K * JT * 8 : (long long)K * J * 12 + (long long)K * 4;
-    if (lds > 60 * 1024) return fail("%s: K*J*J = %d exceeds the LDS table (use the torch path)", who, K * J * J);
+    (void)pairs;        // (the pair and gradient passes tile their per-class tables over class blocks: no K * J * J limit)
+    if ((long long)K * J * 12 + (long long)K * 4 + 8 > 60 * 1024) return fail("%s: K*J = %d exceeds the segment tables of the reduction passes", who, K * J);
     return 0;
 }
 

@@ -126,7 +126,9 @@ int spx_split_groups(const spx_plan& pl, int B, int HW, int32_t* group_first);
 hipError_t spx_launch_group_tail(const float* parts, int groups, long long M, int U, const float* Wg, int K2, float* gact,
                                  float* logits, const int32_t* labels, float* lse, int32_t* pred, float* partials, hipStream_t s);
 hipError_t spx_launch_push_finalize(const uint64_t* scratch, int n, int64_t* idx, float* val, hipStream_t s);
+#ifdef SPX_DIAG
 void spx_gemm_force(int wm, int splits);
+#endif
 size_t spx_gemm_workspace(int M, int N, int K, int flags);
 hipError_t spx_launch_gemm(const float* A, long long ras, long long kas, const float* B, long long rbs, long long kbs,
                            float* C, long long ldc, int M, int N, int K, int flags, const float* E, long long lde,

@@ -22,12 +22,8 @@
 #define SPX_BK_THREADS 512
 // Default since the end of round 2 (with the int16 activation blob the commit phase got heavier): the pipelined + staggered
 // variant for the 6-block panels without the k-step split (the north-star bank), 0.783 -> 0.740 ms on one box.
-#ifndef SPX_BANK_PIPE
 #define SPX_BANK_PIPE 1
-#endif
-#ifndef SPX_BANK_STAGGER
 #define SPX_BANK_STAGGER 1
-#endif
 // LDS row stride of the [channel][px] images: 2 CPX + 16 bytes (144 / 80: conflict-free ds_read_b128)
 __host__ __device__ constexpr int spx_bk_row(int cpx) { return 2 * cpx + 16; }
 
@@ -207,7 +203,6 @@ __global__ __launch_bounds__(SPX_BK_THREADS, 2) void spx_bank_bwd_kernel(const S
     auto issue = [&](Stage& st) {
         const int b = nx_b;
         const int ci = ci0 + nx_ci;
-#ifndef SPX_DIAG_BANK_NOLOAD                          // (timing-only build: every chunk re-reads the first one: cache hits)
         if (nx_c + cstep < c_end) {
             nx_c += cstep;
             nx_b += step_b;
@@ -217,7 +212,6 @@ __global__ __launch_bounds__(SPX_BK_THREADS, 2) void spx_bank_bwd_kernel(const S
                 ++nx_b;
             }
         }
-#endif
         constexpr int CPT = SPX_TILE_PX / CPX;            // chunks per kernel-1 tile
         const size_t tile_g = (size_t)b * tiles_per_img + ci / CPT;
         // the chunk's fragments are contiguous: kernel-1 waves NW1 (ci % CPT) ... of the tile
@@ -231,9 +225,9 @@ __global__ __launch_bounds__(SPX_BK_THREADS, 2) void spx_bank_bwd_kernel(const S
 #pragma unroll
         for (int i = 0; i < FP; ++i) {
             const uint32_t off = (uint32_t)((i * SPX_BK_THREADS + tid) * 16);
-            st.gr[i] = buf_load_b128_p<SPX_AUX_BLOB_LD>(grs, (want_p && off < (uint32_t)FBYTES) ? off : SPX_OOB, 0);
+            st.gr[i] = buf_load_b128(grs, (want_p && off < (uint32_t)FBYTES) ? off : SPX_OOB, 0);
             st.exw[i] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(exs, exsrc ? gsc_off[i] : SPX_OOB, 0, 0);
-            st.ar[i] = buf_load_b128_p<SPX_AUX_BLOB_LD>(ars, (want_w && off < (uint32_t)FBYTES) ? off : SPX_OOB, 0);
+            st.ar[i] = buf_load_b128(ars, (want_w && off < (uint32_t)FBYTES) ? off : SPX_OOB, 0);
         }
         const int px = ci * SPX_BK_PX + piece * 8;
         {
@@ -318,14 +312,14 @@ __global__ __launch_bounds__(SPX_BK_THREADS, 2) void spx_bank_bwd_kernel(const S
             if (XF32) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    f32x2 p;                        // the forward's bf16 rounding first, then fp16 (exact)
+                    f32x2 p;                        // the forward's bf16 rounding first, then fp16 (exact; saturating)
                     p[0] = (float)(__bf16)__uint_as_float(st.xr[i][e >> 1][(2 * e) & 3]);
                     p[1] = (float)(__bf16)__uint_as_float(st.xr[i][e >> 1][(2 * e + 1) & 3]);
-                    v[e] = pack_f16x2(p);
+                    v[e] = pack_f16x2_rtz(p);
                 }
             } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = pack_f16x2(unpack_bf16x2(st.xr[i][0][e]));
+                for (int e = 0; e < 4; ++e) v[e] = pack_f16x2_rtz(unpack_bf16x2(st.xr[i][0][e]));
             }
             if (DO_P) *(u32x4*)(Xs + (prow + RPP * i) * SPX_BK_ROW + piece * 16) = v;
         }
@@ -440,9 +434,6 @@ __global__ __launch_bounds__(SPX_BK_THREADS, 2) void spx_bank_bwd_kernel(const S
         }
     };
     auto compute = [&]() {
-#ifdef SPX_DIAG_BANK_NOCOMPUTE
-        return;                                       // timing-only build: data movement + commit alone
-#endif
         const bool add_p = DO_P && chunk_scale();
         if constexpr (KSPLIT) {
             if (add_p) bank_part(cpair, 0);
@@ -762,7 +753,7 @@ __global__ __launch_bounds__(SPX_BK_THREADS, 2) void spx_bank_dma_kernel(const S
                 u32x4 w;
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
-                    w[k] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(__uint_as_float(raw[k] << 16), __uint_as_float(raw[k] & 0xffff0000u)));
+                    w[k] = pack_f16x2_rtz(unpack_bf16x2(raw[k]));
                 xb[t] = __builtin_bit_cast(f16x8, w);
             }
 #pragma unroll
@@ -815,9 +806,7 @@ __global__ __launch_bounds__(SPX_BK_THREADS, 2) void spx_bank_dma_kernel(const S
             if (e == 0) advance(cg);                    // (step s + 4 starts the next unit)
             issue_x(xs >= 1 ? xs - 1 : 2, e);           // X slot (j + 2) % 3 = (xs + 2) % 3
             if (e == 1) advance(cx);
-#ifndef SPX_DIAG_BD_NOCOMPUTE
             compute(gs, xs, e);
-#endif
             gs = (gs + 1) & 3;
             if (e == 1) xs = xs == 2 ? 0 : xs + 1;
         }

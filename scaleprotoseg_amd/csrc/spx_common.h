@@ -68,41 +68,6 @@ __device__ __forceinline__ void buf_store_b64(u32x2 v, spx_rsrc r, uint32_t voff
     __builtin_amdgcn_raw_buffer_store_b64(v, r, voff, soff, 0);
 }
 
-// Cache policy (the builtins' aux operand; 2 = nt) of the streams that are touched once per launch: the distance map
-// written by the forward, dDist read and dX / blobs written by the pixel-side backward, the blobs read by the bank-side
-// backward.  Compile-time switches so that a policy can be A/B-timed on one box (tools/probes/ab_libs.sh).
-#ifndef SPX_AUX_MAP_ST
-#define SPX_AUX_MAP_ST 0
-#endif
-#ifndef SPX_AUX_DDIST_LD
-#define SPX_AUX_DDIST_LD 0
-#endif
-#ifndef SPX_AUX_BLOB_ST
-#define SPX_AUX_BLOB_ST 0
-#endif
-#ifndef SPX_AUX_DX_ST
-#define SPX_AUX_DX_ST 0
-#endif
-#ifndef SPX_AUX_BLOB_LD
-#define SPX_AUX_BLOB_LD 0
-#endif
-template <int AUX>
-__device__ __forceinline__ float buf_load_f32_p(spx_rsrc r, uint32_t voff, uint32_t soff) {
-    return __uint_as_float((uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, AUX));
-}
-template <int AUX>
-__device__ __forceinline__ void buf_store_f32_p(float v, spx_rsrc r, uint32_t voff, uint32_t soff) {
-    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, AUX);
-}
-template <int AUX>
-__device__ __forceinline__ u32x4 buf_load_b128_p(spx_rsrc r, uint32_t voff, uint32_t soff) {
-    return __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, AUX);
-}
-template <int AUX>
-__device__ __forceinline__ void buf_store_b128_p(u32x4 v, spx_rsrc r, uint32_t voff, uint32_t soff) {
-    __builtin_amdgcn_raw_buffer_store_b128(v, r, voff + soff, 0, AUX);      // see buf_store_b128
-}
-
 // Logical right shift of a 128-bit value (4 dwords, little endian) by `bits` in [0, 128), zeros shifted in.  Used on the
 // ONE 16-byte piece per feature row that straddles the end of an image whose H*W is not a multiple of the piece: the
 // piece is loaded from a window moved back to end exactly at the row's end (never reading past the tensor) and shifted
@@ -241,6 +206,11 @@ __device__ __forceinline__ float add_bf16x2(uint32_t w, float acc) {
     one2[0] = (__bf16)1.0f;
     one2[1] = (__bf16)1.0f;
     return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, w), one2, acc, false);
+}
+// the same with round-toward-zero: ONE instruction (v_cvt_pkrtz_f16_f32), exact for values with <= 11 significant bits (every
+// bf16 value in fp16's normal range), and a value beyond fp16's range saturates at 65504 instead of becoming inf
+__device__ __forceinline__ uint32_t pack_f16x2_rtz(f32x2 v) {
+    return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(v[0], v[1]));
 }
 __device__ __forceinline__ uint32_t pack_f16x2(f32x2 v) {
     f16x2 p;

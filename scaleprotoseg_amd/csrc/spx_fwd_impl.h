@@ -280,14 +280,14 @@ __global__ __launch_bounds__(256 * SPLIT, (NPB == 2 && NCB == 1 ? 3 : SPX_FWD_WA
                     for (int q = 0; q < 4; ++q) {
                         const f32x4 v = *(const f32x4*)(sc + (8 * q + (lane >> 3)) * SPX_FWD_TROW + 4 * (lane & 7));
                         const uint32_t vo = (full || (pb * 32 + 8 * q + (lane >> 3) < np)) ? voff_dw : SPX_OOB;
-                        buf_store_b128_p<SPX_AUX_MAP_ST>(__builtin_bit_cast(u32x4, v), dr, vo, (uint32_t)(8 * q) * HW * 4u);
+                        buf_store_b128(__builtin_bit_cast(u32x4, v), dr, vo, (uint32_t)(8 * q) * HW * 4u);
                     }
                 } else if (a.dist) {
 #pragma unroll
                     for (int reg = 0; reg < 16; ++reg) {
                         const int rb = (reg & 3) + 8 * (reg >> 2);
                         const uint32_t vo = (full || (pb * 32 + rb + 4 * h < np)) ? voff_d : SPX_OOB;
-                        buf_store_f32_p<SPX_AUX_MAP_ST>(dv[reg], dr, vo, (uint32_t)rb * HW * 4u);
+                        buf_store_f32(dv[reg], dr, vo, (uint32_t)rb * HW * 4u);
                     }
                 }
                 if (ACT) {

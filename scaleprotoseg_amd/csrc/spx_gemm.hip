@@ -20,7 +20,11 @@
 
 typedef float spx_f4u __attribute__((ext_vector_type(4), aligned(4)));      // rows of [pixel][n] tensors are only 4-B aligned in general
 
-static int g_gemm_force_wm = 0, g_gemm_force_splits = 0;      // experiments only (spx_diag_set_gemm; splits < 0: linear block -> tile map)
+#ifdef SPX_DIAG
+static int g_gemm_force_wm = 0, g_gemm_force_splits = 0;      // diagnostic builds only (spx_diag_set_gemm; splits < 0: linear block -> tile map)
+#else
+static constexpr int g_gemm_force_wm = 0, g_gemm_force_splits = 0;
+#endif
 
 struct SpxGemmArgs {
     const float* A; long long ras, kas;
@@ -203,7 +207,9 @@ __global__ __launch_bounds__(256) void spx_gemm_reduce_kernel(const float* __res
 
 // Tile and split policy: a pure function of the shape (results never depend on the machine state).
 struct SpxGemmPlan { int wm, splits, kper; };
+#ifdef SPX_DIAG
 void spx_gemm_force(int wm, int splits) { g_gemm_force_wm = wm; g_gemm_force_splits = splits; }
+#endif
 static SpxGemmPlan spx_gemm_plan(int M, int N, int K, int flags) {
     if (g_gemm_force_wm) {
         int sfor = g_gemm_force_splits < 0 ? -g_gemm_force_splits : g_gemm_force_splits;

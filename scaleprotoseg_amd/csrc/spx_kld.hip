@@ -10,7 +10,10 @@
 // tables and INTEGER atomics (ordered float keys for the max, 64-bit fixed point for the sums), so results do not
 // depend on the order of arrival: the loss is run-to-run bit-identical like the rest of the path.
 #include "spx_common.h"
+#include <algorithm>
 #include <type_traits>
+
+#define SPX_KLD_TABLE_LDS (60 * 1024)      // LDS budget of the per-class tables of the pair and gradient passes (class blocks beyond it)
 
 #define SPX_KLD_THREADS 256
 #define SPX_KLD_PX_PER_WG 2048
@@ -252,15 +255,19 @@ __global__ __launch_bounds__(SPX_KLD_THREADS) void spx_kld_sumexp_kernel(const f
 // pixels (see SpxKldWalk).
 template <int JT>
 __global__ __launch_bounds__(SPX_KLD_THREADS) void spx_kld_pairs_kernel(const float* __restrict__ vals, const int32_t* __restrict__ labels,
-                                                                       int J, int HW, int W, int trows, int K, const float* __restrict__ lse,
+                                                                       int J, int HW, int W, int trows, int Kall, int KB, const float* __restrict__ lse,
                                                                        const double* __restrict__ scale_p, unsigned long long* __restrict__ A_fx) {
     extern __shared__ unsigned long long kld_smem[];
+    // the tables cover the class block [c_lo, c_lo + K) of blockIdx.z (one block when all Kall classes fit the LDS; the
+    // reference's ADE / COCO banks - 150 / 182 classes x 12 slots - take 3 - 4): a pixel of another block's class is a pixel
+    // without a class here, and every segment is summed by exactly one block
+    const int c_lo = blockIdx.z * KB, K = min(KB, Kall - c_lo);
     unsigned long long* tab = kld_smem;                    // [K][J][J], two's complement
-    float* ls = (float*)(tab + K * J * J);                 // [K][J]
+    float* ls = (float*)(tab + KB * J * J);                // [K][J]
     const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const double scale = *scale_p;                         // device-side: the host never reads the data (no sync)
     for (int i = tid; i < K * J * J; i += SPX_KLD_THREADS) tab[i] = 0ull;
-    for (int i = tid; i < K * J; i += SPX_KLD_THREADS) ls[i] = lse[(size_t)b * K * J + i];
+    for (int i = tid; i < K * J; i += SPX_KLD_THREADS) ls[i] = lse[((size_t)b * Kall + c_lo) * J + i];
     __syncthreads();
     const float* v = vals + (size_t)b * J * HW;
     const int32_t* lab = labels + (size_t)b * HW;
@@ -285,7 +292,7 @@ __global__ __launch_bounds__(SPX_KLD_THREADS) void spx_kld_pairs_kernel(const fl
     };
     for (int step = 0; step < w.nsteps; ++step) {
         const int px = w.first + step * w.stride;
-        const int c = step < w.nvalid ? lab[px] : -1;
+        const int c = step < w.nvalid ? lab[px] - c_lo : -1;
         const bool ok = c >= 0 && c < K;
         // lanes without a class (void pixels, lanes past the map) contribute neutral values either way: a step is uniform when
         // the lanes that HAVE a class agree on it (void borders and ragged tile edges do not send it down the per-lane path)
@@ -325,7 +332,7 @@ __global__ __launch_bounds__(SPX_KLD_THREADS) void spx_kld_pairs_kernel(const fl
     publish();
     __syncthreads();
     for (int i = tid; i < K * J * J; i += SPX_KLD_THREADS)
-        if (tab[i]) atomicAdd(&A_fx[(size_t)b * K * J * J + i], tab[i]);
+        if (tab[i]) atomicAdd(&A_fx[((size_t)b * Kall + c_lo) * J * J + i], tab[i]);
 }
 
 // pass 3: gradient.  With Cf = dLoss/d(Gram) (per segment; built below from the caller's dLoss/dA) and sum_px p_j = 1:
@@ -333,26 +340,29 @@ __global__ __launch_bounds__(SPX_KLD_THREADS) void spx_kld_pairs_kernel(const fl
 // - per pixel, given the segment's A and Cf: no reduction.
 template <int JT>
 __global__ __launch_bounds__(SPX_KLD_THREADS) void spx_kld_backward_kernel(const float* __restrict__ vals, const int32_t* __restrict__ labels,
-                                                                          int J, int HW, int K, const float* __restrict__ lse,
+                                                                          int J, int HW, int Kall, int KB, const float* __restrict__ lse,
                                                                           const float* __restrict__ A, const float* __restrict__ Cf,
                                                                           const float* __restrict__ cf_scale, int ppw,
                                                                           float* __restrict__ grad) {
     extern __shared__ unsigned long long kld_smem[];
+    // class block of blockIdx.z (see spx_kld_pairs_kernel): this workgroup writes the gradient of the pixels whose class lies
+    // in its block; block 0 also the zeros of the pixels without a class
+    const int c_lo = blockIdx.z * KB, K = min(KB, Kall - c_lo);
     // tables with rows padded to JT floats (16-B aligned: a pixel reads a row with ds_read_b128; lanes of one class broadcast)
     float* sC = (float*)kld_smem;                          // [K][JT][JT]  Cf, diagonal fixed below
-    float* sT = sC + K * JT * JT;                          // [K][JT][JT]  first A, then Cf transposed
-    float* sL = sT + K * JT * JT;                          // [K][JT]      lse
-    float* sR = sL + K * JT;                               // [K][JT]      sum_j Cf[j][m] + sum_k Cf[m][k] A[m][k]
+    float* sT = sC + KB * JT * JT;                         // [K][JT][JT]  first A, then Cf transposed
+    float* sL = sT + KB * JT * JT;                         // [K][JT]      lse
+    float* sR = sL + KB * JT;                              // [K][JT]      sum_j Cf[j][m] + sum_k Cf[m][k] A[m][k]
     const int b = blockIdx.y, tid = threadIdx.x;
     const float cs = cf_scale ? *cf_scale : 1.0f;          // Cf may arrive unnormalised with its factor in device memory
     for (int i = tid; i < K * JT * JT; i += SPX_KLD_THREADS) {
         const int c = i / (JT * JT), m = (i / JT) % JT, k = i % JT;
         const bool in = m < J && k < J;
-        const size_t src = (size_t)b * K * J * J + ((size_t)c * J + m) * J + k;
+        const size_t src = ((size_t)b * Kall + c_lo) * J * J + ((size_t)c * J + m) * J + k;
         sT[i] = in ? A[src] : 0.0f;
         sC[i] = in ? Cf[src] * cs : 0.0f;
     }
-    for (int i = tid; i < K * JT; i += SPX_KLD_THREADS) sL[i] = (i % JT) < J ? lse[(size_t)b * K * J + (i / JT) * J + (i % JT)] : 0.0f;
+    for (int i = tid; i < K * JT; i += SPX_KLD_THREADS) sL[i] = (i % JT) < J ? lse[((size_t)b * Kall + c_lo) * J + (i / JT) * J + (i % JT)] : 0.0f;
     __syncthreads();
     // A holds A[j][k] - A[j][j] (pass 2), so dLoss/d(Gram) has the off-diagonal entries of Cf and zero row sums;
     // with zero row sums the A[m][m] offset drops out of sum_k Cf[m][k] (l_k - A[m][k]) below
@@ -383,8 +393,9 @@ __global__ __launch_bounds__(SPX_KLD_THREADS) void spx_kld_backward_kernel(const
     const int32_t* lab = labels + (size_t)b * HW;
     const int px_end = min(HW, (int)(blockIdx.x + 1) * ppw);
     for (int px = blockIdx.x * ppw + tid; px < px_end; px += SPX_KLD_THREADS) {
-        const int c = lab[px];
+        const int craw = lab[px], c = craw - c_lo;
         const bool ok = c >= 0 && c < K;
+        if (!ok && !(blockIdx.z == 0 && (craw < 0 || craw >= Kall))) continue;      // another block's pixel
         float l[JT], p[JT];
         spx_kld_load_planes(l, v, J, HW, px);
         const float* slc = sL + (ok ? c : 0) * JT;
@@ -544,25 +555,32 @@ hipError_t spx_launch_kld(int pass, const float* vals, const int32_t* labels, in
     else if (pass == 1)
         hipLaunchKernelGGL(spx_kld_sumexp_kernel, grid, blk, (size_t)K * J * 12, s, vals, labels, J, HW, W, trows, K, (const unsigned int*)t0, (unsigned long long*)out);
     else if (pass == 2) {
-        const size_t lds = (size_t)K * J * J * 8 + (size_t)K * J * 4;
+        // class blocks (grid.z) so that a block's tables fit SPX_KLD_TABLE_LDS
+        const size_t per_class = (size_t)J * J * 8 + (size_t)J * 4;
+        const int KB = (int)std::min<size_t>((size_t)K, std::max<size_t>(1, SPX_KLD_TABLE_LDS / per_class));
+        grid.z = (unsigned)((K + KB - 1) / KB);
+        const size_t lds = (size_t)KB * per_class;
         unsigned long long* o = (unsigned long long*)out;
-        if (J <= 4) hipLaunchKernelGGL(spx_kld_pairs_kernel<4>, grid, blk, lds, s, vals, labels, J, HW, W, trows, K, t0, scale, o);
-        else if (J <= 8) hipLaunchKernelGGL(spx_kld_pairs_kernel<8>, grid, blk, lds, s, vals, labels, J, HW, W, trows, K, t0, scale, o);
-        else if (J <= 12) hipLaunchKernelGGL(spx_kld_pairs_kernel<12>, grid, blk, lds, s, vals, labels, J, HW, W, trows, K, t0, scale, o);
-        else hipLaunchKernelGGL(spx_kld_pairs_kernel<16>, grid, blk, lds, s, vals, labels, J, HW, W, trows, K, t0, scale, o);
+        if (J <= 4) hipLaunchKernelGGL(spx_kld_pairs_kernel<4>, grid, blk, lds, s, vals, labels, J, HW, W, trows, K, KB, t0, scale, o);
+        else if (J <= 8) hipLaunchKernelGGL(spx_kld_pairs_kernel<8>, grid, blk, lds, s, vals, labels, J, HW, W, trows, K, KB, t0, scale, o);
+        else if (J <= 12) hipLaunchKernelGGL(spx_kld_pairs_kernel<12>, grid, blk, lds, s, vals, labels, J, HW, W, trows, K, KB, t0, scale, o);
+        else hipLaunchKernelGGL(spx_kld_pairs_kernel<16>, grid, blk, lds, s, vals, labels, J, HW, W, trows, K, KB, t0, scale, o);
     } else {
         const int JT = J <= 4 ? 4 : (J <= 8 ? 8 : (J <= 12 ? 12 : 16));
-        const size_t lds = (size_t)(2 * K * JT * JT + 2 * K * JT) * 4;
+        const size_t per_class = (size_t)(2 * JT * JT + 2 * JT) * 4;
+        const int KB = (int)std::min<size_t>((size_t)K, std::max<size_t>(1, SPX_KLD_TABLE_LDS / per_class));
+        grid.z = (unsigned)((K + KB - 1) / KB);
+        const size_t lds = (size_t)KB * per_class;
         float* o = (float*)out;
         // pixels per workgroup: 2048 on large maps; small maps (training crops) get enough workgroups to fill the chip - a thread
         // then takes one pixel instead of walking eight in sequence behind the table set-up (80 -> ~20 us at 10 x 65 x 65)
         int ppw = SPX_KLD_PX_PER_WG;
         while (ppw > SPX_KLD_THREADS && (long long)B * ((HW + ppw - 1) / ppw) < 512) ppw >>= 1;
         grid.x = (unsigned)((HW + ppw - 1) / ppw);
-        if (J <= 4) hipLaunchKernelGGL(spx_kld_backward_kernel<4>, grid, blk, lds, s, vals, labels, J, HW, K, t0, t1, t2, cf_scale, ppw, o);
-        else if (J <= 8) hipLaunchKernelGGL(spx_kld_backward_kernel<8>, grid, blk, lds, s, vals, labels, J, HW, K, t0, t1, t2, cf_scale, ppw, o);
-        else if (J <= 12) hipLaunchKernelGGL(spx_kld_backward_kernel<12>, grid, blk, lds, s, vals, labels, J, HW, K, t0, t1, t2, cf_scale, ppw, o);
-        else hipLaunchKernelGGL(spx_kld_backward_kernel<16>, grid, blk, lds, s, vals, labels, J, HW, K, t0, t1, t2, cf_scale, ppw, o);
+        if (J <= 4) hipLaunchKernelGGL(spx_kld_backward_kernel<4>, grid, blk, lds, s, vals, labels, J, HW, K, KB, t0, t1, t2, cf_scale, ppw, o);
+        else if (J <= 8) hipLaunchKernelGGL(spx_kld_backward_kernel<8>, grid, blk, lds, s, vals, labels, J, HW, K, KB, t0, t1, t2, cf_scale, ppw, o);
+        else if (J <= 12) hipLaunchKernelGGL(spx_kld_backward_kernel<12>, grid, blk, lds, s, vals, labels, J, HW, K, KB, t0, t1, t2, cf_scale, ppw, o);
+        else hipLaunchKernelGGL(spx_kld_backward_kernel<16>, grid, blk, lds, s, vals, labels, J, HW, K, KB, t0, t1, t2, cf_scale, ppw, o);
     }
     return hipGetLastError();
 }

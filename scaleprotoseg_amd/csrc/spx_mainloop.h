@@ -216,12 +216,7 @@ struct SpxAStager {
 
     __device__ __forceinline__ void load(const char* bank_chunk, bool real, int tid) {
         const spx_rsrc br_ = make_rsrc_pred(bank_chunk);
-#ifdef SPX_DIAG_NO_BANK
-        const uint32_t bvo = SPX_OOB;   // timing-only build: prices the bank-fragment stream (results are wrong)
-        (void)real;
-#else
         const uint32_t bvo = real ? (uint32_t)(tid * 16) : SPX_OOB;
-#endif
 #pragma unroll
         for (int i = 0; i < APASS; ++i) ar[i] = buf_load_b128(br_, in_range(i, tid) ? bvo : SPX_OOB, (uint32_t)(i * PASS_BYTES));
     }

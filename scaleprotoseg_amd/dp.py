@@ -187,8 +187,18 @@ class DataParallelStep:
         self.grad_hook = grad_hook
         self.scheduler = scheduler
         self.iter_steps = 0
-        params = [p for g in optimizer.param_groups for p in g["params"]]
-        self.bucket = FlatGradBucket(params, attach=True)
+        self.bucket = FlatGradBucket(self._trainable(), attach=True)
+
+    def _trainable(self):
+        return [p for g in self.optimizer.param_groups for p in g["params"] if p.requires_grad]
+
+    def _sync_bucket(self):
+        """The optimizer's trainable parameters can change between steps (the warm-up -> joint phase switch unfreezes the
+        backbone, a param group is added): a parameter outside the bucket would be neither all-reduced nor cleared and the
+        replicas would drift apart silently.  Rebuild the bucket when the set differs (existing gradients are carried over)."""
+        now = self._trainable()
+        if len(now) != len(self.bucket.params) or any(a is not b for a, b in zip(now, self.bucket.params)):
+            self.bucket = FlatGradBucket(now, attach=True)
 
     def backward(self, loss: torch.Tensor) -> bool:
         """Accumulate ``loss / iter_size``; at the end of the window all-reduce, step and re-project.  Returns True when
@@ -198,6 +208,7 @@ class DataParallelStep:
         if self.iter_steps < self.iter_size:
             return False
         self.iter_steps = 0
+        self._sync_bucket()
         self.bucket.all_reduce(group=self.group, average=True)
         if self.grad_hook is not None:
             self.grad_hook()

@@ -684,6 +684,9 @@ def proto_head_forward(
 ):
     """(logits [B*H*W, K] | None, distances [B,P,H,W] | None, activations [B*H*W, P] | None).
 
+    ``x``: the reference's ``conv_features`` (a Sigmoid's output, values in (0, 1)); any bf16 / fp32 values are accepted, but
+    the prototype gradient takes features beyond +-65504 as saturated (its product runs in fp16; include/spx_hip.h).
+
     With ``class_gather`` the distance output is the class-gathered tensor [B, J, H*W] (slot planes) instead of the P-wide map
     (the only entries the reference's KLDLoss reads, segmentation/model/loss.py:89-107)."""
     if activation not in ACT_FN:

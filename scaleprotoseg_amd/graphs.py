@@ -28,8 +28,28 @@ from ._lib import SpxError
 _STALE = "AccumulateGrad node's stream does not match"
 
 
+class StepGraph:
+    """A captured step.  ``replay()`` re-runs it and then drops the package's pack cache: a captured step that contains the
+    optimizer edits the parameters IN PLACE without touching their ``_version`` or storage - the cache's key - so a pack
+    built by an eager forward before the replay (evaluation, the prototype push) would otherwise be served again after it.
+    (The captured step itself never uses the cache: its pack kernels are part of the graph.)  ``graph`` is the underlying
+    ``torch.cuda.CUDAGraph``; whoever replays THAT directly must call ``functional.invalidate_pack_cache()`` themselves."""
+
+    def __init__(self, graph: "torch.cuda.CUDAGraph"):
+        self.graph = graph
+
+    def replay(self) -> None:
+        from .functional import invalidate_pack_cache
+
+        self.graph.replay()
+        invalidate_pack_cache()
+
+    def __getattr__(self, name):
+        return getattr(self.graph, name)
+
+
 def capture_step(step: Callable[[], Any], warmup: int = 3, stream: Optional[torch.cuda.Stream] = None,
-                 ) -> Tuple[torch.cuda.CUDAGraph, Any]:
+                 ) -> Tuple[StepGraph, Any]:
     """Warm ``step`` up ``warmup`` times and capture one call of it into a HIP graph.
 
     ``step`` is a closure over static input tensors (refill them in place between replays) that runs forward and - if
@@ -70,4 +90,7 @@ def capture_step(step: Callable[[], Any], warmup: int = 3, stream: Optional[torc
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph, stream=s):
         outputs = step()
-    return graph, outputs
+    from .functional import invalidate_pack_cache
+
+    invalidate_pack_cache()          # (the warm-up ran eagerly: whatever it cached predates the graph's own updates)
+    return StepGraph(graph), outputs

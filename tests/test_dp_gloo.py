@@ -313,3 +313,28 @@ def test_flat_bucket_views_survive_backward_and_zero():
     (b.sum()).backward()
     bucket.all_reduce()
     assert b.grad.data_ptr() == bucket.views[1].data_ptr() and torch.allclose(b.grad, torch.ones(5))
+
+
+def test_data_parallel_step_follows_a_parameter_unfrozen_later():
+    """The warm-up -> joint phase switch unfreezes parameters the optimizer already holds: from that step on they must be in the
+    bucket (all-reduced AND cleared), not accumulate outside it."""
+    from scaleprotoseg_amd.dp import DataParallelStep
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = torch.nn.Parameter(torch.ones(3))
+            self.b = torch.nn.Parameter(torch.ones(2), requires_grad=False)      # frozen during the warm-up phase
+
+    net = Net()
+    opt = torch.optim.SGD([net.a, net.b], lr=0.0)
+    dp = DataParallelStep(net, opt)
+    dp.backward((net.a * 2).sum() + (net.b * 3).sum())
+    assert net.b.grad is None and len(dp.bucket.params) == 1
+    net.b.requires_grad_(True)                                                    # joint phase
+    for _ in range(3):
+        assert dp.backward((net.a * 2).sum() + (net.b * 3).sum())
+        assert len(dp.bucket.params) == 2
+        assert float(net.b.grad.abs().sum()) == 0.0                               # cleared with the bucket: no accumulation across steps
+    (net.b * 3).sum().backward()
+    assert torch.allclose(net.b.grad, torch.full((2,), 3.0)) and net.b.grad.data_ptr() == dp.bucket.views[1].data_ptr()

@@ -873,6 +873,39 @@ def test_kld_kernels_large_random():
         assert (v1.grad.double() - v2.grad).abs().max().item() <= 1e-4 * s + 1e-12
 
 
+@pytest.mark.parametrize("K,per", [(150, 12), (182, 12)])
+def test_kld_kernels_with_the_ade_and_coco_class_counts(K, per):
+    """scaleproto_ade.gin (150 classes x 12 prototypes) / scaleproto_coco.gin (182 x 12) with loss_weight_kld = 0.25: the
+    [K, J, J] tables of the pair and gradient passes exceed the LDS and are tiled over class blocks (the loss had no
+    backend there).  Value and gradient against the oracle's torch restatement in fp64, on the crops those configs train on."""
+    import scaleprotoseg_amd as spx
+
+    dev = _dev()
+    P, S, B, H, W = K * per, 4, 2, 33, 65
+    ident = O.default_class_identity(P, K, S)
+    ranges = O.default_scale_ranges(P, S)
+    lay = _layout(P, K if K <= 160 else 1, S, 16, ranges)       # (more than 160 classes: the head is not in the plan, as in the module)
+    keys, J, table = spx.class_gather_table(lay, ident, dev)
+    assert J == per
+    gen = torch.Generator(device=dev).manual_seed(11)
+    coarse = torch.randn(B, K + 1, 3, 5, device=dev, generator=gen)
+    t = torch.nn.functional.interpolate(coarse, size=(H, W), mode="bilinear", align_corners=False).argmax(dim=1)     # irregular regions
+    t[0, :4] = torch.randint(0, K + 1, (4, W), device=dev, generator=gen)                                            # and some salt
+    base = torch.rand(B, J, H * W, device=dev, generator=gen) * 20
+    loss_fn = spx.KLDLoss(ident, S, ranges)
+    lab0 = (t.reshape(B, -1) - 1).int()
+    v1 = base.clone().requires_grad_(True)
+    l1 = loss_fn(spx.ClassDistances(v1, lab0, table, (H, W)), t)
+    l1.backward()
+    v2 = base.double().clone().requires_grad_(True)
+    l2 = LO.kld_loss(loss_fn, spx.ClassDistances(v2, lab0, table, (H, W)), t)
+    l2.backward()
+    torch.cuda.synchronize()
+    assert abs(l1.item() - l2.item()) <= 1e-5 * max(1.0, abs(l2.item())), (l1.item(), l2.item())
+    sc = v2.grad.abs().max().item()
+    assert sc > 0 and (v1.grad.double() - v2.grad).abs().max().item() <= 1e-4 * sc + 1e-12
+
+
 def test_kld_group_kernels_match_reference_golden(golden):
     """KLDLossGroup on the GPU (class-gathered group activations through csrc/spx_kld.hip) against the reference's
     KLDLossGroup value and gradients (segmentation/model/loss.py:461-545), run-to-run bit-identical."""
@@ -1199,6 +1232,65 @@ def test_hip_graph_capture_replay():
     del graph
     ref2 = eager()
     assert all(torch.equal(a, b) for a, b in zip(got, ref2))
+
+
+@pytest.mark.parametrize("hw", [(8, 16), (5, 7)])       # the LDS-DMA and the register-staged parameter kernel
+def test_features_beyond_the_fp16_range_give_finite_prototype_gradients(hw):
+    """The d_bank product runs in fp16: a feature of 1e5 (representable in bf16) must saturate, not become inf (0 * inf = NaN
+    in every prototype gradient)."""
+    from scaleprotoseg_amd.functional import proto_head_forward
+
+    dev = _dev()
+    B, S, Cs, P, K = 1, 1, 128, 40, 5
+    H, W = hw
+    conv, bank, Wl, ident, ranges = _problem(B, S, Cs, P, K, H, W, seed=4)
+    conv[0, 3, 1, 2] = 1.0e5
+    conv[0, 70, 0, 0] = -3.0e5
+    x = conv.to(dev, torch.bfloat16)
+    pv = bank.to(dev).requires_grad_(True)
+    w = Wl.to(dev).requires_grad_(True)
+    logits, dist, _ = proto_head_forward(x, pv, w, _layout(P, K, S, Cs, ranges), want_distances=True)
+    g = torch.Generator().manual_seed(3)
+    ((logits * (torch.randn(B * H * W, K, generator=g) * 1e-3).to(dev)).sum() + (dist * 1e-9).sum()).backward()
+    assert torch.isfinite(pv.grad).all() and torch.isfinite(w.grad).all()
+
+
+def test_eager_forward_after_graph_replays_sees_the_updated_parameters():
+    """A captured step with the optimizer inside edits bank and head in place (no version bump, same storage): the pack cache
+    must not serve an eager forward the packs of the parameters as they were BEFORE the replays."""
+    from scaleprotoseg_amd.functional import proto_head_forward
+    from scaleprotoseg_amd.graphs import capture_step
+
+    dev = _dev()
+    B, S, Cs, P, K, H, W = 1, 1, 32, 40, 5, 8, 16
+    conv, bank, Wl, ident, ranges = _problem(B, S, Cs, P, K, H, W, seed=9)
+    lay = _layout(P, K, S, Cs, ranges)
+    x = conv.to(dev)
+    pv = bank.to(dev).requires_grad_(True)
+    w = Wl.to(dev).requires_grad_(True)
+    opt = torch.optim.SGD([pv, w], lr=0.5)
+    g_logits = (torch.randn(B * H * W, K, generator=torch.Generator().manual_seed(1)) * 1e-2).to(dev)
+
+    def step():
+        opt.zero_grad(set_to_none=False)
+        logits, _, _ = proto_head_forward(x, pv, w, lay, want_distances=False)
+        (logits * g_logits).sum().backward()
+        opt.step()
+
+    with torch.no_grad():
+        proto_head_forward(x, pv, w, lay, want_distances=True)       # an eager forward: fills the pack cache
+    graph, _ = capture_step(step, warmup=1)
+    for _ in range(3):
+        graph.replay()
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        logits, dist, _ = proto_head_forward(x, pv, w, lay, want_distances=True)
+    # the oracle on the parameters AS THEY ARE NOW (rounded to bf16 as the kernels take the bank)
+    ref_logits, ref_dist, _ = O.forward_from_conv_features(conv, O.bf16_representable(pv.detach().cpu()), ranges, S, w.detach().cpu())
+    assert not torch.equal(pv.detach().cpu(), bank)                   # the optimizer did move them
+    assert ((dist.cpu() - ref_dist).abs() <= 1e-4 * (1 + ref_dist)).all()
+    rl = ref_logits.reshape(-1, K)
+    assert (logits.cpu() - rl).abs().max() <= 1e-4 * max(1.0, rl.abs().max().item())
 
 
 def test_capture_step_refuses_a_stale_default_stream_graph():

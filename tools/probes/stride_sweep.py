@@ -10,7 +10,7 @@ from scaleprotoseg_amd.functional import proto_head_forward
 dev = torch.device("cuda:0")
 from scaleprotoseg_amd import _lib
 MUL = int(sys.argv[1]) if len(sys.argv) > 1 else 0      # 0 = the library's automatic choice, 1 = identity
-_lib.load().spx_diag_set_tile_mul(MUL)
+_lib.load().spx_diag_set_tile_mul(MUL)      # needs a library built with -DSPX_DIAG (tools/build_variant.sh)
 print('tile multiplier', MUL)
 C_, P, K = 256, 190, 19
 lay = spx.BankLayout(P, K, 1, C_, ((0, P),))
