@@ -452,14 +452,14 @@ def main():
                     and args.outputs == "logits,dist" and args.grads == "logits,dist" and not args.freeze and not args.group_tail:
                 try:
                     tj = json.load(open(tfile))
-                    parts = ["spx_dist_fwd"] if dominant == "spx_dist_fwd" else ["spx_dist_bwd", "spx_bank_bwd", "spx_bank_reduce"]
+                    parts = ["spx_dist_fwd"] if dominant == "spx_dist_fwd" else ["spx_dist_bwd", "spx_bank_bwd", "spx_dw_reduce", "spx_bank_reduce"]
                     if all(p_ in tj for p_ in parts[:2 if dominant == "backward" else 1]):
                         traffic = int(sum(tj.get(p_, 0) for p_ in parts))
                         traffic_src = f"profiles/traffic.json ({tj.get('_source', 'rocprofv3 --pmc passes')})"
                 except Exception:
                     traffic = None
             out["roofline"] = {
-                "kernel": dominant if dominant != "backward" else "backward = spx_dist_bwd (kernel 1) + spx_bank_bwd (kernels 2 + 3)",
+                "kernel": dominant if dominant != "backward" else "backward = spx_dist_bwd (pixel kernel) + spx_bank_bwd (parameter kernel + the two fixed-order reductions)",
                 "bound": "hbm",
                 "achieved": round(ach, 1),
                 "peak": HBM_PEAK_GBS,

@@ -42,7 +42,7 @@ for f in glob.glob(root + "/pmc_*/*/*counter_collection.csv"):
 if agg:
     # HBM bytes per launch per operator (C-ABI name), for bench.py's roofline.traffic
     opmap = {"spx_fwd_kernel": "spx_dist_fwd", "spx_bwd_kernel": "spx_dist_bwd", "spx_bank_bwd_kernel": "spx_bank_bwd",
-             "spx_bank_reduce_kernel": "spx_bank_reduce", "spx_bwdf_kernel": "spx_dist_bwd_fused"}
+             "spx_bank_dma_kernel": "spx_bank_bwd", "spx_bank_reduce_kernel": "spx_bank_reduce", "spx_dw_reduce_kernel": "spx_dw_reduce"}
     traffic = {}
     for k, v in agg.items():
         for kn, op in opmap.items():
