@@ -19,7 +19,7 @@ static constexpr int g_tile_mul_req = 0;
 
 // Block -> tile permutation of the pixel kernels: tile = (block * mul) mod tiles with mul coprime to the tile count, so that
 // the workgroups running at one time are spread over the whole pixel range instead of covering one contiguous stretch of every
-// feature plane (plane strides).
+// feature plane (see profiles/EXPERIMENTS.md, plane strides).
 static int gcd_i(int a, int b) { while (b) { const int t = a % b; a = b; b = t; } return a; }
 int spx_tile_mul(int tiles_launch, long long plane_bytes) {
     // Automatic: only where the feature planes are a multiple of 1 MiB apart (power-of-two grids such as 1024 x 2048: plane

@@ -76,7 +76,7 @@ __device__ __forceinline__ SpxKldWalk spx_kld_walk(int HW, int W, int trows, int
         // a step of a wave = a 16-column x 4-row block, the wave walks DOWN its 16-column strip (trows rows: 64 = 16 steps on
         // large maps, fewer on small ones so that the chip fills), the four waves of a workgroup sit side by side.  A compact block lies inside ONE label region far more often
         // than a 64 x 1 row segment does (a 64-pixel row of a map with 16-pixel regions is never of one class; 613 us -> see
-        // DESIGN.md for the pair pass at 2 Mpx), and every load instruction still moves four whole 64-B pieces.
+        // profiles/EXPERIMENTS.md for the pair pass at 2 Mpx), and every load instruction still moves four whole 64-B pieces.
         const int tiles_x = (W + SPX_KLD_TILE - 1) / SPX_KLD_TILE, H = HW / W;
         const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
         const int col = tx * SPX_KLD_TILE + wave * 16 + (lane & 15), row = ty * trows + (lane >> 4);
