@@ -519,14 +519,15 @@ class _ProtoHeadFn(torch.autograd.Function):
                                                   _lib.ptr(pred_), _lib.ptr(partials), _lib.stream_ptr()))
                         ce_state = (ce_labels_, lse_, pred_, partials)
         ctx.gather = gather
-        ctx.gact = gact
         ctx.tail2d = tail2d
         ctx.layout, ctx.plan, ctx.packs = layout, plan, packs
         ctx.epsilon, ctx.act_fn = float(epsilon), act_fn
         ctx.have = (logits is not None, dist is not None, act is not None)
         # (the logits are an OUTPUT: kept through save_for_backward, never as a ctx attribute - that would be a reference
         # cycle node -> ctx -> tensor -> node that outlives the backward and keeps the leaves' AccumulateGrad nodes alive)
-        ctx.save_for_backward(x, bank2d, head2d, logits if ce_state is not None else None)
+        # (gact too: it is a differentiable OUTPUT since round 4 - compute_group's list - and as a ctx attribute it would close the
+        # same cycle)
+        ctx.save_for_backward(x, bank2d, head2d, logits if ce_state is not None else None, gact)
         ctx.bank_shape = tuple(bank.shape)
         outs = tuple(t if t is not None else x.new_empty(0) for t in (logits, dist, act))
         extra = gact if tail2d is not None else x.new_empty(0)     # exp(units): compute_group's list; a gradient on it enters the backward's dUnits
@@ -544,7 +545,7 @@ class _ProtoHeadFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_logits, g_dist, g_act, g_gact=None, g_ce=None, _g_pred=None):
         lib = _lib.load()
-        x, bank2d, head2d, ce_logits = ctx.saved_tensors
+        x, bank2d, head2d, ce_logits, gact = ctx.saved_tensors
         layout, plan, packs = ctx.layout, ctx.plan, ctx.packs
         B, HW = _check_x(x, layout)
         P, K, Cs = layout.num_prototypes, layout.num_classes, layout.channels_per_scale
@@ -596,7 +597,7 @@ class _ProtoHeadFn(torch.autograd.Function):
                 _lib.check(
                     lib.spx_dist_bwd_group_ce(
                         pp, _lib.ptr(x), xd, B, HW, _lib.ptr(packs.bank), _lib.ptr(packs.bankT), _lib.ptr(packs.p2),
-                        _lib.ptr(packs.headT), _lib.ptr(packs.tailT), int(tail2d.shape[0]), _lib.ptr(ctx.gact),
+                        _lib.ptr(packs.headT), _lib.ptr(packs.tailT), int(tail2d.shape[0]), _lib.ptr(gact),
                         _lib.ptr(gd), _lib.ptr(ga), C.byref(ce), _lib.ptr(gg), _lib.ptr(d_units), _lib.ptr(dx), _lib.ptr(dx_acc), _lib.ptr(g_scr),
                         _lib.ptr(a_scr), ctx.epsilon, ACT_FN[ctx.act_fn], s,
                     )
@@ -606,7 +607,7 @@ class _ProtoHeadFn(torch.autograd.Function):
                 _lib.check(
                     lib.spx_dist_bwd_group(
                         pp, _lib.ptr(x), xd, B, HW, _lib.ptr(packs.bank), _lib.ptr(packs.bankT), _lib.ptr(packs.p2),
-                        _lib.ptr(packs.headT), _lib.ptr(packs.tailT), int(tail2d.shape[0]), _lib.ptr(ctx.gact),
+                        _lib.ptr(packs.headT), _lib.ptr(packs.tailT), int(tail2d.shape[0]), _lib.ptr(gact),
                         _lib.ptr(gd), _lib.ptr(ga), _lib.ptr(gl), _lib.ptr(gg), _lib.ptr(d_units), _lib.ptr(dx), _lib.ptr(dx_acc), _lib.ptr(g_scr),
                         _lib.ptr(a_scr), ctx.epsilon, ACT_FN[ctx.act_fn], s,
                     )
@@ -644,7 +645,7 @@ class _ProtoHeadFn(torch.autograd.Function):
             gl = d_logits_ce                          # formed by the pixel kernel's prologue
         if tail2d is not None:
             if ctx.needs_input_grad[9]:
-                d_tail = _pixel_outer(gl, ctx.gact)   # d W_g [K2, U]: one small product over the pixels
+                d_tail = _pixel_outer(gl, gact)   # d W_g [K2, U]: one small product over the pixels
             gl = d_units                              # the parameter kernel's d_logits operand
         if need_bank or need_head:
             ws = torch.empty(lib.spx_bank_bwd_workspace_bytes(pp, B, HW) // 4, dtype=torch.float32, device=dev)
