@@ -472,10 +472,13 @@ __global__ __launch_bounds__(256, SPX_BWD_WAVES) void spx_bwd_kernel(const SpxBw
             if (pb < nv) {
                 if (have_dd && pb + 1 < nv) load_ddist(pb + 1, ddnext);
                 const bool full = pb * 32 + 32 <= np;
-                f32x16 ga;        // (dAct + dLogits.W) * c1, c1 = the constant factor of act'(d)
+                // (dAct + dLogits.W) * c1, c1 = the constant factor of act'(d).  The chain starts from a literal zero C operand
+                // (no 16 v_mov per block); with the head image in LDS it runs unconditionally - without a logits gradient both
+                // the image and the dLogits fragments are zeros
+                f32x16 ga;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) ga[i] = 0.0f;
-                if (have_dl) {
+                if (head_lds != 0 || have_dl) {
 #pragma unroll
                     for (int c = 0; c < ncstep; ++c) {
                         bf16x8 whi, wlo;

@@ -938,3 +938,38 @@ def test_fused_cross_entropy_leaves_no_graph_alive():
         torch.cuda.synchronize()
     finally:
         gc.enable()
+
+
+def test_group_step_leaves_no_graph_alive():
+    """The same for the group phase, whose kernel output exp(units) is differentiable (compute_group's list) and must reach the
+    backward through save_for_backward, not as a ctx attribute (round 4: that cycle made capture_step refuse the step)."""
+    import gc
+    from scaleprotoseg_amd.graphs import capture_step
+    from scaleprotoseg_amd.model_multiscale_group import PPNetMultiScale as GroupNet
+
+    dev = _dev()
+    gc.collect()
+    gc.disable()
+    try:
+        B, S, Cs, P, K, H, W = 2, 4, 16, 40, 5, 9, 11
+        net = GroupNet(_Backbone(S * Cs), 64, (P, Cs, 1, 1), [], K, add_on_layers_type="deeplab_simple",
+                       patch_classification=True, num_scales=S, num_groups=3).to(dev)
+        net.add_on_layers = nn.Sequential()
+        x = torch.rand(B, S * Cs, H, W, device=dev).requires_grad_(True)
+        gl = torch.randn(B, H, W, K, device=dev) * 1e-3
+
+        def step():
+            x.grad = None
+            for p in net.parameters():
+                p.grad = None
+            logits, dist, act = net.forward_from_conv_features(x, return_activations=True, return_distances=True)
+            groups = net.compute_group(act)
+            ((logits * gl).sum() + 1e-3 * torch.cat(groups, dim=1).sum()).backward()
+
+        step()
+        step()
+        graph, _ = capture_step(step, warmup=1)          # raises SpxError if an eager graph is still alive
+        graph.replay()
+        torch.cuda.synchronize()
+    finally:
+        gc.enable()
