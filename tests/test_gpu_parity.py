@@ -678,6 +678,9 @@ def _random_case(rng):
     H, W = int(rng.integers(1, 24)), int(rng.integers(1, 40))
     if rng.random() < 0.3:
         W = 8 * int(rng.integers(1, 12))         # aligned rows: vector staging path
+    if rng.random() < 0.2:                       # (drawn last: the other seeds keep their round-3 configurations)
+        # H*W a multiple of 64 and scales wider than 64 channels: the LDS-DMA parameter kernel (bf16 features, K <= 32)
+        H, W, Cs = 8 * int(rng.integers(1, 4)), 8 * int(rng.integers(1, 6)), int(rng.choice([80, 96, 128]))
     return B, S, Cs, per_scale, K, H, W
 
 
