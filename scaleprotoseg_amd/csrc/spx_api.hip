@@ -319,9 +319,7 @@ int spx_dist_fwd_group_ws(const spx_plan* pl, const void* x, int32_t x_dtype, in
                       activations, parts, epsilon, act_fn, stream, SpxTailFwd{nullptr, 0, nullptr}, nullptr, nullptr, true))
         return 1;
     const long long M = (long long)B * HW;
-    // the tail writes one (sum, count) pair per 64 pixels; the caller sized `partials` with spx_ce_partials_flat (>= that)
-    if (ce && hipMemsetAsync(ce->partials, 0, spx_ce_partials_flat(M) * 2 * sizeof(float), (hipStream_t)stream) != hipSuccess)
-        return fail("spx_dist_fwd_group_ws: clearing the partials failed");
+    // the tail writes one (sum, count) pair per 64 pixels and clears the rest of the spx_ce_partials_flat(M) pairs itself
     return hip_status(spx_launch_group_tail(parts, groups, M, pl->num_classes, Wg, K2, group_activations, logits,
                                             ce ? ce->labels : nullptr, ce ? ce->lse : nullptr, ce ? ce->pred : nullptr,
                                             ce ? ce->partials : nullptr, (hipStream_t)stream), "spx_dist_fwd_group_ws (tail)");

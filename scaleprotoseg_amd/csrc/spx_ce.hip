@@ -67,16 +67,17 @@ __global__ __launch_bounds__(SPX_CE_THREADS) void spx_sum_many_groups_kernel(con
     __shared__ float red[8][32];
     const int el = threadIdx.x & 31, sl = threadIdx.x >> 5;
     const size_t i = (size_t)blockIdx.x * 32 + el;
-    float s0 = 0.0f, s1 = 0.0f;
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
     if (i < n) {
         int g = sl;
-        for (; g + 8 < groups; g += 16) {
-            s0 += parts[(size_t)g * n + i];
-            s1 += parts[(size_t)(g + 8) * n + i];
+        for (; g + 24 < groups; g += 32) {          // four independent loads in flight per round
+            const float v0 = parts[(size_t)g * n + i], v1 = parts[(size_t)(g + 8) * n + i];
+            const float v2 = parts[(size_t)(g + 16) * n + i], v3 = parts[(size_t)(g + 24) * n + i];
+            s0 += v0; s1 += v1; s2 += v2; s3 += v3;
         }
-        if (g < groups) s0 += parts[(size_t)g * n + i];
+        for (; g < groups; g += 8) s0 += parts[(size_t)g * n + i];
     }
-    red[sl][el] = s0 + s1;
+    red[sl][el] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (sl == 0 && i < n) {
         float t = red[0][el];
@@ -106,58 +107,124 @@ __global__ __launch_bounds__(SPX_CE_THREADS) void spx_group_tail_kernel(const fl
                                                                       float* __restrict__ gact, float* __restrict__ logits,
                                                                       const int32_t* __restrict__ labels, float* __restrict__ lse_out,
                                                                       int32_t* __restrict__ pred, float* __restrict__ partials) {
-    extern __shared__ float tail_s[];
+    extern __shared__ __attribute__((aligned(16))) float tail_s[];
     const int US = U | 1;                                 // odd row stride: conflict-free column walks
-    float* const wg_s = tail_s;                           // [K2][U]
-    float* const g_s = wg_s + K2 * U;                     // [64][US]
+    float* const wg_s = tail_s;                           // [U][32]
+    float* const g_s = wg_s + 32 * U;                     // [64][US]
     float* const l_s = g_s + SPX_TAIL_PX * US;            // [64][33]
+    float* const q_s = l_s + SPX_TAIL_PX * 33;            // [64][4] x 3: the class quarters' maxima, arg maxima, exp sums
     const long long m0 = (long long)blockIdx.x * SPX_TAIL_PX;
     const int npx = (int)((M - m0) < SPX_TAIL_PX ? (M - m0) : SPX_TAIL_PX);
-    for (int i = threadIdx.x; i < K2 * U; i += SPX_CE_THREADS) wg_s[i] = Wg[i];
     const size_t base = (size_t)m0 * U;
-    for (int i = threadIdx.x; i < SPX_TAIL_PX * U; i += SPX_CE_THREADS) {
-        const int p = i / U, u = i - p * U;
-        float gv = 0.0f;
-        if (p < npx) {
-            float un = parts[base + i];
-            for (int g = 1; g < groups; ++g) un += parts[(size_t)g * M * U + base + i];     // scale order: deterministic
-            gv = ce_exp(un);
-            if (gact) gact[base + i] = gv;
+    // Staging: every round has all its loads in flight before the first use (a rolled load -> LDS loop pays one memory round
+    // trip per element and scale group: 14 x 4 of them for 57 units and four groups, most of this kernel's time as measured).
+    // W_g transposed and padded to 32 classes ([u][32], zeros past K2): a thread's 8 classes of one unit are two 16-B reads,
+    // and the product loop carries no per-class condition (a guarded LDS read is its own wait: 9 serial LDS round trips per
+    // unit, 20 of this kernel's 31 us on the Cityscapes crops as first written)
+    const int nw = 32 * U;
+    for (int i0 = threadIdx.x; i0 < nw; i0 += 8 * SPX_CE_THREADS) {
+        float w[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int i = i0 + t * SPX_CE_THREADS, u = i >> 5, k = i & 31;
+            w[t] = (i < nw && k < K2) ? Wg[k * U + u] : 0.0f;
         }
-        g_s[p * US + u] = gv;
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+            if (i0 + t * SPX_CE_THREADS < nw) wg_s[i0 + t * SPX_CE_THREADS] = w[t];
+    }
+    const int ntot = npx * U;
+    const unsigned inv_u = ((1u << 24) + (unsigned)U - 1u) / (unsigned)U;
+    for (int i0 = threadIdx.x; i0 < ntot; i0 += 8 * SPX_CE_THREADS) {
+        float un[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) un[t] = 0.0f;
+        for (int g0 = 0; g0 < groups; g0 += 4) {            // scale order: deterministic
+            float v[4][8];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float* const pg = parts + (size_t)(g0 + g < groups ? g0 + g : 0) * M * U + base;
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const int i = i0 + t * SPX_CE_THREADS;
+                    v[g][t] = (g0 + g < groups && i < ntot) ? pg[i] : 0.0f;
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int t = 0; t < 8; ++t) un[t] += v[g][t];
+        }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int i = i0 + t * SPX_CE_THREADS;
+            if (i < ntot) {
+                const float gv = ce_exp(un[t]);
+                if (gact) gact[base + i] = gv;
+                const int p = (int)(((unsigned)i * inv_u) >> 24);      // = i / U: exact for i < 64 U, U <= 160
+                g_s[p * US + (i - p * U)] = gv;
+            }
+        }
+    }
+    for (int i = ntot + threadIdx.x; i < SPX_TAIL_PX * U; i += SPX_CE_THREADS) {     // rows past the end read as 0
+        const int p = i / U;
+        g_s[p * US + (i - p * U)] = 0.0f;
     }
     __syncthreads();
     const int p = threadIdx.x & (SPX_TAIL_PX - 1), kq = threadIdx.x / SPX_TAIL_PX;     // pixel, class quarter (8 classes)
     float acc[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = 0.0f;
+    const float4* const wq = (const float4*)(wg_s + kq * 8);
+#pragma unroll 4
     for (int u = 0; u < U; ++u) {
         const float gv = g_s[p * US + u];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int k = kq * 8 + j;
-            if (k < K2) acc[j] = __builtin_fmaf(wg_s[k * U + u], gv, acc[j]);
-        }
+        const float4 w0 = wq[u * 8], w1 = wq[u * 8 + 1];
+        acc[0] = __builtin_fmaf(w0.x, gv, acc[0]);
+        acc[1] = __builtin_fmaf(w0.y, gv, acc[1]);
+        acc[2] = __builtin_fmaf(w0.z, gv, acc[2]);
+        acc[3] = __builtin_fmaf(w0.w, gv, acc[3]);
+        acc[4] = __builtin_fmaf(w1.x, gv, acc[4]);
+        acc[5] = __builtin_fmaf(w1.y, gv, acc[5]);
+        acc[6] = __builtin_fmaf(w1.z, gv, acc[6]);
+        acc[7] = __builtin_fmaf(w1.w, gv, acc[7]);
     }
+    // the quarter's share of the cross entropy from its registers: maximum / arg maximum first ...
+    float qm = -3.0e38f;
+    int qb = 0x7fffffff;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int k = kq * 8 + j;
-        if (k < K2) l_s[p * 33 + k] = acc[j];
+        if (k < K2) {
+            l_s[p * 33 + k] = acc[j];
+            ce_best(acc[j], k, qm, qb);
+        }
     }
+    q_s[p * 4 + kq] = qm;
+    q_s[SPX_TAIL_PX * 4 + p * 4 + kq] = __int_as_float(qb);
     __syncthreads();
     for (int i = threadIdx.x; i < npx * K2; i += SPX_CE_THREADS) {       // coalesced [px][K2] rows
         const int pp = i / K2, k = i - pp * K2;
         logits[(size_t)m0 * K2 + i] = l_s[pp * 33 + k];
     }
-    if (!labels || threadIdx.x >= SPX_TAIL_PX) return;                      // wave 0: one pixel per lane
+    if (!labels) return;
+    // ... then the pixel's maximum (quarters in class order: the lowest index wins ties) and the quarter's exp sum
+    float mx = -3.0e38f;
+    int best = 0x7fffffff;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) ce_best(q_s[p * 4 + q], __float_as_int(q_s[SPX_TAIL_PX * 4 + p * 4 + q]), mx, best);
+    float qs = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        if (kq * 8 + j < K2) qs += ce_exp(acc[j] - mx);
+    q_s[2 * SPX_TAIL_PX * 4 + p * 4 + kq] = qs;
+    __syncthreads();
+    if (threadIdx.x >= SPX_TAIL_PX) return;                                 // wave 0: one pixel per lane
     const bool in = p < npx;
     const int lab = in ? labels[m0 + p] : -1;
     const bool valid = in && (unsigned)lab < (unsigned)K2;
-    float mx = -3.0e38f;
-    int best = 0x7fffffff;
-    for (int k = 0; k < K2; ++k) ce_best(l_s[p * 33 + k], k, mx, best);
-    float ssum = 0.0f;
-    for (int k = 0; k < K2; ++k) ssum += ce_exp(l_s[p * 33 + k] - mx);
+    const float* const qq = q_s + 2 * SPX_TAIL_PX * 4 + p * 4;
+    const float ssum = ((qq[0] + qq[1]) + qq[2]) + qq[3];
     const float lse = mx + ce_log(ssum);
     if (in) {
         lse_out[m0 + p] = lse;
@@ -172,13 +239,17 @@ __global__ __launch_bounds__(SPX_CE_THREADS) void spx_group_tail_kernel(const fl
     if (threadIdx.x == 0) {
         partials[(size_t)blockIdx.x * 2] = lossv;
         partials[(size_t)blockIdx.x * 2 + 1] = cnt;
+        // the caller's buffer holds spx_ce_partials_flat(M) pairs (a multiple of 4, at most 3 more than the grid): the
+        // last workgroup clears the rest (no separate memset node in front of the kernel)
+        if (blockIdx.x == gridDim.x - 1)
+            for (unsigned e = gridDim.x; e < ((gridDim.x + 3u) & ~3u); ++e) partials[(size_t)e * 2] = partials[(size_t)e * 2 + 1] = 0.0f;
     }
 }
 size_t spx_group_tail_partials(long long M) { return (size_t)((M + SPX_TAIL_PX - 1) / SPX_TAIL_PX); }
 hipError_t spx_launch_group_tail(const float* parts, int groups, long long M, int U, const float* Wg, int K2, float* gact,
                                  float* logits, const int32_t* labels, float* lse, int32_t* pred, float* partials, hipStream_t s) {
     const unsigned grid = (unsigned)((M + SPX_TAIL_PX - 1) / SPX_TAIL_PX);
-    const size_t lds = ((size_t)K2 * U + (size_t)SPX_TAIL_PX * (U | 1) + SPX_TAIL_PX * 33) * sizeof(float);
+    const size_t lds = ((size_t)32 * U + (size_t)SPX_TAIL_PX * (U | 1) + SPX_TAIL_PX * 33 + 3 * SPX_TAIL_PX * 4) * sizeof(float);
     hipLaunchKernelGGL(spx_group_tail_kernel, dim3(grid), dim3(SPX_CE_THREADS), lds, s, parts, groups, M, U,
                        Wg, K2, gact, logits, labels, lse, pred, partials);
     return hipGetLastError();
@@ -228,14 +299,65 @@ __global__ __launch_bounds__(SPX_CE_THREADS) void spx_pixel_outer_kernel(const f
         if (e < nout) parts[(size_t)blockIdx.x * nout + e] = acc[t];
     }
 }
+// The same product for n1 <= 32, n2 <= 64 (d W_g of the Cityscapes / Pascal grouping tails) on the fp32 matrix pipe:
+// v_mfma_f32_32x32x2_f32 with the PIXEL as k - a wave's k-step is two pixels, its operands the two pixels' rows read straight
+// from memory (adjacent rows: one contiguous piece per instruction), fp32 in, fp32 accumulate (no operand rounding).  The four
+// waves of a workgroup take interleaved pixel pairs; their accumulators are summed through LDS in wave order.
+typedef float spx_f32x16 __attribute__((ext_vector_type(16)));
+#define SPX_OUTER_UNROLL 8
+__global__ __launch_bounds__(SPX_CE_THREADS) void spx_pixel_outer_mfma_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                                            long long M, int n1, int n2, float* __restrict__ parts) {
+    __shared__ float red[4][2][16][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 31, kh = lane >> 5;
+    const long long per = ((M + gridDim.x - 1) / gridDim.x + 31) / 32 * 32;
+    const long long m_begin = (long long)blockIdx.x * per, m_end = m_begin + per < M ? m_begin + per : M;
+    spx_f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.0f;
+    const bool ia = i < n1, ib0 = i < n2, ib1 = 32 + i < n2;
+    for (long long m = m_begin + 2 * wave + kh; m < m_end + kh; m += 8 * SPX_OUTER_UNROLL) {
+        float av[SPX_OUTER_UNROLL], b0[SPX_OUTER_UNROLL], b1[SPX_OUTER_UNROLL];
+#pragma unroll
+        for (int u = 0; u < SPX_OUTER_UNROLL; ++u) {          // every load is issued before the first MFMA
+            const long long px = m + 8 * u;
+            const bool ok = px < m_end;
+            av[u] = (ok && ia) ? a[px * n1 + i] : 0.0f;
+            b0[u] = (ok && ib0) ? b[px * n2 + i] : 0.0f;
+            b1[u] = (ok && ib1) ? b[px * n2 + 32 + i] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < SPX_OUTER_UNROLL; ++u) {
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], b0[u], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], b1[u], acc1, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        red[wave][0][r][lane] = acc0[r];
+        red[wave][1][r][lane] = acc1[r];
+    }
+    __syncthreads();
+    // accumulator register r of lane l: row (r & 3) + 8 (r >> 2) + 4 (l >> 5), column l & 31
+    for (int e = threadIdx.x; e < 2 * 16 * 64; e += SPX_CE_THREADS) {
+        const int blk = e >> 10, r = (e >> 6) & 15, l = e & 63;
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), col = 32 * blk + (l & 31);
+        if (row < n1 && col < n2)
+            parts[(size_t)blockIdx.x * n1 * n2 + row * n2 + col] =
+                ((red[0][blk][r][l] + red[1][blk][r][l]) + red[2][blk][r][l]) + red[3][blk][r][l];
+    }
+}
 int spx_pixel_outer_blocks(long long M) {
-    long long n = (M + 127) / 128;          // a workgroup per 128 pixels (4 LDS tiles) until the chip is well covered
+    long long n = (M + 127) / 128;          // a workgroup per 128 pixels until the chip is well covered
     return (int)(n < 1 ? 1 : (n > 1024 ? 1024 : n));
 }
 hipError_t spx_launch_pixel_outer(const float* a, const float* b, long long M, int n1, int n2, float* out, float* parts, hipStream_t s) {
     const int blocks = spx_pixel_outer_blocks(M);
-    hipLaunchKernelGGL(spx_pixel_outer_kernel, dim3((unsigned)blocks), dim3(SPX_CE_THREADS), (size_t)32 * (n1 + n2) * sizeof(float), s,
-                       a, b, M, n1, n2, parts);
+    if (n1 <= 32 && n2 <= 64)
+        hipLaunchKernelGGL(spx_pixel_outer_mfma_kernel, dim3((unsigned)blocks), dim3(SPX_CE_THREADS), 0, s, a, b, M, n1, n2, parts);
+    else
+        hipLaunchKernelGGL(spx_pixel_outer_kernel, dim3((unsigned)blocks), dim3(SPX_CE_THREADS), (size_t)32 * (n1 + n2) * sizeof(float), s,
+                           a, b, M, n1, n2, parts);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     return spx_launch_sum_groups(parts, (size_t)n1 * n2, blocks, out, s);
