@@ -37,7 +37,7 @@ extern "C" {
 #endif
 
 #define SPX_MAX_PANELS 64   /* (scale, <=192-prototype block) work units per pixel tile */
-#define SPX_ABI_VERSION 14
+#define SPX_ABI_VERSION 15
 
 /* How the prototype bank is cut into MFMA panels.  Filled by spx_make_plan(). */
 typedef struct spx_plan {
@@ -79,6 +79,14 @@ int spx_pack_bank(const spx_plan* plan, const float* bank, void* packed_bank, vo
 /* Re-pack a dense [K, P] head matrix (last_layer.weight, model_multiscale.py:225; or the dense
  * form of the grouping projections) into split-bf16 fragments.  packed_headT may be NULL. */
 int spx_pack_head(const spx_plan* plan, const float* W, void* packed_head, void* packed_headT, void* stream);
+
+/* Everything one forward (+ backward) needs in ONE launch: spx_pack_bank + spx_pack_head (+ spx_pack_group_tail, and then the
+ * head^T in the unit order of spx_pack_headT_units) - the per-step form for training, where every parameter changes between
+ * steps and four small launches cost more than the packing itself.  W / Wg and their outputs may be NULL (no head / no
+ * grouping tail); packed_bankT, packed_headT, packed_tailT NULL = no backward.  Same buffers and sizes as the single calls. */
+int spx_pack_all(const spx_plan* plan, const float* bank, const float* W, const float* Wg, int32_t K2, void* packed_bank,
+                 void* packed_bankT, float* packed_p2, void* packed_head, void* packed_headT, void* packed_tail,
+                 void* packed_tailT, void* stream);
 
 /* Fused forward: distances -> similarity -> linear head.
  * Replaces _scale_l2_convolution + _l2_convolution (model_multiscale.py:255-317),

@@ -15,7 +15,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libspx_hip.so")
 SPX_MAX_PANELS = 64
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 
 class SpxError(RuntimeError):
@@ -70,6 +70,7 @@ SIGNATURES = {
     "spx_packed_headT_bytes": (C.c_size_t, [_PP]),
     "spx_pack_bank": (C.c_int, [_PP, _V, _V, _V, _V, _V]),
     "spx_pack_head": (C.c_int, [_PP, _V, _V, _V, _V]),
+    "spx_pack_all": (C.c_int, [_PP, _V, _V, _V, _I, _V, _V, _V, _V, _V, _V, _V, _V]),
     "spx_dist_fwd": (C.c_int, [_PP, _V, _I, _I, _I, _V, _V, _V, _V, _V, _V, _F, _I, _V]),
     "spx_dist_bwd": (C.c_int, [_PP, _V, _I, _I, _I, _V, _V, _V, _V, _V, _V, _V, _V, _V, _V, _V, _F, _I, _V]),
     "spx_dist_fwd_cls": (C.c_int, [_PP, _V, _I, _I, _I, _V, _V, _V, _V, _V, _I, _V, _V, _V, _F, _I, _V]),

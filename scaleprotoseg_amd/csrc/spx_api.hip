@@ -184,6 +184,24 @@ int spx_pack_head(const spx_plan* pl, const float* W, void* ph, void* phT, void*
 
 size_t spx_packed_tail_bytes(const spx_plan* pl) { return (size_t)pl->ncb * 2 * 2048; }
 
+int spx_pack_all(const spx_plan* pl, const float* bank, const float* W, const float* Wg, int32_t K2, void* packed_bank,
+                 void* packed_bankT, float* p2, void* packed_head, void* packed_headT, void* packed_tail, void* packed_tailT,
+                 void* stream) {
+    if (check_plan(pl)) return 1;
+    if (!bank || !packed_bank || !p2) return fail("spx_pack_all: NULL bank buffer");
+    if ((packed_head || packed_headT) && !W) return fail("spx_pack_all: head outputs without a head");
+    if (packed_headT && !packed_head) return fail("spx_pack_all: packed_headT without packed_head");
+    if ((packed_tail || packed_tailT) && (!Wg || !W || !packed_tail)) return fail("spx_pack_all: tail outputs need W, Wg and packed_tail");
+    if (packed_tail && (K2 < 1 || K2 > 32)) return fail("spx_pack_all: %d tail classes (the fused tail carries at most 32)", K2);
+    SpxPackAllArgs a{};
+    a.plan = *pl;
+    a.bank = bank; a.W = W; a.Wg = Wg; a.K2 = K2;
+    a.headT_units = packed_tail != nullptr;      // the grouping backward reads head^T in accumulator (unit) order
+    a.packed_bank = packed_bank; a.packed_bankT = packed_bankT; a.p2 = p2;
+    a.packed_head = packed_head; a.packed_headT = packed_headT; a.packed_tail = packed_tail; a.packed_tailT = packed_tailT;
+    return hip_status(spx_launch_pack_all(a, (hipStream_t)stream), "spx_pack_all");
+}
+
 int spx_pack_group_tail(const spx_plan* pl, const float* Wg, int32_t K2, void* packed_tail, void* packed_tailT, void* stream) {
     if (check_plan(pl)) return 1;
     if (!Wg || !packed_tail) return fail("spx_pack_group_tail: NULL buffer");

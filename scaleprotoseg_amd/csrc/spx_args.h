@@ -115,6 +115,19 @@ hipError_t spx_launch_pack_bank(const spx_plan& pl, const float* bank, void* pb,
 hipError_t spx_launch_pack_head(const spx_plan& pl, const float* W, void* ph, void* phT, hipStream_t s);
 hipError_t spx_launch_pack_tail(const spx_plan& pl, const float* Wg, int K2, void* pt, void* ptT, hipStream_t s);
 hipError_t spx_launch_pack_headT_units(const spx_plan& pl, const float* W, void* phT, hipStream_t s);
+// every operand of one forward (+ backward) in one launch (spx_pack_all); the nb_* workgroup ranges are filled by the launcher
+struct SpxPackAllArgs {
+    spx_plan plan;
+    const float* bank;
+    const float* W;            // head [K, P] or NULL
+    const float* Wg;           // group tail [K2, K] or NULL
+    int K2, headT_units;       // headT_units: head^T with the unit index in accumulator order (grouping backward)
+    void *packed_bank, *packed_bankT;
+    float* p2;
+    void *packed_head, *packed_headT, *packed_tail, *packed_tailT;
+    int nb_bank, nb_head, nb_headT;
+};
+hipError_t spx_launch_pack_all(SpxPackAllArgs a, hipStream_t s);
 hipError_t spx_launch_push_argmin(const float* dist, const int32_t* labels, const float* ident, int B, int P, int K,
                                   int HW, int void_class, float max_dist, int64_t* idx, float* val,
                                   uint64_t* scratch, hipStream_t s);

@@ -342,21 +342,21 @@ class _Packs:
         self.bank = torch.empty(lib.spx_packed_bank_bytes(pp), **u8)
         self.bankT = torch.empty(lib.spx_packed_bankT_bytes(pp), **u8) if need_bwd else None
         self.p2 = torch.empty(lib.spx_packed_p2_bytes(pp) // 4, dtype=torch.float32, device=dev)
-        s = _lib.stream_ptr()
-        _lib.check(lib.spx_pack_bank(pp, _lib.ptr(bank2d), _lib.ptr(self.bank), _lib.ptr(self.bankT), _lib.ptr(self.p2), s))
-        self.head = self.headT = None
+        self.head = self.headT = self.tail = self.tailT = None
         if head is not None:
             self.head = torch.empty(lib.spx_packed_head_bytes(pp), **u8)
             self.headT = torch.empty(lib.spx_packed_headT_bytes(pp), **u8) if need_bwd else None
-            _lib.check(lib.spx_pack_head(pp, _lib.ptr(head), _lib.ptr(self.head), _lib.ptr(self.headT), s))
-        self.tail = self.tailT = None
         if tail is not None:
             # grouping-head tail: W_g fragments; the backward takes head^T with the unit index in accumulator order
             self.tail = torch.empty(lib.spx_packed_tail_bytes(pp), **u8)
             self.tailT = torch.empty(lib.spx_packed_tail_bytes(pp), **u8) if need_bwd else None
-            _lib.check(lib.spx_pack_group_tail(pp, _lib.ptr(tail), int(tail.shape[0]), _lib.ptr(self.tail), _lib.ptr(self.tailT), s))
-            if need_bwd:
-                _lib.check(lib.spx_pack_headT_units(pp, _lib.ptr(head), _lib.ptr(self.headT), s))
+        _lib.check(
+            lib.spx_pack_all(
+                pp, _lib.ptr(bank2d), _lib.ptr(head), _lib.ptr(tail), int(tail.shape[0]) if tail is not None else 0,
+                _lib.ptr(self.bank), _lib.ptr(self.bankT), _lib.ptr(self.p2), _lib.ptr(self.head), _lib.ptr(self.headT),
+                _lib.ptr(self.tail), _lib.ptr(self.tailT), _lib.stream_ptr(),
+            )
+        )
 
 
 # ---- pack cache: the MFMA-ordered operands depend on the parameters only, so an unchanged bank / head /

@@ -1419,3 +1419,57 @@ def test_features_at_an_unaligned_address(x_dtype, offset):
     _grad_close(gx, dx_ref, "dX", tol=_dx_tol(x_dtype, ranges))
     _grad_close(gp, dp_ref, "dPrototypes")
     _grad_close(gw, dw_ref, "dLastLayer")
+
+
+@pytest.mark.parametrize("P,K,S,Cs,K2", [(190, 19, 1, 256, 0), (228, 57, 4, 64, 19), (1800, 150, 4, 64, 0), (37, 9, 2, 48, 5), (64, 0, 1, 64, 0)])
+def test_pack_all_equals_the_single_pack_calls(P, K, S, Cs, K2):
+    """spx_pack_all (one launch per step) leaves byte for byte what spx_pack_bank / spx_pack_head / spx_pack_group_tail /
+    spx_pack_headT_units leave (include/spx_hip.h); K = 0: no head, K2 = 0: no grouping tail."""
+    import ctypes as C
+    from scaleprotoseg_amd import _lib
+    from scaleprotoseg_amd.functional import BankLayout
+
+    dev = _dev()
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(P + K)
+    per = P // S
+    ranges = tuple((s * per, P if s == S - 1 else (s + 1) * per) for s in range(S))
+    plan = BankLayout(P, max(K, 1), S, Cs, ranges).plan()
+    pp = C.byref(plan)
+    bank = torch.rand(P, Cs, generator=g).to(dev)
+    W = torch.randn(K, P, generator=g).to(dev) if K else None
+    Wg = torch.randn(K2, K, generator=g).to(dev) if K2 else None
+    s = _lib.stream_ptr()
+
+    def bufs():
+        u8 = dict(dtype=torch.uint8, device=dev)
+        mk = lambda n: torch.full((n,), 0xA5, **u8)
+        out = dict(bank=mk(lib.spx_packed_bank_bytes(pp)), bankT=mk(lib.spx_packed_bankT_bytes(pp)), p2=mk(lib.spx_packed_p2_bytes(pp)))
+        if K:
+            out.update(head=mk(lib.spx_packed_head_bytes(pp)), headT=mk(lib.spx_packed_headT_bytes(pp)))
+        if K2:
+            out.update(tail=mk(lib.spx_packed_tail_bytes(pp)), tailT=mk(lib.spx_packed_tail_bytes(pp)))
+        return out
+
+    a, b = bufs(), bufs()
+    _lib.check(lib.spx_pack_bank(pp, _lib.ptr(bank), _lib.ptr(a["bank"]), _lib.ptr(a["bankT"]), _lib.ptr(a["p2"]), s))
+    if K:
+        _lib.check(lib.spx_pack_head(pp, _lib.ptr(W), _lib.ptr(a["head"]), _lib.ptr(a["headT"]), s))
+    if K2:
+        _lib.check(lib.spx_pack_group_tail(pp, _lib.ptr(Wg), K2, _lib.ptr(a["tail"]), _lib.ptr(a["tailT"]), s))
+        _lib.check(lib.spx_pack_headT_units(pp, _lib.ptr(W), _lib.ptr(a["headT"]), s))
+    _lib.check(lib.spx_pack_all(pp, _lib.ptr(bank), _lib.ptr(W), _lib.ptr(Wg), K2, _lib.ptr(b["bank"]), _lib.ptr(b["bankT"]),
+                                _lib.ptr(b["p2"]), _lib.ptr(b.get("head")), _lib.ptr(b.get("headT")), _lib.ptr(b.get("tail")),
+                                _lib.ptr(b.get("tailT")), s))
+    torch.cuda.synchronize()
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    # forward-only form: the backward operands may be NULL
+    c = bufs()
+    _lib.check(lib.spx_pack_all(pp, _lib.ptr(bank), _lib.ptr(W), _lib.ptr(Wg), K2, _lib.ptr(c["bank"]), None, _lib.ptr(c["p2"]),
+                                _lib.ptr(c.get("head")), None, _lib.ptr(c.get("tail")), None, s))
+    torch.cuda.synchronize()
+    for k in ("bank", "p2", "head", "tail"):
+        if k in c:
+            assert torch.equal(a[k], c[k]), k
+    assert bool((c["bankT"] == 0xA5).all())
