@@ -254,6 +254,17 @@ int spx_dist_bwd_group_ce(const spx_plan* plan, const void* x, int32_t x_dtype, 
  * d_W_g = d_logits^T . g is a [K2, U] product left to the caller.
  * spx_exp / spx_exp_bwd: y = exp(x) and dx = g * y over n fp32 elements - the same g for heads the fused kernels do not
  * carry, and for compute_group() on activations that did not come out of the fused forward. */
+/* Dense [U, P] head matrix of the grouping head from the per-class projection weights (group_projection[j].weight [g_j, n_j],
+ * segmentation/model/model_multiscale_group.py:249-269): out[u][p] = W_j[row_local[u]][col_local[p]] where row_block[u] ==
+ * col_block[p] == j, 0 elsewhere (one launch; every element written).  block_ptrs / block_cols: HOST arrays of nblocks (<= 192)
+ * DEVICE pointers / column counts n_j; row_block, row_local [U] and col_block, col_local [P]: device int32 tables (block -1 =
+ * belongs to no class present).  spx_group_dense_bwd: the adjoint - d_flat[i] = d_out[flat_row[i]][flat_col[i]] for the n weight
+ * elements in block order (the caller hands out views of d_flat as the weights' gradients). */
+int spx_group_dense(const float* const* block_ptrs, const int32_t* block_cols, int32_t nblocks, const int32_t* row_block,
+                    const int32_t* row_local, const int32_t* col_block, const int32_t* col_local, int32_t U, int32_t P, float* out,
+                    void* stream);
+int spx_group_dense_bwd(const float* d_out, const int32_t* flat_row, const int32_t* flat_col, int64_t n, int32_t P, float* d_flat,
+                        void* stream);
 size_t spx_packed_tail_bytes(const spx_plan* plan);
 int spx_pack_group_tail(const spx_plan* plan, const float* Wg, int32_t K2, void* packed_tail, void* packed_tailT,
                         void* stream);

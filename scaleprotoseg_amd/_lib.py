@@ -75,6 +75,8 @@ SIGNATURES = {
     "spx_dist_bwd": (C.c_int, [_PP, _V, _I, _I, _I, _V, _V, _V, _V, _V, _V, _V, _V, _V, _V, _V, _F, _I, _V]),
     "spx_dist_fwd_cls": (C.c_int, [_PP, _V, _I, _I, _I, _V, _V, _V, _V, _V, _I, _V, _V, _V, _F, _I, _V]),
     "spx_dist_bwd_cls": (C.c_int, [_PP, _V, _I, _I, _I, _V, _V, _V, _V, _V, _V, _I, _V, _V, _V, _V, _V, _V, _V, _F, _I, _V]),
+    "spx_group_dense": (C.c_int, [_V, _V, _I, _V, _V, _V, _V, _I, _I, _V, _V]),
+    "spx_group_dense_bwd": (C.c_int, [_V, _V, _V, C.c_int64, _I, _V, _V]),
     "spx_packed_tail_bytes": (C.c_size_t, [_PP]),
     "spx_pack_group_tail": (C.c_int, [_PP, _V, _I, _V, _V, _V]),
     "spx_pack_headT_units": (C.c_int, [_PP, _V, _V, _V]),

@@ -565,6 +565,29 @@ int spx_exp_bwd(const float* g, const float* y, float* dx, int64_t n, void* stre
     return hip_status(spx_launch_exp(nullptr, g, y, dx, n, (hipStream_t)stream), "spx_exp_bwd");
 }
 
+int spx_group_dense(const float* const* block_ptrs, const int32_t* block_cols, int32_t nblocks, const int32_t* row_block,
+                    const int32_t* row_local, const int32_t* col_block, const int32_t* col_local, int32_t U, int32_t P, float* out,
+                    void* stream) {
+    if (!block_ptrs || !block_cols || !row_block || !row_local || !col_block || !col_local || !out) return fail("spx_group_dense: NULL buffer");
+    if (nblocks < 1 || nblocks > SPX_GROUP_BLOCKS_MAX) return fail("spx_group_dense: %d blocks (1..%d)", nblocks, SPX_GROUP_BLOCKS_MAX);
+    if (U < 1 || P < 1 || (long long)U * P > 0x7fffffffLL) return fail("spx_group_dense: bad sizes (U=%d P=%d)", U, P);
+    SpxGroupDenseArgs a{};
+    for (int j = 0; j < nblocks; ++j) {
+        if (!block_ptrs[j] || block_cols[j] < 1) return fail("spx_group_dense: block %d is empty", j);
+        a.ptrs[j] = block_ptrs[j];
+        a.ncols[j] = block_cols[j];
+    }
+    a.row_block = row_block; a.row_local = row_local; a.col_block = col_block; a.col_local = col_local;
+    a.U = U; a.P = P; a.out = out;
+    return hip_status(spx_launch_group_dense(a, (hipStream_t)stream), "spx_group_dense");
+}
+int spx_group_dense_bwd(const float* d_out, const int32_t* flat_row, const int32_t* flat_col, int64_t n, int32_t P, float* d_flat,
+                        void* stream) {
+    if (!d_out || !flat_row || !flat_col || !d_flat) return fail("spx_group_dense_bwd: NULL buffer");
+    if (n < 1 || P < 1 || (n + 255) / 256 > 0x7fffffffLL) return fail("spx_group_dense_bwd: bad sizes");
+    return hip_status(spx_launch_group_dense_bwd(d_out, flat_row, flat_col, n, P, d_flat, (hipStream_t)stream), "spx_group_dense_bwd");
+}
+
 int spx_ce_fwd(const float* logits, const int32_t* labels, int64_t M, int32_t K, float* lse, int32_t* pred, float* partials,
                void* stream) {
     if (!logits || !labels || !lse || !partials) return fail("spx_ce_fwd: NULL buffer");

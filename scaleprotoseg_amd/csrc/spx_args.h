@@ -128,6 +128,18 @@ struct SpxPackAllArgs {
     int nb_bank, nb_head, nb_headT;
 };
 hipError_t spx_launch_pack_all(SpxPackAllArgs a, hipStream_t s);
+// dense form of the per-class group projections (spx_group_dense)
+#define SPX_GROUP_BLOCKS_MAX 192
+struct SpxGroupDenseArgs {
+    const float* ptrs[SPX_GROUP_BLOCKS_MAX];     // device pointer of every block's weight [g_j, n_j]
+    int ncols[SPX_GROUP_BLOCKS_MAX];             // n_j
+    const int32_t *row_block, *row_local, *col_block, *col_local;
+    int U, P;
+    float* out;
+};
+hipError_t spx_launch_group_dense(const SpxGroupDenseArgs& a, hipStream_t s);
+hipError_t spx_launch_group_dense_bwd(const float* d_out, const int32_t* rows, const int32_t* cols, long long n, int P, float* d_flat,
+                                      hipStream_t s);
 hipError_t spx_launch_push_argmin(const float* dist, const int32_t* labels, const float* ident, int B, int P, int K,
                                   int HW, int void_class, float max_dist, int64_t* idx, float* val,
                                   uint64_t* scratch, hipStream_t s);

@@ -390,3 +390,36 @@ hipError_t spx_launch_exp(const float* x, const float* g, const float* y, float*
     hipLaunchKernelGGL(spx_exp_kernel, dim3((unsigned)((n + SPX_CE_THREADS - 1) / SPX_CE_THREADS)), dim3(SPX_CE_THREADS), 0, s, x, g, y, out, n);
     return hipGetLastError();
 }
+
+// Dense [U, P] form of the per-class group projections (segmentation/model/model_multiscale_group.py:249-269, :283-303: class
+// j's weight [g_j, n_j] acts on the prototypes of class j): out[u][p] = W_j[row_local(u)][col_local(p)] where unit u and prototype
+// p belong to the same block j, 0 elsewhere.  Every element is written (no zero fill, no concatenation of the weights first:
+// torch's zeros + cat + index_put were three launches per step); the block pointers travel in the kernel arguments.
+__global__ __launch_bounds__(SPX_CE_THREADS) void spx_group_dense_kernel(const SpxGroupDenseArgs a) {
+    const int i = blockIdx.x * SPX_CE_THREADS + threadIdx.x;
+    if (i >= a.U * a.P) return;
+    const int u = i / a.P, p = i - u * a.P;
+    const int jb = a.row_block[u];
+    const bool ok = jb >= 0 && jb == a.col_block[p];
+    const int j = ok ? jb : 0;
+    const float v = a.ptrs[j][ok ? a.row_local[u] * a.ncols[j] + a.col_local[p] : 0];
+    a.out[i] = ok ? v : 0.0f;
+}
+hipError_t spx_launch_group_dense(const SpxGroupDenseArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(spx_group_dense_kernel, dim3((unsigned)((a.U * a.P + SPX_CE_THREADS - 1) / SPX_CE_THREADS)), dim3(SPX_CE_THREADS), 0, s, a);
+    return hipGetLastError();
+}
+// its adjoint: the weights' gradients, flat in block order, gathered from d_out at the (row, col) of every weight element
+__global__ __launch_bounds__(SPX_CE_THREADS) void spx_group_dense_bwd_kernel(const float* __restrict__ d_out, const int32_t* __restrict__ rows,
+                                                                           const int32_t* __restrict__ cols, long long n, int P,
+                                                                           float* __restrict__ d_flat) {
+    const long long i = (long long)blockIdx.x * SPX_CE_THREADS + threadIdx.x;
+    if (i >= n) return;
+    d_flat[i] = d_out[(size_t)rows[i] * P + cols[i]];
+}
+hipError_t spx_launch_group_dense_bwd(const float* d_out, const int32_t* rows, const int32_t* cols, long long n, int P, float* d_flat,
+                                      hipStream_t s) {
+    hipLaunchKernelGGL(spx_group_dense_bwd_kernel, dim3((unsigned)((n + SPX_CE_THREADS - 1) / SPX_CE_THREADS)), dim3(SPX_CE_THREADS), 0, s,
+                       d_out, rows, cols, n, P, d_flat);
+    return hipGetLastError();
+}

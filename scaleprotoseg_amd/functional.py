@@ -312,6 +312,64 @@ class _ExpFn(torch.autograd.Function):
         return dx
 
 
+def shifted_labels_i32(labels: torch.Tensor, device) -> torch.Tensor:
+    """labels - 1 as contiguous int32 on ``device`` (the kernels' class index: 0 = void becomes -1, loss.py:32) in ONE elementwise
+    launch for signed integer labels already on the device (``.to(int32)`` followed by ``- 1`` are two)."""
+    if labels.device == torch.device(device) and labels.dtype in (torch.int64, torch.int32, torch.int16, torch.int8):
+        out = torch.empty(labels.shape, dtype=torch.int32, device=labels.device)
+        return torch.sub(labels, 1, out=out)
+    return (labels.to(device=device, dtype=torch.int32) - 1).contiguous()
+
+
+class GroupTables:
+    """Device index tables of the dense [U, P] form of the per-class group projections (one per module and device; built by
+    ``PPNetMultiScale._group_index``): which block (class present) a unit row / prototype column belongs to and where, and the
+    (row, col) of every weight element in block order."""
+
+    def __init__(self, row_block, row_local, col_block, col_local, flat_row, flat_col, block_cols, U, P):
+        self.row_block, self.row_local, self.col_block, self.col_local = row_block, row_local, col_block, col_local
+        self.flat_row, self.flat_col, self.block_cols, self.U, self.P = flat_row, flat_col, list(block_cols), int(U), int(P)
+        self.c_cols = (C.c_int32 * len(self.block_cols))(*self.block_cols)
+
+
+class _GroupDenseFn(torch.autograd.Function):
+    """Wd [U, P] from the group_projection weights in one launch (spx_group_dense); backward: one gather (spx_group_dense_bwd),
+    the weights' gradients are views of its flat output (segmentation/model/model_multiscale_group.py:283-303 in dense form)."""
+
+    @staticmethod
+    def forward(ctx, tables, *weights):
+        lib = _lib.load()
+        ws = [w.detach().contiguous().float() for w in weights]
+        if len(ws) != len(tables.block_cols) or any(int(w.shape[1]) != n for w, n in zip(ws, tables.block_cols)):
+            raise SpxError("group_dense: the weights do not match the index tables")
+        ptrs = (C.c_void_p * len(ws))(*[w.data_ptr() for w in ws])
+        out = torch.empty((tables.U, tables.P), dtype=torch.float32, device=ws[0].device)
+        _lib.check(lib.spx_group_dense(ptrs, tables.c_cols, len(ws), _lib.ptr(tables.row_block), _lib.ptr(tables.row_local),
+                                       _lib.ptr(tables.col_block), _lib.ptr(tables.col_local), tables.U, tables.P, _lib.ptr(out),
+                                       _lib.stream_ptr()))
+        ctx.tables, ctx.shapes = tables, [tuple(w.shape) for w in weights]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        t = ctx.tables
+        g = g.contiguous().float()
+        n = int(t.flat_row.numel())
+        d_flat = torch.empty(n, dtype=torch.float32, device=g.device)
+        _lib.check(lib.spx_group_dense_bwd(_lib.ptr(g), _lib.ptr(t.flat_row), _lib.ptr(t.flat_col), n, t.P, _lib.ptr(d_flat),
+                                           _lib.stream_ptr()))
+        parts = torch.split(d_flat, [a * b for a, b in ctx.shapes])
+        return (None,) + tuple(v.view(sh) for v, sh in zip(parts, ctx.shapes))
+
+
+def group_dense(tables: "GroupTables", weights) -> torch.Tensor:
+    weights = list(weights)
+    if not weights or not weights[0].is_cuda:
+        raise SpxError("scaleprotoseg_amd runs on an AMD GPU only; there is no CPU fallback")
+    return _GroupDenseFn.apply(tables, *weights)
+
+
 def group_exp(units: torch.Tensor) -> torch.Tensor:
     if not units.is_cuda:
         raise SpxError("scaleprotoseg_amd runs on an AMD GPU only; there is no CPU fallback")

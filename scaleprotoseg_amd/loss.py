@@ -78,9 +78,11 @@ class PixelWiseCrossEntropyLoss(nn.Module):
         if predicted_logits.is_cuda:
             from .functional import cross_entropy_from_logits
 
-            labels0 = target_labels.reshape(-1).to(predicted_logits.device) - 1                  # loss.py:32
             ignores_a_class = self.ignore_index is not None and 0 <= self.ignore_index < K
             stale = fused is not None and (fused.target is not target_labels or fused.target_version != target_labels._version)
+            if fused is not None and not stale and not ignores_a_class and not self.return_correct:
+                return fused.loss                       # the epilogue's value: not one more launch here
+            labels0 = target_labels.reshape(-1).to(predicted_logits.device) - 1                  # loss.py:32
             if fused is None or stale or ignores_a_class:
                 lab = labels0 if not ignores_a_class else torch.where(labels0 == self.ignore_index, torch.full_like(labels0, -1), labels0)
                 fused = cross_entropy_from_logits(predicted_logits, lab)

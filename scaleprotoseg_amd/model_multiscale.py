@@ -16,7 +16,7 @@ import torch
 import torch.nn as nn
 
 from .functional import (MAX_FUSED_HEAD_ROWS, BankLayout, ClassGather, SpxError, class_gather_table,
-                         cross_entropy_from_logits, proto_head_forward, wide_linear)
+                         cross_entropy_from_logits, proto_head_forward, shifted_labels_i32, wide_linear)
 from .loss import ClassDistances
 
 
@@ -290,7 +290,7 @@ class PPNetMultiScale(_PrototypeBankMixin, nn.Module):
         if ce_target is not None:
             if tuple(ce_target.shape) != (B, H, W):
                 raise SpxError(f"ce_target must be [{B}, {H}, {W}] (latent grid), got {tuple(ce_target.shape)}")
-            ce_labels = (ce_target.reshape(B, -1).to(device=conv_features.device, dtype=torch.int32) - 1).contiguous()
+            ce_labels = shifted_labels_i32(ce_target.reshape(B, -1), conv_features.device)
         out = proto_head_forward(
             conv_features, self.prototype_vectors, None if wide else self.last_layer.weight, layout,
             want_distances=want_dist and gather is None, want_activations=return_activations or wide,

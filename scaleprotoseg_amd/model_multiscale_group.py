@@ -18,8 +18,8 @@ from typing import Any, List, Optional, Tuple
 import torch
 import torch.nn as nn
 
-from .functional import (MAX_FUSED_HEAD_ROWS, MAX_FUSED_TAIL_CLASSES, SpxError, cross_entropy_from_logits, group_exp,
-                         proto_head_forward, wide_group_tail, wide_linear)
+from .functional import (MAX_FUSED_HEAD_ROWS, MAX_FUSED_TAIL_CLASSES, GroupTables, SpxError, cross_entropy_from_logits,
+                         group_dense, group_exp, proto_head_forward, shifted_labels_i32, wide_group_tail, wide_linear)
 from .model_multiscale import _PrototypeBankMixin, _build_add_on, _first_add_on_channels
 from .utils import projection_simplex_sort
 
@@ -93,13 +93,16 @@ class PPNetMultiScale(_PrototypeBankMixin, nn.Module):
         self._group_index_cache = None
 
     def _group_index(self, device):
-        """(rows, cols) of every group-projection weight inside the dense [NG, P] head matrix."""
+        """(rows, cols, number of units, GroupTables) of every group-projection weight inside the dense [NG, P] head matrix."""
         ident = self.prototype_class_identity
         key = (self._tables_version, ident._version, tuple(gp.weight.shape for gp in self.group_projection), str(device))
         c = self._group_index_cache
         if c is not None and c[0] is ident and c[1] == key:
             return c[2]
+        P = self.num_prototypes
         rows, cols, r0 = [], [], 0
+        col_block, col_local = torch.full((P,), -1, dtype=torch.int32), torch.zeros(P, dtype=torch.int32)
+        row_block, row_local, block_cols = [], [], []
         for j, k in enumerate(self._present_classes()):
             idx = torch.nonzero(ident[:, k]).flatten()
             g = self.group_projection[j].weight.shape[0]
@@ -107,14 +110,27 @@ class PPNetMultiScale(_PrototypeBankMixin, nn.Module):
             cc = idx.repeat(g)
             rows.append(rr)
             cols.append(cc)
+            col_block[idx] = j
+            col_local[idx] = torch.arange(idx.numel(), dtype=torch.int32)
+            row_block += [j] * g
+            row_local += list(range(g))
+            block_cols.append(int(idx.numel()))
             r0 += g
-        out = (torch.cat(rows).to(device), torch.cat(cols).to(device), r0)
+        rows_, cols_ = torch.cat(rows), torch.cat(cols)
+        i32 = lambda t: torch.as_tensor(t, dtype=torch.int32).to(device).contiguous()
+        tables = None
+        if torch.device(device).type == "cuda" and len(block_cols) <= 192:
+            tables = GroupTables(i32(row_block), i32(row_local), i32(col_block), i32(col_local), i32(rows_), i32(cols_),
+                                 block_cols, r0, P)
+        out = (rows_.to(device), cols_.to(device), r0, tables)
         self._group_index_cache = (ident, key, out)
         return out
 
     def _dense_group_matrix(self) -> torch.Tensor:
         dev = self.prototype_vectors.device
-        rows, cols, ng = self._group_index(dev)
+        rows, cols, ng, tables = self._group_index(dev)
+        if tables is not None:
+            return group_dense(tables, [gp.weight for gp in self.group_projection])      # one launch (spx_group_dense)
         vals = torch.cat([gp.weight.reshape(-1) for gp in self.group_projection])
         return torch.zeros(ng, self.num_prototypes, device=dev, dtype=vals.dtype).index_put((rows, cols), vals)
 
@@ -186,7 +202,7 @@ class PPNetMultiScale(_PrototypeBankMixin, nn.Module):
         if ce_target is not None:
             if tuple(ce_target.shape) != (B, H, W):
                 raise SpxError(f"ce_target must be [{B}, {H}, {W}] (latent grid), got {tuple(ce_target.shape)}")
-            ce_labels = (ce_target.reshape(B, -1).to(device=conv_features.device, dtype=torch.int32) - 1).contiguous()
+            ce_labels = shifted_labels_i32(ce_target.reshape(B, -1), conv_features.device)
         if rows <= MAX_FUSED_HEAD_ROWS and k2 <= MAX_FUSED_TAIL_CLASSES:
             # whole grouping head in the kernels: units = act . Wd^T, exp, last_layer_group (:303-308)
             out = proto_head_forward(

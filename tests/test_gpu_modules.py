@@ -973,3 +973,31 @@ def test_group_step_leaves_no_graph_alive():
         torch.cuda.synchronize()
     finally:
         gc.enable()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("P,K,G,drop", [(228, 19, 3, ()), (60, 7, 2, (1, 4)), (1800, 150, 3, ())])
+def test_group_dense_matrix_kernel_matches_index_put(P, K, G, drop):
+    """spx_group_dense / spx_group_dense_bwd (the dense [U, P] form of the per-class group projections in one launch each,
+    model_multiscale_group.py:249-269) against torch's zeros + cat + index_put and its autograd; classes in ``drop`` own no
+    prototype (pruned away): their columns / rows do not exist."""
+    from scaleprotoseg_amd.model_multiscale_group import PPNetMultiScale as GroupNet
+
+    dev = torch.device("cuda:0")
+    torch.manual_seed(P + K)
+    net = GroupNet(_Backbone(64), 64, (P, 16, 1, 1), [], K, add_on_layers_type="deeplab_simple", patch_classification=True,
+                   num_scales=4, num_groups=G).to(dev)
+    if drop:
+        keep = [p for p in range(P) if int(net.prototype_class_identity[p].argmax()) not in drop]
+        net.prune_prototypes([p for p in range(P) if p not in keep])
+    rows, cols, ng, tables = net._group_index(dev)
+    assert tables is not None
+    ws = [gp.weight for gp in net.group_projection]
+    wd = net._dense_group_matrix()
+    ref = torch.zeros(ng, net.num_prototypes, device=dev).index_put((rows, cols), torch.cat([w.reshape(-1) for w in ws]))
+    assert torch.equal(wd, ref)
+    g = torch.randn_like(wd)
+    got = torch.autograd.grad(wd, ws, g)
+    want = torch.autograd.grad(ref, ws, g)
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)

@@ -269,7 +269,7 @@ def test_table_caches_follow_in_place_edits_and_reassignment():
 
     net = GroupNet(_Backbone(32), 64, (12, 8, 1, 1), [], 3, add_on_layers_type="deeplab_simple",
                    patch_classification=True, num_scales=4, num_groups=2)
-    r0, c0, n0 = net._group_index("cpu")
+    r0, c0, n0, _ = net._group_index("cpu")
     assert net._group_index("cpu")[0] is r0                      # cached
     v = net._tables_version
     net.prototype_class_identity = net.prototype_class_identity.clone()
@@ -278,7 +278,7 @@ def test_table_caches_follow_in_place_edits_and_reassignment():
     r1 = net._group_index("cpu")[0]
     net.prototype_class_identity[0, 0] = 0                       # in-place edit: tensor version moves
     net.prototype_class_identity[0, 1] = 1
-    r2, c2, _ = net._group_index("cpu")
+    r2, c2, _, _ = net._group_index("cpu")
     assert r2 is not r1 and not torch.equal(c2, c0)
 
 
