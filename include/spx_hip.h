@@ -200,6 +200,11 @@ int spx_ce_fwd(const float* logits, const int32_t* labels, int64_t M, int32_t K,
                float* partials, void* stream);
 int spx_ce_bwd(const float* logits, const float* lse, const int32_t* labels, const float* coef, int64_t M, int32_t K,
                float* d_logits, void* stream);
+/* mean loss -> loss[0], (count, loss sum) -> count_sum[0..1] from the (sum, count) partial pairs the cross-entropy kernels leave
+ * (spx_ce_fwd / the fused epilogues / the grouping tail): one launch, fixed summation order; 0 / 0 = nan as torch's mean over
+ * no pixel (loss.py:36-40).  spx_shift_labels: out = labels - 1 as int32 (loss.py:32) from int64 (is_int64 = 1) or int32 labels. */
+int spx_ce_finish(const float* partials, int64_t n_pairs, float* loss, float* count_sum, void* stream);
+int spx_shift_labels(const void* labels, int32_t is_int64, int64_t n, int32_t* out, void* stream);
 
 /* out [n1, n2] = a^T . b for tall-skinny fp32 operands a [M, n1], b [M, n2] with n1 * n2 <= 8192: the d W_g = d_logits^T . g
  * product of the grouping tail (segmentation/model/model_multiscale_group.py:305-308 through autograd) and its relatives.

@@ -111,6 +111,8 @@ SIGNATURES = {
     "spx_rows_gemm": (C.c_int, [_V, C.c_int64, C.c_int64, _V, C.c_int64, C.c_int64, _V, C.c_int64, _I, _I, _I, _I, _V, C.c_int64, _V, _V]),
     "spx_ce_partials": (C.c_size_t, [_I, _I]),
     "spx_ce_partials_flat": (C.c_size_t, [C.c_int64]),
+    "spx_ce_finish": (C.c_int, [_V, C.c_int64, _V, _V, _V]),
+    "spx_shift_labels": (C.c_int, [_V, _I, C.c_int64, _V, _V]),
     "spx_dist_fwd_ce": (C.c_int, [_PP, _V, _I, _I, _I, _V, _V, _V, _V, _V, _I, _V, _V, _V, _V, _PCE, _F, _I, _V]),
     "spx_dist_bwd_ce": (C.c_int, [_PP, _V, _I, _I, _I, _V, _V, _V, _V, _V, _V, _I, _V, _V, _V, _PCE, _V, _V, _V, _V, _F, _I, _V]),
     "spx_ce_fwd": (C.c_int, [_V, _V, C.c_int64, _I, _V, _V, _V, _V]),

@@ -594,6 +594,14 @@ int spx_ce_fwd(const float* logits, const int32_t* labels, int64_t M, int32_t K,
     if (M < 1 || K < 1 || (M + 255) / 256 > 0x7fffffffLL) return fail("spx_ce_fwd: bad sizes (M=%lld K=%d)", (long long)M, K);
     return hip_status(spx_launch_ce_fwd(logits, labels, M, K, lse, pred, partials, (hipStream_t)stream), "spx_ce_fwd");
 }
+int spx_ce_finish(const float* partials, int64_t n_pairs, float* loss, float* count_sum, void* stream) {
+    if (!partials || !loss || !count_sum || n_pairs < 1) return fail("spx_ce_finish: bad arguments");
+    return hip_status(spx_launch_ce_finish(partials, n_pairs, loss, count_sum, (hipStream_t)stream), "spx_ce_finish");
+}
+int spx_shift_labels(const void* labels, int32_t is_int64, int64_t n, int32_t* out, void* stream) {
+    if (!labels || !out || n < 1 || (n + 255) / 256 > 0x7fffffffLL) return fail("spx_shift_labels: bad arguments");
+    return hip_status(spx_launch_shift_labels(labels, is_int64, n, out, (hipStream_t)stream), "spx_shift_labels");
+}
 int spx_ce_bwd(const float* logits, const float* lse, const int32_t* labels, const float* coef, int64_t M, int32_t K,
                float* d_logits, void* stream) {
     if (!logits || !lse || !labels || !coef || !d_logits) return fail("spx_ce_bwd: NULL buffer");

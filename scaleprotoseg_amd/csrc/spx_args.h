@@ -128,6 +128,8 @@ struct SpxPackAllArgs {
     int nb_bank, nb_head, nb_headT;
 };
 hipError_t spx_launch_pack_all(SpxPackAllArgs a, hipStream_t s);
+hipError_t spx_launch_ce_finish(const float* partials, long long n, float* loss, float* aux, hipStream_t s);
+hipError_t spx_launch_shift_labels(const void* in, int is64, long long n, int32_t* out, hipStream_t s);
 // dense form of the per-class group projections (spx_group_dense)
 #define SPX_GROUP_BLOCKS_MAX 192
 struct SpxGroupDenseArgs {

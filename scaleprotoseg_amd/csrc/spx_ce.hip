@@ -38,6 +38,55 @@ __global__ __launch_bounds__(SPX_CE_THREADS) void spx_ce_fwd_kernel(const float*
     }
 }
 
+// mean loss -> loss[0], (count, loss sum) -> aux[0..1] from the kernels' (sum, count) partial pairs: one workgroup, a fixed summation order (thread-strided
+// pairs, wave butterfly, waves in order) - the reduce + divide pair of torch launches as one; 0 / 0 = nan as torch's mean
+__global__ __launch_bounds__(SPX_CE_THREADS) void spx_ce_finish_kernel(const float* __restrict__ partials, long long n, float* __restrict__ loss, float* __restrict__ aux) {
+    __shared__ float red[2][SPX_CE_THREADS / 64];
+    float s0 = 0.0f, s1 = 0.0f, c0 = 0.0f, c1 = 0.0f;
+    long long i = threadIdx.x;
+    for (; i + SPX_CE_THREADS < n; i += 2 * SPX_CE_THREADS) {
+        const float2 a = ((const float2*)partials)[i], b = ((const float2*)partials)[i + SPX_CE_THREADS];
+        s0 += a.x; c0 += a.y; s1 += b.x; c1 += b.y;
+    }
+    if (i < n) {
+        const float2 a = ((const float2*)partials)[i];
+        s0 += a.x; c0 += a.y;
+    }
+    float sv = s0 + s1, cv = c0 + c1;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        sv += __shfl_xor(sv, off);
+        cv += __shfl_xor(cv, off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = sv;
+        red[1][threadIdx.x >> 6] = cv;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float st = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3], ct = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
+        loss[0] = st / ct;
+        aux[0] = ct;
+        aux[1] = st;
+    }
+}
+hipError_t spx_launch_ce_finish(const float* partials, long long n, float* loss, float* aux, hipStream_t s) {
+    hipLaunchKernelGGL(spx_ce_finish_kernel, dim3(1), dim3(SPX_CE_THREADS), 0, s, partials, n, loss, aux);
+    return hipGetLastError();
+}
+// labels - 1 as int32 (loss.py:32: 0 = void becomes -1) from int64 / int32 labels: one launch
+__global__ __launch_bounds__(SPX_CE_THREADS) void spx_shift_labels_kernel(const void* __restrict__ in, int is64, long long n, int32_t* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * SPX_CE_THREADS + threadIdx.x;
+    if (i >= n) return;
+    const long long v = is64 ? ((const long long*)in)[i] : (long long)((const int32_t*)in)[i];
+    const long long w = v - 1;
+    out[i] = (w < -2147483647LL || w > 2147483647LL) ? -1 : (int32_t)w;       // anything outside int32 is no class
+}
+hipError_t spx_launch_shift_labels(const void* in, int is64, long long n, int32_t* out, hipStream_t s) {
+    hipLaunchKernelGGL(spx_shift_labels_kernel, dim3((unsigned)((n + SPX_CE_THREADS - 1) / SPX_CE_THREADS)), dim3(SPX_CE_THREADS), 0, s, in, is64, n, out);
+    return hipGetLastError();
+}
+
 // d_logits[m, k] = coef * (softmax - onehot) on the non-ignored pixels, 0 elsewhere
 __global__ __launch_bounds__(SPX_CE_THREADS) void spx_ce_bwd_kernel(const float* __restrict__ logits, const float* __restrict__ lse,
                                                                   const int32_t* __restrict__ labels, const float* __restrict__ coef,

@@ -111,17 +111,17 @@ class _CrossEntropyFn(torch.autograd.Function):
         pred = torch.empty((M,), dtype=torch.int32, device=lg.device)
         partials = torch.empty((lib.spx_ce_partials_flat(M), 2), dtype=torch.float32, device=lg.device)
         _lib.check(lib.spx_ce_fwd(_lib.ptr(lg), _lib.ptr(lab), M, K, _lib.ptr(lse), _lib.ptr(pred), _lib.ptr(partials), _lib.stream_ptr()))
-        tot = partials.sum(dim=0)
+        loss, tot = _ce_finish(partials)                             # mean, (count, sum)
         ctx.save_for_backward(lg, lse, lab, tot)
         ctx.shape = tuple(logits.shape)
         ctx.mark_non_differentiable(pred, lab)
-        return tot[0] / tot[1], pred, lab
+        return loss, pred, lab
 
     @staticmethod
     def backward(ctx, g_loss, _g_pred=None, _g_lab=None):
         lib = _lib.load()
         lg, lse, lab, tot = ctx.saved_tensors
-        coef = (g_loss.float() / tot[1]).reshape(1).contiguous()
+        coef = (g_loss.float() / tot[0]).reshape(1).contiguous()
         dl = torch.empty_like(lg)
         _lib.check(lib.spx_ce_bwd(_lib.ptr(lg), _lib.ptr(lse), _lib.ptr(lab), _lib.ptr(coef), lg.shape[0], lg.shape[1], _lib.ptr(dl), _lib.stream_ptr()))
         return dl.reshape(ctx.shape), None
@@ -312,12 +312,27 @@ class _ExpFn(torch.autograd.Function):
         return dx
 
 
+def _ce_finish(partials: torch.Tensor) -> torch.Tensor:
+    """(mean loss [], (count, loss sum) [2]) of the kernels' (sum, count) partial pairs in one launch (spx_ce_finish); two
+    allocations: the loss becomes an autograd OUTPUT, the count is kept by the node (never the same storage, see forward())."""
+    lib = _lib.load()
+    loss = torch.empty((), dtype=torch.float32, device=partials.device)
+    aux = torch.empty(2, dtype=torch.float32, device=partials.device)
+    _lib.check(lib.spx_ce_finish(_lib.ptr(partials), int(partials.shape[0]), _lib.ptr(loss), _lib.ptr(aux), _lib.stream_ptr()))
+    return loss, aux
+
+
 def shifted_labels_i32(labels: torch.Tensor, device) -> torch.Tensor:
     """labels - 1 as contiguous int32 on ``device`` (the kernels' class index: 0 = void becomes -1, loss.py:32) in ONE elementwise
-    launch for signed integer labels already on the device (``.to(int32)`` followed by ``- 1`` are two)."""
-    if labels.device == torch.device(device) and labels.dtype in (torch.int64, torch.int32, torch.int16, torch.int8):
+    launch (spx_shift_labels) for int64 / int32 labels already on the device (``.to(int32)`` followed by ``- 1`` are two)."""
+    if labels.is_cuda and labels.device == torch.device(device) and labels.dtype in (torch.int64, torch.int32):
+        lib = _lib.load()
+        labels = labels.contiguous()
         out = torch.empty(labels.shape, dtype=torch.int32, device=labels.device)
-        return torch.sub(labels, 1, out=out)
+        if labels.numel():
+            _lib.check(lib.spx_shift_labels(_lib.ptr(labels), int(labels.dtype == torch.int64), labels.numel(), _lib.ptr(out),
+                                            _lib.stream_ptr()))
+        return out
     return (labels.to(device=device, dtype=torch.int32) - 1).contiguous()
 
 
@@ -592,10 +607,9 @@ class _ProtoHeadFn(torch.autograd.Function):
         ce_loss, ce_pred = x.new_empty(0), x.new_empty(0)
         ctx.ce_state = ctx.ce_count = None
         if ce_state is not None:
-            tot = ce_state[3].sum(dim=0)                          # (sum of the pixel losses, non-ignored pixels): fixed order
-            ce_loss = tot[0] / tot[1]                               # 0 / 0 = nan when every pixel is ignored, as torch's mean
+            ce_loss, tot = _ce_finish(ce_state[3])                # mean (0 / 0 = nan when every pixel is ignored, as torch's), (count, sum)
             ce_pred = ce_state[2]
-            ctx.ce_state, ctx.ce_count = ce_state, tot[1]
+            ctx.ce_state, ctx.ce_count = ce_state, tot[0]
         ctx.mark_non_differentiable(*([o for o, h in zip(outs, ctx.have) if not h] + ([extra] if tail2d is None else []) + [ce_pred]
                                       + ([ce_loss] if ce_state is None else [])))
         return outs + (extra, ce_loss, ce_pred)
