@@ -196,6 +196,200 @@ __global__ __launch_bounds__(256) void spx_gemm_kernel(const SpxGemmArgs a) {
         }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same product on the bf16 matrix pipe at fp32 accuracy ("bf16x3"): every fp32 operand is split into three bf16 planes
+// x = h + m + l (8 + 8 + 8 significant bits = the fp32 mantissa, each plane the round-to-nearest bf16 of the remainder), and
+//     x . y  =  h h' + (h m' + m h') + (h l' + l h' + m m')  (+ m l' + l m' + l l':  <= 2^-23 |x y|, dropped)
+// runs as SIX v_mfma_f32_32x32x16_bf16 per fp32 k-step of 16: 6 x 8 passes against the 8 x 16 passes of
+// v_mfma_f32_32x32x2_f32 over the same k - 2.7x the fp32 pipe's rate with the same fp32 accumulation, the dropped terms
+// below the summation-order noise (tests/test_gpu_gemm.py holds both kernels to the same 2e-6 |A|.|B| bound).
+// Workgroup = 4 waves = 128 x 128 of C (wave: 64 x 64 = 2 x 2 MFMA tiles), k in chunks of 32 (a k-contiguous operand is then
+// fetched in whole 128-B row pieces) through ONE LDS buffer of three bf16 planes per operand (60 KiB: two workgroups per CU):
+//   k-contiguous operand:   [plane][row][32 k] with 80-B rows   - a fragment (row = lane & 31, k = 8 (lane >> 5) + j) is one
+//                           ds_read_b128 (20-dword row stride: the 16 lanes of a read group fall on 16 distinct 16-B slots);
+//   row-contiguous operand: [plane][k][128 rows] with 320-B rows - a thread's 8 consecutive rows are one 16-B write, and
+//                           the fragment comes back through two ds_read_b64_tr_b16 (k becomes the register index; the
+//                           80-dword row stride keeps the four k rows and two column halves of a 32-lane group on distinct banks).
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+#define SPX_G3_TI 128
+#define SPX_G3_TK 32
+#define SPX_G3_KS 80                      // k-contiguous image: row stride in bytes (32 k + 16 B)
+#define SPX_G3_RS 320                     // row-contiguous image: k-row stride in bytes (128 rows + 64 B)
+#define SPX_G3_PLANE 10240                // 128 * 80 = 32 * 320
+#define SPX_G3_OPER (3 * SPX_G3_PLANE)
+
+__device__ __forceinline__ void split3_bf16x8(const float (&r)[8], bf16x8& h, bf16x8& m, bf16x8& l) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const __bf16 a = (__bf16)r[e];
+        const float r1 = r[e] - (float)a;
+        const __bf16 b = (__bf16)r1;
+        h[e] = a;
+        m[e] = b;
+        l[e] = (__bf16)(r1 - (float)b);
+    }
+}
+
+// One operand's chunk: 128 rows x 32 k as two pieces of 256 threads x 8 floats (k-contiguous: 8 k of one row, rows +64 for the
+// second piece;  row-contiguous: 8 rows of one k, k +16), fetched with UNCONDITIONAL 16-B buffer loads: the resource starts at
+// the chunk's first element and ends with the tensor, a lane without a valid element passes an out-of-range offset, and a
+// lane whose window crosses the end of its row range keeps a count of valid elements and zeroes the rest at commit.  (The
+// fp32-pipe kernel's guarded element loads put a vmcnt(0) between the pieces on every ragged tile: eight serial memory round
+// trips per chunk, the 128-tiles of N = 450 ran at a third of the rate of its interior tiles.)
+template <bool KCONT>
+struct SpxGemm3Operand {
+    u32x4 v[2][2];
+    int nval[2];
+    int row, kk;
+    uint32_t voff, pstride;
+    __device__ __forceinline__ void init(int tid, long long rs, long long ks) {
+        if (KCONT) { row = tid >> 2; kk = (tid & 3) * 8; voff = (uint32_t)((row * rs + kk) * 4); pstride = (uint32_t)(64 * rs * 4); }
+        else { kk = tid >> 4; row = (tid & 15) * 8; voff = (uint32_t)((kk * ks + row) * 4); pstride = (uint32_t)(16 * ks * 4); }
+    }
+    __device__ __forceinline__ void load(const float* __restrict__ P, long long rs, long long ks, int r0, int nrows, int K, int k0, int kend) {
+        const long long RS = KCONT ? rs : 1, KS = KCONT ? 1 : ks;
+        const long long total = (long long)(nrows - 1) * RS + (long long)(K - 1) * KS + 1;
+        const long long base = (long long)r0 * RS + (long long)k0 * KS;
+        long long rem = (total - base) * 4;
+        rem = rem < 0 ? 0 : (rem > 0x7FFFFFFFLL ? 0x7FFFFFFFLL : rem);
+        const spx_rsrc rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(rem ? P + base : P), 0, (uint32_t)rem, 0x00020000);
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int gi = r0 + row + (KCONT ? 64 * p : 0), k = k0 + kk + (KCONT ? 0 : 16 * p);
+            int n = KCONT ? kend - k : nrows - gi;
+            n = n < 0 ? 0 : (n > 8 ? 8 : n);
+            if (KCONT ? gi >= nrows : k >= kend) n = 0;
+            const uint32_t off = n ? voff + p * pstride : SPX_OOB;
+            v[p][0] = buf_load_b128(rsrc, off, 0);
+            v[p][1] = buf_load_b128(rsrc, off + 16, 0);
+            nval[p] = n;
+        }
+    }
+    __device__ __forceinline__ void commit(char* __restrict__ img, bool ex) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            float r[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) r[e] = __uint_as_float(v[p][e >> 2][e & 3]);
+            if (ex) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) r[e] = expf(r[e]);
+            }
+            if (__builtin_amdgcn_ballot_w64(nval[p] != 8) != 0) {        // wave-uniform: interior chunks skip the masking
+#pragma unroll
+                for (int e = 0; e < 8; ++e) r[e] = e < nval[p] ? r[e] : 0.0f;
+            }
+            bf16x8 h, m, l;
+            split3_bf16x8(r, h, m, l);
+            // KCONT: 8 k of one row;  else: 8 rows of one k - 16 contiguous bytes of the image either way
+            char* const dst = img + (KCONT ? (row + 64 * p) * SPX_G3_KS + kk * 2 : (kk + 16 * p) * SPX_G3_RS + row * 2);
+            *(bf16x8*)dst = h;
+            *(bf16x8*)(dst + SPX_G3_PLANE) = m;
+            *(bf16x8*)(dst + 2 * SPX_G3_PLANE) = l;
+        }
+    }
+};
+
+// fragment of k-step ks (16 k) of the 32 rows starting at r0 of one plane image
+template <bool KCONT>
+__device__ __forceinline__ bf16x8 g3_frag(const char* __restrict__ plane, int r0, int ks, int lane) {
+    if (KCONT) return *(const bf16x8*)(plane + (r0 + (lane & 31)) * SPX_G3_KS + 32 * ks + 16 * (lane >> 5));
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, pq = i & 3;
+    const char* const p0 = plane + (16 * ks + 8 * (g >> 1) + q) * SPX_G3_RS + (r0 + 16 * (g & 1) + 4 * pq) * 2;
+    const s16x4 lo = lds_tr_read(p0), hi = lds_tr_read(p0 + 4 * SPX_G3_RS);
+    s16x8 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+template <bool AK, bool BK>
+__global__ __launch_bounds__(256, 2) void spx_gemm3_kernel(const SpxGemmArgs a) {
+    constexpr int TI = SPX_G3_TI, TK = SPX_G3_TK;
+    extern __shared__ __attribute__((aligned(16))) char g3_lds[];        // [A | B][plane image]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wi = wave >> 1, wj = wave & 1;
+    const int per = (a.ntiles + 7) / 8;                                    // XCD-aware block -> tile map (see spx_gemm_kernel)
+    const int L = a.linear_map ? (int)blockIdx.x : (int)(blockIdx.x & 7u) * per + (int)(blockIdx.x >> 3);
+    if (L >= a.ntiles || (!a.linear_map && (int)(blockIdx.x >> 3) >= per)) return;
+    const int bj = L % a.nj, bi = (L / a.nj) % a.ni, bz = L / (a.nj * a.ni);
+    const int i0 = bi * TI, j0 = bj * TI;
+    const int kbeg = bz * a.kper;
+    const int kend = (kbeg + a.kper < a.K) ? kbeg + a.kper : a.K;
+    const bool exa = a.flags & 1, exb = a.flags & 2;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int v = 0; v < 2; ++v)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[u][v][r] = 0.0f;
+
+    SpxGemm3Operand<AK> sa;
+    SpxGemm3Operand<BK> sb;
+    sa.init(tid, a.ras, a.kas);
+    sb.init(tid, a.rbs, a.kbs);
+    char* const ia = g3_lds;
+    char* const ib = g3_lds + SPX_G3_OPER;
+    // One LDS buffer, one register set: chunk c + 1 is in flight in registers while chunk c feeds the matrix pipe; the two
+    // workgroups of a CU fill each other's commit phases.  (A second register set - two chunks of lead - measured no faster.)
+    sa.load(a.A, a.ras, a.kas, i0, a.M, a.K, kbeg, kend);
+    sb.load(a.B, a.rbs, a.kbs, j0, a.N, a.K, kbeg, kend);
+    for (int k0 = kbeg; k0 < kend; k0 += TK) {
+        __syncthreads();                     // the previous chunk's fragment reads are done
+        sa.commit(ia, exa);
+        sb.commit(ib, exb);
+        __syncthreads();
+        sa.load(a.A, a.ras, a.kas, i0, a.M, a.K, k0 + TK, kend);       // (a chunk past the end loads nothing)
+        sb.load(a.B, a.rbs, a.kbs, j0, a.N, a.K, k0 + TK, kend);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 fa[2][3], fb[2][3];
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    fa[u][pl] = g3_frag<AK>(ia + pl * SPX_G3_PLANE, (wi * 2 + u) * 32, ks, lane);
+                    fb[u][pl] = g3_frag<BK>(ib + pl * SPX_G3_PLANE, (wj * 2 + u) * 32, ks, lane);
+                }
+            // smallest terms first into the accumulator
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int v = 0; v < 2; ++v) {
+                    f32x16 c = acc[u][v];
+                    c = mfma_bf16(fa[u][2], fb[v][0], c);       // l h'
+                    c = mfma_bf16(fa[u][0], fb[v][2], c);       // h l'
+                    c = mfma_bf16(fa[u][1], fb[v][1], c);       // m m'
+                    c = mfma_bf16(fa[u][1], fb[v][0], c);       // m h'
+                    c = mfma_bf16(fa[u][0], fb[v][1], c);       // h m'
+                    c = mfma_bf16(fa[u][0], fb[v][0], c);       // h h'
+                    acc[u][v] = c;
+                }
+        }
+    }
+
+    float* const out = a.splits > 1 ? a.ws + (size_t)bz * (size_t)a.M * (size_t)a.N : a.C;
+    const long long ldo = a.splits > 1 ? a.N : a.ldc;
+    const bool mulexp = (a.flags & 4) && a.splits == 1;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            const int j = j0 + (wj * 2 + v) * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = i0 + (wi * 2 + u) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (i < a.M && j < a.N) {
+                    float val = acc[u][v][r];
+                    if (mulexp) val *= expf(a.E[(long long)i * a.lde + j]);
+                    out[(long long)i * ldo + j] = val;
+                }
+            }
+        }
+}
+
 // C[i][j] = sum over slabs, in slab order
 __global__ __launch_bounds__(256) void spx_gemm_reduce_kernel(const float* __restrict__ ws, int splits, long long MN, int N, float* __restrict__ C, long long ldc) {
     const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -222,6 +416,23 @@ static SpxGemmPlan spx_gemm_plan(int M, int N, int K, int flags) {
     // the 64-tiles beat the 128-tiles until there are several thousand of them, and a contraction is split (slabs summed in
     // order by a second kernel) until that many workgroups exist, keeping >= 512 k per slab.
     const long long t64 = (long long)((M + 63) / 64) * ((N + 63) / 64);
+    // The bf16x3 kernel (128-tiles) unless its tiles would be mostly padding (N = 150: 1.7x) or there is next to no work.
+    // Splits, from the sweep over the ADE / COCO head shapes (tools/probes/gemm3_sweep.py, profiles/EXPERIMENTS.md): slabs of
+    // ~700 k (a workgroup's fixed cost is worth ~6 chunks of 32), at least ~400 workgroups, and never between one and one and a
+    // half rounds of the 512 workgroup slots (536 workgroups took as long as 268: the last 24 run alone).
+    const long long t128 = (long long)((M + 127) / 128) * ((N + 127) / 128);
+    const double waste = (double)(t128 * 128 * 128) / ((double)M * (double)N);
+    if (waste <= 1.5 && t128 >= 8 && K >= 64) {
+        int sp = 1;
+        if (!(flags & 4)) {
+            sp = (K + 350) / 700;
+            sp = sp < 1 ? 1 : (sp > 16 ? 16 : sp);
+            while (sp < 16 && t128 * sp < 400 && K / (sp + 1) >= 128) ++sp;
+            while (sp < 16 && t128 * sp > 512 && t128 * sp < 800 && K / (sp + 1) >= 128) ++sp;
+        }
+        int kp = ((K + sp - 1) / sp + SPX_G_TK - 1) / SPX_G_TK * SPX_G_TK;
+        return SpxGemmPlan{3, (K + kp - 1) / kp, kp};
+    }
     if (t64 >= 8192) return SpxGemmPlan{2, 1, (K + SPX_G_TK - 1) / SPX_G_TK * SPX_G_TK};
     int sp = 1;
     while (!(flags & 4) && sp < 32 && t64 * sp < 2048 && K / (2 * sp) >= 512) sp *= 2;
@@ -249,6 +460,20 @@ static void spx_launch_gemm_wm(const SpxGemmArgs& a_, bool ak, bool bk, hipStrea
     else hipLaunchKernelGGL((spx_gemm_kernel<false, false, WM>), grid, dim3(256), 0, s, a);
 }
 
+static void spx_launch_gemm3(const SpxGemmArgs& a_, bool ak, bool bk, hipStream_t s) {
+    SpxGemmArgs a = a_;
+    a.ni = (a.M + SPX_G3_TI - 1) / SPX_G3_TI;
+    a.nj = (a.N + SPX_G3_TI - 1) / SPX_G3_TI;
+    a.ntiles = a.ni * a.nj * a.splits;
+    a.linear_map = g_gemm_force_splits < 0;
+    const dim3 grid((unsigned)(((a.ntiles + 7) / 8) * 8));
+    constexpr size_t lds = 2 * SPX_G3_OPER;
+    if (ak && bk) hipLaunchKernelGGL((spx_gemm3_kernel<true, true>), grid, dim3(256), lds, s, a);
+    else if (ak) hipLaunchKernelGGL((spx_gemm3_kernel<true, false>), grid, dim3(256), lds, s, a);
+    else if (bk) hipLaunchKernelGGL((spx_gemm3_kernel<false, true>), grid, dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((spx_gemm3_kernel<false, false>), grid, dim3(256), lds, s, a);
+}
+
 hipError_t spx_launch_gemm(const float* A, long long ras, long long kas, const float* B, long long rbs, long long kbs,
                            float* C, long long ldc, int M, int N, int K, int flags, const float* E, long long lde,
                            float* ws, hipStream_t s) {
@@ -264,7 +489,8 @@ hipError_t spx_launch_gemm(const float* A, long long ras, long long kas, const f
     a.kper = p.kper;
     a.ws = ws;
     const bool ak = kas == 1, bk = kbs == 1;
-    if (p.wm == 2) spx_launch_gemm_wm<2>(a, ak, bk, s);
+    if (p.wm == 3) spx_launch_gemm3(a, ak, bk, s);
+    else if (p.wm == 2) spx_launch_gemm_wm<2>(a, ak, bk, s);
     else spx_launch_gemm_wm<1>(a, ak, bk, s);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;

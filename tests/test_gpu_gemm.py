@@ -1,8 +1,10 @@
-"""GPU parity of the fp32 MFMA product kernels behind the wide heads (csrc/spx_gemm.hip, include/spx_hip.h: spx_rows_gemm):
-the three products of the reference's nn.Linear (segmentation/model/model_multiscale.py:243-244 and its autograd,
+"""GPU parity of the product kernels behind the wide heads (csrc/spx_gemm.hip, include/spx_hip.h: spx_rows_gemm): the three
+products of the reference's nn.Linear (segmentation/model/model_multiscale.py:243-244 and its autograd,
 model_multiscale_group.py:303-308 with the exponential) against float64 on the CPU.
 
-Tolerance: fp32 operands and accumulation, so |C - C_ref| <= 2e-6 * (|A| . |B|) element-wise (summation order only)."""
+Two kernels share the entry point: fp32 MFMAs (small or mostly-padding shapes) and the bf16x3 split (three bf16 planes per
+fp32 operand, six bf16 MFMAs per k-step, fp32 accumulation; the dropped cross terms are <= 2^-23 of a product).  Both are held
+to the SAME bound: |C - C_ref| <= 2e-6 * (|A| . |B|) element-wise - fp32 operands and accumulation up to summation order."""
 import pytest
 import torch
 
@@ -39,6 +41,10 @@ SHAPES = [
     (127, 129, 17),
     (256, 128, 16),
     (300, 33, 1030),
+    # shapes the bf16x3 kernel takes (>= 8 tiles of 128 x 128, little padding):
+    (1000, 300, 203),      # ragged k (203 = 8 * 25 + 3), ragged rows and columns
+    (640, 384, 1030),      # whole tiles, k % 8 = 6, split into 8 slabs
+    (1290, 520, 64),       # one chunk pair only
 ]
 
 
@@ -85,6 +91,30 @@ def test_wide_group_tail_forward_backward():
     dev = _dev()
     M, U, K2 = 333, 150, 50
     g = torch.Generator().manual_seed(4)
+    units = torch.randn(M, U, generator=g)
+    wg = torch.randn(K2, U, generator=g) * 0.1
+    go = torch.randn(M, K2, generator=g)
+    u0 = units.double().requires_grad_(True)
+    w0 = wg.double().requires_grad_(True)
+    ref = torch.exp(u0) @ w0.t()
+    ref.backward(go.double())
+    u1 = units.to(dev).requires_grad_(True)
+    w1 = wg.to(dev).requires_grad_(True)
+    out = F_.wide_group_tail(u1, w1)
+    out.backward(go.to(dev))
+    for got, want, what in ((out, ref.detach(), "logits"), (u1.grad, u0.grad, "d_units"), (w1.grad, w0.grad, "d_W_g")):
+        err = (got.double().cpu() - want).abs().max().item()
+        assert err <= 1e-5 * want.abs().max().item(), f"{what}: {err:.3e} of {want.abs().max().item():.3e}"
+
+
+def test_wide_group_tail_on_the_bf16x3_kernel():
+    """The same three products at a size the bf16x3 kernel takes, with the exponential on either operand and in the epilogue
+    (flags 1 / 2 / 4 of spx_rows_gemm)."""
+    from scaleprotoseg_amd import functional as F_
+
+    dev = _dev()
+    M, U, K2 = 1024, 450, 256
+    g = torch.Generator().manual_seed(5)
     units = torch.randn(M, U, generator=g)
     wg = torch.randn(K2, U, generator=g) * 0.1
     go = torch.randn(M, K2, generator=g)

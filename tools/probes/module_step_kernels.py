@@ -1,5 +1,5 @@
 """Probe: the kernels of ONE eager step through the drop-in modules at crop size (torch profiler table).
-usage: module_step_kernels.py [group|proto] [ce]"""
+usage: module_step_kernels.py [group|proto|adegroup|adeproto] [ce]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch, torch.nn as nn
@@ -19,11 +19,17 @@ kind = sys.argv[1] if len(sys.argv) > 1 else "group"
 ce = len(sys.argv) > 2 and sys.argv[2] == "ce"
 torch.manual_seed(0)
 mk = dict(add_on_layers_type="deeplab_simple", patch_classification=True, num_scales=4)
+B, H, W, K = 10, 65, 65, 19
 if kind == "group":
     net = GroupNet(BB(256), 64, (228, 64, 1, 1), [], 19, num_groups=3, **mk).to(dev)
+elif kind == "adegroup":
+    B, K = 2, 150
+    net = GroupNet(BB(256), 64, (1800, 64, 1, 1), [], 150, num_groups=3, **mk).to(dev)
+elif kind == "adeproto":
+    B, K = 2, 150
+    net = spx.PPNetMultiScale(BB(256), 64, (1800, 64, 1, 1), [], 150, **mk).to(dev)
 else:
     net = spx.PPNetMultiScale(BB(256), 64, (228, 64, 1, 1), [], 19, **mk).to(dev)
-B, H, W, K = 10, 65, 65, 19
 x = torch.sigmoid(torch.randn(B, 256, H, W, device=dev)).bfloat16().requires_grad_(True)
 net.add_on_layers = nn.Sequential()
 gl = torch.randn(B, H, W, K, device=dev) * 1e-3
