@@ -97,6 +97,23 @@ __device__ __forceinline__ SpxKldWalk spx_kld_walk(int HW, int W, int trows, int
     return w;
 }
 
+// One step's inputs of a lane: its pixel's label and J plane values.  Fetched UNCONDITIONALLY (a lane without a pixel at that
+// step reads pixel 0 and ignores it) and ONE STEP AHEAD: the label and the planes leave together, and the next step's round
+// trip runs under this step's arithmetic - a wave's walk was a chain of two dependent round trips per step (label, then
+// planes) with nothing else to issue.
+template <int JT>
+struct SpxKldStep {
+    int c;
+    float d[JT];
+};
+template <int JT>
+__device__ __forceinline__ void spx_kld_fetch(SpxKldStep<JT>& o, const float* __restrict__ v, const int32_t* __restrict__ lab,
+                                              const SpxKldWalk& w, int step, int J, int HW) {
+    const int px = step < w.nvalid ? w.first + step * w.stride : 0;
+    o.c = lab[px];
+    spx_kld_load_planes(o.d, v, J, HW, px);
+}
+
 // pass 0: smax_key[b][c][j] = max over the segment's pixels of vals (ordered-uint key of the float)
 __global__ __launch_bounds__(SPX_KLD_THREADS) void spx_kld_max_kernel(const float* __restrict__ vals, const int32_t* __restrict__ labels,
                                                                      int J, int HW, int W, int trows, int K, unsigned int* __restrict__ smax_key,
@@ -129,9 +146,12 @@ __global__ __launch_bounds__(SPX_KLD_THREADS) void spx_kld_max_kernel(const floa
         if (lane == 0) atomicAdd(&cnt[cur], run);
         run = 0;
     };
+    SpxKldStep<SPX_KLD_MAXJ> nx;
+    spx_kld_fetch(nx, v, lab, w, 0, J, HW);
     for (int step = 0; step < w.nsteps; ++step) {
-        const int px = w.first + step * w.stride;
-        const int c = step < w.nvalid ? lab[px] : -1;
+        const SpxKldStep<SPX_KLD_MAXJ> cs = nx;
+        spx_kld_fetch(nx, v, lab, w, step + 1, J, HW);
+        const int c = step < w.nvalid ? cs.c : -1;
         const bool ok = c >= 0 && c < K;
         // lanes without a class (void pixels, lanes past the map) contribute neutral values either way: a step is uniform when
         // the lanes that HAVE a class agree on it (void borders and ragged tile edges do not send it down the per-lane path)
@@ -139,7 +159,8 @@ __global__ __launch_bounds__(SPX_KLD_THREADS) void spx_kld_max_kernel(const floa
         const int c0 = okm ? __builtin_amdgcn_readlane(c, __builtin_ffsll((long long)okm) - 1) : -1;
         const bool uniform = __builtin_amdgcn_ballot_w64(ok && c != c0) == 0;
         float d[SPX_KLD_MAXJ];
-        spx_kld_load_planes(d, v, J, HW, step < w.nvalid ? px : 0);
+#pragma unroll
+        for (int j = 0; j < SPX_KLD_MAXJ; ++j) d[j] = cs.d[j];
         if (range_keys) {
 #pragma unroll
             for (int j = 0; j < SPX_KLD_MAXJ; ++j) vmn = fminf(vmn, (ok && j < J) ? d[j] : 3.0e38f);
@@ -214,9 +235,12 @@ __global__ __launch_bounds__(SPX_KLD_THREADS) void spx_kld_sumexp_kernel(const f
                 acc[j] = 0.0f;
             }
     };
+    SpxKldStep<SPX_KLD_MAXJ> nx;
+    spx_kld_fetch(nx, v, lab, w, 0, J, HW);
     for (int step = 0; step < w.nsteps; ++step) {
-        const int px = w.first + step * w.stride;
-        const int c = step < w.nvalid ? lab[px] : -1;
+        const SpxKldStep<SPX_KLD_MAXJ> cs = nx;
+        spx_kld_fetch(nx, v, lab, w, step + 1, J, HW);
+        const int c = step < w.nvalid ? cs.c : -1;
         const bool ok = c >= 0 && c < K;
         // lanes without a class (void pixels, lanes past the map) contribute neutral values either way: a step is uniform when
         // the lanes that HAVE a class agree on it (void borders and ragged tile edges do not send it down the per-lane path)
@@ -224,7 +248,8 @@ __global__ __launch_bounds__(SPX_KLD_THREADS) void spx_kld_sumexp_kernel(const f
         const int c0 = okm ? __builtin_amdgcn_readlane(c, __builtin_ffsll((long long)okm) - 1) : -1;
         const bool uniform = __builtin_amdgcn_ballot_w64(ok && c != c0) == 0;
         float e[SPX_KLD_MAXJ];
-        spx_kld_load_planes(e, v, J, HW, step < w.nvalid ? px : 0);
+#pragma unroll
+        for (int j = 0; j < SPX_KLD_MAXJ; ++j) e[j] = cs.d[j];
         const float* smc = sm + (ok ? c : 0) * J;
 #pragma unroll
         for (int j = 0; j < SPX_KLD_MAXJ; ++j) e[j] = (ok && j < J) ? __expf(e[j] - smc[min(j, J - 1)]) : 0.0f;
@@ -290,9 +315,12 @@ __global__ __launch_bounds__(SPX_KLD_THREADS) void spx_kld_pairs_kernel(const fl
                     acc[j][k] = 0.0f;
                 }
     };
+    SpxKldStep<JT> nx;
+    spx_kld_fetch(nx, v, lab, w, 0, J, HW);
     for (int step = 0; step < w.nsteps; ++step) {
-        const int px = w.first + step * w.stride;
-        const int c = step < w.nvalid ? lab[px] - c_lo : -1;
+        const SpxKldStep<JT> cs = nx;
+        spx_kld_fetch(nx, v, lab, w, step + 1, J, HW);
+        const int c = step < w.nvalid ? cs.c - c_lo : -1;
         const bool ok = c >= 0 && c < K;
         // lanes without a class (void pixels, lanes past the map) contribute neutral values either way: a step is uniform when
         // the lanes that HAVE a class agree on it (void borders and ragged tile edges do not send it down the per-lane path)
@@ -300,7 +328,8 @@ __global__ __launch_bounds__(SPX_KLD_THREADS) void spx_kld_pairs_kernel(const fl
         const int c0 = okm ? __builtin_amdgcn_readlane(c, __builtin_ffsll((long long)okm) - 1) : -1;
         const bool uniform = __builtin_amdgcn_ballot_w64(ok && c != c0) == 0;
         float l[JT], p[JT];          // JT = J rounded up to a multiple of 4: static indices, padded slots contribute 0
-        spx_kld_load_planes(l, v, J, HW, step < w.nvalid ? px : 0);
+#pragma unroll
+        for (int j = 0; j < JT; ++j) l[j] = cs.d[j];
         const float* lsc = ls + (ok ? c : 0) * J;
 #pragma unroll
         for (int j = 0; j < JT; ++j) {
@@ -392,12 +421,23 @@ __global__ __launch_bounds__(SPX_KLD_THREADS) void spx_kld_backward_kernel(const
     float* g = grad + (size_t)b * J * HW;
     const int32_t* lab = labels + (size_t)b * HW;
     const int px_end = min(HW, (int)(blockIdx.x + 1) * ppw);
-    for (int px = blockIdx.x * ppw + tid; px < px_end; px += SPX_KLD_THREADS) {
-        const int craw = lab[px], c = craw - c_lo;
+    // label and planes of the NEXT pixel of the thread are in flight while this one is worked on (see SpxKldStep)
+    int px = blockIdx.x * ppw + tid;
+    int craw_n = lab[px < px_end ? px : 0];
+    float l_n[JT];
+    spx_kld_load_planes(l_n, v, J, HW, px < px_end ? px : 0);
+    for (; px < px_end; px += SPX_KLD_THREADS) {
+        const int craw = craw_n, c = craw - c_lo;
+        float l[JT], p[JT];
+#pragma unroll
+        for (int j = 0; j < JT; ++j) l[j] = l_n[j];
+        {
+            const int pn = px + SPX_KLD_THREADS < px_end ? px + SPX_KLD_THREADS : 0;
+            craw_n = lab[pn];
+            spx_kld_load_planes(l_n, v, J, HW, pn);
+        }
         const bool ok = c >= 0 && c < K;
         if (!ok && !(blockIdx.z == 0 && (craw < 0 || craw >= Kall))) continue;      // another block's pixel
-        float l[JT], p[JT];
-        spx_kld_load_planes(l, v, J, HW, px);
         const float* slc = sL + (ok ? c : 0) * JT;
 #pragma unroll
         for (int j = 0; j < JT; ++j) {
