@@ -13,6 +13,9 @@ class BB(nn.Module):
     def __repr__(s): return "MSC(standin)"
     def forward(s, x): return x
 
+if os.environ.get("SPX_PROBE_HEAD_ROWS"):      # experiment: heads above this many rows take the product kernels instead of the fused head
+    import scaleprotoseg_amd.model_multiscale as _mm
+    _mm.MAX_FUSED_HEAD_ROWS = int(os.environ["SPX_PROBE_HEAD_ROWS"])
 dev = torch.device("cuda:0")
 ONLY = sys.argv[1] if len(sys.argv) > 1 else ""
 
