@@ -36,6 +36,13 @@ __host__ __device__ constexpr int spx_fwd_head_lds_bytes() { return 0; }   // ex
 template <int NPB, int NCB>
 __host__ __device__ constexpr int spx_fwd_head_lds_bytes() { return NCB * NPB <= 6 ? NCB * NPB * 4096 : 0; }   // <= 24 KiB: resident in LDS
 #endif
+// Heads whose panel image does not fit (more than 6 class-block x prototype-block cells: 150 classes, or two class blocks over
+// 192-prototype panels) pass ONE prototype block's fragments at a time (NCB x 4 KiB) through LDS, fetched once per workgroup a
+// block ahead: as per-wave loads from L2 the same fragments were read four times per tile - 120 KiB per panel and wave for
+// 150 classes, 386 MB per launch on the ADE crops.  Measured: that forward 115 -> 100 us; the 2 Mpx grouping forward (two class
+// blocks x six prototype blocks) unchanged at 0.91 ms (profiles/EXPERIMENTS.md).
+template <int NPB, int NCB>
+__host__ __device__ constexpr int spx_fwd_head_blk_bytes() { return spx_fwd_head_lds_bytes<NPB, NCB>() == 0 ? NCB * 4096 : 0; }
 // region 0 = the two main-loop stages, re-used after the loop as the waves' epilogue scratch
 template <int NPB, int SPLIT>
 __host__ __device__ constexpr int spx_fwd_region0_bytes() {
@@ -43,7 +50,7 @@ __host__ __device__ constexpr int spx_fwd_region0_bytes() {
 }
 template <int NPB, int NCB, int SPLIT>
 __host__ __device__ constexpr int spx_fwd_lds_bytes() {
-    return spx_fwd_region0_bytes<NPB, SPLIT>() + spx_fwd_head_lds_bytes<NPB, NCB>() + 3 * NPB * 32 * 4 + NPB * 32 * 8;   // + |p|^2, class keys, slot plane offsets, push minima
+    return spx_fwd_region0_bytes<NPB, SPLIT>() + spx_fwd_head_lds_bytes<NPB, NCB>() + spx_fwd_head_blk_bytes<NPB, NCB>() + 3 * NPB * 32 * 4 + NPB * 32 * 8;   // + |p|^2, class keys, slot plane offsets, push minima
 }
 
 // SPLIT = waves per 32-pixel group.  SPLIT 1: 4 waves, each with all NPB blocks of its pixels (<= 256 VGPRs, two
@@ -91,7 +98,9 @@ __global__ __launch_bounds__(256 * SPLIT, (NPB == 2 && NCB == 1 ? 3 : SPX_FWD_WA
     constexpr int region0 = spx_fwd_region0_bytes<NPB, SPLIT>();
     const int nchunks = (Cs + SPX_KC - 1) / SPX_KC;
     char* const wlds = smem + region0;
-    float* const p2s = (float*)(wlds + head_lds);
+    constexpr int head_blk = spx_fwd_head_blk_bytes<NPB, NCB>();
+    constexpr bool HSTREAM = head_blk != 0 && NT == 256;     // (the 8-wave experiment keeps the per-wave loads)
+    float* const p2s = (float*)(wlds + head_lds + head_blk);
     uint32_t* const keys = (uint32_t*)(p2s + NPB * 32);     // GATHER: (class << 16) | slot per padded prototype row
     uint32_t* const koff = keys + NPB * 32;                 // GATHER: byte offset of the row's slot plane (slot * HW * 4)
     unsigned long long* const pmin = (unsigned long long*)(koff + NPB * 32);   // fused push: the workgroup's (value key, pixel) minimum per row
@@ -184,12 +193,28 @@ __global__ __launch_bounds__(256 * SPLIT, (NPB == 2 && NCB == 1 ? 3 : SPX_FWD_WA
     // Panel epilogue as a ROLLED loop over the panel's 32-prototype blocks (the body is compiled once, with a
     // small fixed register footprint, instead of NPB unrolled copies); the block's accumulator tile is fetched
     // with a wave-uniform select over static register indices and cleared for the next panel.
+    // HSTREAM: the next block's head fragments (thread t: bytes [16 t, 16 t + 16) of each class block's 4 KiB) on their way to LDS
+    u32x4 wreg[HSTREAM ? NCB : 1];
+    auto w_issue = [&](int panel, int pb) {
+#pragma unroll
+        for (int cb = 0; cb < (HSTREAM ? NCB : 0); ++cb)
+            wreg[cb] = buf_load_b128(hr, want_head ? (uint32_t)tid * 16u : SPX_OOB, (uint32_t)(((cb * pl.npanels + panel) * NPB + pb) * 4096));
+    };
     auto epilogue = [&](int panel) {
         const float x2 = x2part + __shfl_xor(x2part, 32);
         const int p0 = pl.panel_p0[panel], np = pl.panel_np[panel];
+        if (HSTREAM && panel == q_begin) w_issue(panel, ph * NH);
 #pragma unroll 1
         for (int pbl = 0; pbl < NH; ++pbl) {
             const int pb = ph * NH + pbl;              // block index inside the panel
+            if (HSTREAM) {
+                __syncthreads();                       // every wave is done with the previous block's fragments
+#pragma unroll
+                for (int cb = 0; cb < (HSTREAM ? NCB : 0); ++cb) *(u32x4*)(wlds + cb * 4096 + tid * 16) = wreg[cb];
+                __syncthreads();
+                if (pbl + 1 < NH) w_issue(panel, pb + 1);
+                else if (panel + 1 < q_end) w_issue(panel + 1, ph * NH);
+            }
             const f32x16 tile = tile_get<NH>(acc, pbl);
             if (pb * 32 < np) {
                 const spx_rsrc dr = make_rsrc_pred(a.dist ? a.dist + ((size_t)b * P + p0 + pb * 32) * a.HW : nullptr);
@@ -323,6 +348,10 @@ __global__ __launch_bounds__(256 * SPLIT, (NPB == 2 && NCB == 1 ? 3 : SPX_FWD_WA
                             bf16x8 whi, wlo;
                             if (head_lds) {
                                 const char* wf = wlds + ((cb * NPB + pb) * 2 + s2) * 2048 + lane * 16;
+                                whi = *(const bf16x8*)wf;
+                                wlo = *(const bf16x8*)(wf + 1024);
+                            } else if (HSTREAM) {
+                                const char* wf = wlds + (cb * 2 + s2) * 2048 + lane * 16;
                                 whi = *(const bf16x8*)wf;
                                 wlo = *(const bf16x8*)(wf + 1024);
                             } else {
