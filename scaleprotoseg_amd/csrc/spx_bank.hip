@@ -840,8 +840,9 @@ __global__ __launch_bounds__(SPX_BK_THREADS, 2) void spx_bank_dma_kernel(const S
 // kernel 3: fixed-order sum of the slabs, + the p * colsum(G) term.  Four independent partial sums per output
 // (slab j goes to partial j & 3) keep several loads in flight per thread; the order is fixed, so results are
 // run-to-run identical.
-#define SPX_RED_ELEMS 32     // output elements per workgroup
-#define SPX_RED_PARTS 8      // slab ranges summed in parallel per element (256 threads)
+#define SPX_RED_ELEMS 64     // output elements per workgroup (a wave reads 256-B row pieces: 128-B pieces streamed at half the rate)
+#define SPX_RED_PARTS 4      // slab ranges summed in parallel per element (256 threads)
+#define SPX_RED_FLY 8        // slabs in flight per thread
 __global__ __launch_bounds__(SPX_RED_ELEMS * SPX_RED_PARTS) void spx_bank_reduce_kernel(const SpxBankBwdArgs a) {
     __shared__ float red_s[SPX_RED_PARTS][SPX_RED_ELEMS], red_c[SPX_RED_PARTS][SPX_RED_ELEMS];
     const spx_plan& pl = a.plan;
@@ -863,27 +864,35 @@ __global__ __launch_bounds__(SPX_RED_ELEMS * SPX_RED_PARTS) void spx_bank_reduce
     const float* base = a.workspace + ((size_t)q * rows + row) * ws;
     const int c0 = is_p ? col : nchb * 32 + (col - Cs);
     const int c1 = nchb * 32 + pl.ncb * 32;          // colsum column
-    // this thread's slab range; inside it slab j goes to partial (j - j0) & 3: a fixed order, so results are
-    // run-to-run identical
+    // this thread's slab range; inside it slab j goes to partial (j - j0) % SPX_RED_FLY: a fixed order, so results are
+    // run-to-run identical.  The colsum column is read unconditionally (head columns ignore it): no load sits under a branch.
     const int per = (a.nsplit + SPX_RED_PARTS - 1) / SPX_RED_PARTS;
     const int j0 = part * per, j1 = min(a.nsplit, j0 + per);
-    float s[4] = {0.f, 0.f, 0.f, 0.f}, cs[4] = {0.f, 0.f, 0.f, 0.f};
+    float s[SPX_RED_FLY], cs[SPX_RED_FLY];
+#pragma unroll
+    for (int u = 0; u < SPX_RED_FLY; ++u) s[u] = cs[u] = 0.0f;
     if (live) {
         int j = j0;
-        for (; j + 4 <= j1; j += 4) {
+        for (; j + SPX_RED_FLY <= j1; j += SPX_RED_FLY) {
+            float v[SPX_RED_FLY], w[SPX_RED_FLY];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                s[u] += base[(size_t)(j + u) * slab_stride + c0];
-                if (is_p) cs[u] += base[(size_t)(j + u) * slab_stride + c1];
+            for (int u = 0; u < SPX_RED_FLY; ++u) {
+                v[u] = base[(size_t)(j + u) * slab_stride + c0];
+                w[u] = base[(size_t)(j + u) * slab_stride + c1];
+            }
+#pragma unroll
+            for (int u = 0; u < SPX_RED_FLY; ++u) {
+                s[u] += v[u];
+                cs[u] += w[u];
             }
         }
         for (; j < j1; ++j) {
-            s[(j - j0) & 3] += base[(size_t)j * slab_stride + c0];
-            if (is_p) cs[(j - j0) & 3] += base[(size_t)j * slab_stride + c1];
+            s[(j - j0) % SPX_RED_FLY] += base[(size_t)j * slab_stride + c0];
+            cs[(j - j0) % SPX_RED_FLY] += base[(size_t)j * slab_stride + c1];
         }
     }
-    red_s[part][el] = (s[0] + s[1]) + (s[2] + s[3]);
-    red_c[part][el] = (cs[0] + cs[1]) + (cs[2] + cs[3]);
+    red_s[part][el] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+    red_c[part][el] = ((cs[0] + cs[1]) + (cs[2] + cs[3])) + ((cs[4] + cs[5]) + (cs[6] + cs[7]));
     __syncthreads();
     if (part != 0 || !live) return;
     float st = 0.0f, ct = 0.0f;
