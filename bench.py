@@ -144,7 +144,7 @@ def secondary_modes(dev, spx, F_, steps=5, warmup=2):
             x.grad = bank.grad = head.grad = None
             logits, dmap, _ = spx.proto_head_forward(x, bank, head, layout, want_distances=False, class_gather=gather)
             if kld:
-                loss = kld_fn(spx.ClassDistances(dmap, gather.labels, gather.table, (H, W)), target1)
+                loss = kld_fn(spx.ClassDistances(dmap, gather.labels, gather.table, (H, W), target1, target1._version), target1)
                 torch.autograd.backward([logits, loss], [g_logits, None])
             else:
                 torch.autograd.backward([logits, dmap], [g_logits, g_cls])
@@ -203,7 +203,7 @@ def secondary_modes(dev, spx, F_, steps=5, warmup=2):
     def crop_step():
         x.grad = bank.grad = head.grad = None
         logits, dmap, _ = spx.proto_head_forward(x, bank, head, layout, want_distances=False, class_gather=gather)
-        loss = kld_fn(spx.ClassDistances(dmap, gather.labels, gather.table, (H, W)), target)
+        loss = kld_fn(spx.ClassDistances(dmap, gather.labels, gather.table, (H, W), target, target._version), target)
         torch.autograd.backward([logits, loss], [gl, None])
     graph, _ = capture_step(crop_step, warmup=2)
     ms = timed(graph.replay, n=20, w=3)
@@ -391,7 +391,7 @@ def main():
         if "logits" in args.grads:
             outs.append(logits); gouts.append(g_logits)
         if "dist" in args.grads and gather is not None and args.kld:
-            outs.append(kld_fn(spx.ClassDistances(dmap, gather.labels, gather.table, (H, W)), target1)); gouts.append(None)
+            outs.append(kld_fn(spx.ClassDistances(dmap, gather.labels, gather.table, (H, W), target1, target1._version), target1)); gouts.append(None)
         elif "dist" in args.grads and gather is not None:
             outs.append(dmap); gouts.append(g_cls)
         elif "dist" in args.grads and want_d:

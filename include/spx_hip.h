@@ -121,11 +121,13 @@ int spx_dist_bwd(const spx_plan* plan, const void* x, int32_t x_dtype, int32_t B
  * distances to the prototypes of ITS OWN class - the only entries KLDLoss reads for that pixel
  * (segmentation/model/loss.py:89-107; caller segmentation/model/module_multiscale.py:239-242) - so the fp32 map
  * and its gradient never cross HBM.
- *   labels     int32 [B, HW]: class 0..K-1 of the pixel; any other value = no class (its row is not written)
+ *   labels     int32 [B, HW]: class 0..K-1 of the pixel; any other value = no class (its slots read 0)
  *   proto_key  uint32 [npanels * 32*npb], in the plan's padded row order: (class << 16) | slot, slot < J =
  *              rank of the prototype among its class's prototypes (ascending index); 0xFFFFFFFF = none / padding
  *   class_distances fp32 [B, J, HW] (slot planes): entry (slot, px) = distance of pixel px to prototype `slot` of class
- *              labels[px]; entries that no prototype maps to are not written (the caller zero-fills).
+ *              labels[px]; entries that no prototype maps to (every slot of a pixel without a class, the slots past its class's
+ *              prototype count) are written as 0 by the kernel for classes below 1024 - the planes may arrive uninitialised;
+ *              tables with larger class ids: the caller zero-fills.
  * Everything else as in spx_dist_fwd / spx_dist_bwd. */
 int spx_dist_fwd_cls(const spx_plan* plan, const void* x, int32_t x_dtype, int32_t B, int32_t HW,
                      const void* packed_bank, const float* packed_p2, const void* packed_head,

@@ -27,6 +27,7 @@
 #ifndef SPX_FWD_TROW
 #define SPX_FWD_TROW 40
 #endif
+#define SPX_GATHER_CLASSES 1024         // classes of the in-kernel slot-count table of the gathered mode (4 KiB of idle stage memory)
 #define SPX_FWD_TSCRATCH 8192           // per wave: >= 32 * SPX_FWD_TROW * 4 (distance turn) and 32 px x 64 values (block I/O)
 // LDS carve (bytes): [stage 0][stage 1][head fragments of the current panel (NCB == 1 only)][|p|^2 of the panel]
 #ifdef SPX_FWD_HEAD_L2
@@ -155,6 +156,26 @@ __global__ __launch_bounds__(256 * SPLIT, (NPB == 2 && NCB == 1 ? 3 : SPX_FWD_WA
             lab16 = (px_ok && c >= 0 && c < a.push_K) ? (uint32_t)c : 0xFFFEu;
         }
         voff_c = px_ok ? (uint32_t)px * 4u : SPX_OOB;          // [slot][px] planes: a wave's 32 pixels are one 128-B run
+        if (a.cls_dist && blockIdx.y == 0) {
+            // Slots no prototype maps to - every slot of a pixel without a class, the slots past its class's prototype count -
+            // are written as zeros HERE (the caller hands over uninitialised planes: a memset of 40 B/px less per forward).
+            // The counts come from the key table (1 + the largest slot of a class), built once per workgroup in the still idle
+            // stage memory; a slot that gets a zero never gets a value, so the stores below cannot race with these.
+            // (label classes are the key table's, not the plan's head rows: a table of SPX_GATHER_CLASSES entries; a class beyond
+            // it keeps all its slots - the host side zero-fills for such tables itself)
+            int* const cnt_s = (int*)smem;
+            for (int i = tid; i < SPX_GATHER_CLASSES; i += NT) cnt_s[i] = 0;
+            __syncthreads();
+            for (int i = tid; i < pl.npanels * NPB * 32; i += NT) {
+                const uint32_t key = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(keyr, (uint32_t)i * 4u, 0, 0);
+                if ((key >> 16) < (uint32_t)SPX_GATHER_CLASSES) atomicMax(cnt_s + (key >> 16), (int)(key & 0xFFFFu) + 1);
+            }
+            __syncthreads();
+            const int cnt = lab16 < (uint32_t)SPX_GATHER_CLASSES ? cnt_s[lab16] : (lab16 == 0xFFFEu ? 0 : a.J);
+            if (px_ok && lane < 32)
+                for (int j = cnt; j < a.J; ++j) buf_store_f32(0.0f, cdr, voff_c + (uint32_t)j * (uint32_t)a.HW * 4u, 0);
+            __syncthreads();                                   // the stages are the pipeline's from here on
+        }
     }
 
     // panel prologue: head fragments + |p|^2 of the panel -> LDS (read in the epilogue, after >= 1 barrier)

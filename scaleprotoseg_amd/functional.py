@@ -557,8 +557,10 @@ class _ProtoHeadFn(torch.autograd.Function):
             if gather is not None:
                 if tuple(gather.labels.shape) != (B, HW) or gather.labels.dtype != torch.int32:
                     raise SpxError(f"gather labels must be int32 [{B}, {HW}]")
-                # slots no prototype maps to (and pixels without a class) stay 0
-                dist = torch.zeros((B, gather.width, HW), **f32)
+                # slots no prototype maps to (and pixels without a class) are written as 0 by the kernel itself (class ids
+                # below 1024: include/spx_hip.h); beyond that the planes are zero-filled here
+                few = gather.table is not None and int(gather.table.shape[0]) <= 1024
+                dist = (torch.empty if few else torch.zeros)((B, gather.width, HW), **f32)
                 g_args = (_lib.ptr(gather.labels), _lib.ptr(gather.keys), gather.width, _lib.ptr(dist), None)
             else:
                 dist = torch.empty((B, P) + tuple(x.shape[2:]), **f32) if want_dist else None

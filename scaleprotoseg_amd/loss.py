@@ -12,7 +12,7 @@ algebra that the tests hold the kernels against is test infrastructure and lives
 from __future__ import annotations
 
 from dataclasses import dataclass
-from typing import Dict, Tuple, Union
+from typing import Dict, Optional, Tuple, Union
 
 import torch
 from torch import nn
@@ -29,6 +29,10 @@ class ClassDistances:
     labels: torch.Tensor
     table: torch.Tensor
     grid: Tuple[int, int]
+    # the target map ``labels`` was derived from (labels = target - 1) and its version then: a loss that is handed this very
+    # tensor takes ``labels`` as they are instead of shifting and converting the map a second time
+    target: Optional[torch.Tensor] = None
+    target_version: int = -1
 
 
 def class_slot_table(prototype_class_identity: torch.Tensor) -> torch.Tensor:
@@ -237,7 +241,11 @@ class KLDLoss(nn.Module):
         return same & upper
 
     def forward(self, prototype_distances: Union[torch.Tensor, ClassDistances], target_labels: torch.Tensor) -> torch.Tensor:
-        labels0 = target_labels.reshape(target_labels.shape[0], -1).long() - 1          # loss.py:73
+        cd = prototype_distances if isinstance(prototype_distances, ClassDistances) else None
+        if cd is not None and cd.target is target_labels and cd.target_version == target_labels._version:
+            labels0 = cd.labels                                                           # already target - 1 (int32)
+        else:
+            labels0 = target_labels.reshape(target_labels.shape[0], -1).long() - 1      # loss.py:73
         if isinstance(prototype_distances, ClassDistances):
             table = prototype_distances.table
             vals = prototype_distances.values.permute(0, 2, 1)          # [B, H*W, J] view

@@ -124,7 +124,7 @@ class _PrototypeBankMixin:
             self._gather_cache = cache
         keys, width, table = cache[2]
         B = target_labels.shape[0]
-        labels0 = (target_labels.reshape(B, -1).to(device=device, dtype=torch.int32) - 1).contiguous()
+        labels0 = shifted_labels_i32(target_labels.reshape(B, -1), device)
         return ClassGather(labels=labels0, keys=keys, width=width, table=table)
 
     def _check_fusable(self):
@@ -305,7 +305,8 @@ class PPNetMultiScale(_PrototypeBankMixin, nn.Module):
         elif ce_labels is not None:
             fused_ce = out[3]
         if gather is not None:
-            dist = ClassDistances(values=dist, labels=gather.labels, table=gather.table, grid=(H, W))
+            dist = ClassDistances(values=dist, labels=gather.labels, table=gather.table, grid=(H, W), target=target_labels,
+                                  target_version=target_labels._version)
         logits = logits.reshape(B, H, W, -1)
         if fused_ce is not None:
             fused_ce.target = ce_target

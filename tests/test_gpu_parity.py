@@ -1473,3 +1473,53 @@ def test_pack_all_equals_the_single_pack_calls(P, K, S, Cs, K2):
         if k in c:
             assert torch.equal(a[k], c[k]), k
     assert bool((c["bankT"] == 0xA5).all())
+
+
+@pytest.mark.parametrize("S,H,W", [(1, 17, 40), (4, 33, 33), (2, 1, 5)])
+def test_gathered_forward_writes_every_slot_of_uninitialised_planes(S, H, W):
+    """spx_dist_fwd_cls on NaN-filled planes (include/spx_hip.h: the planes may arrive uninitialised): the slots past a class's
+    prototype count and every slot of a pixel without a class read exactly 0 afterwards, the mapped ones the oracle's value.
+    Classes own 3, 2, 1 and 0 prototypes per scale, so J = 3 S and most classes leave slots unmapped."""
+    import ctypes as C_
+    from scaleprotoseg_amd import _lib
+    from scaleprotoseg_amd.functional import BankLayout, _Packs, class_gather_table
+
+    dev = _dev()
+    lib = _lib.load()
+    K, Cs, B = 4, 32, 2
+    per_scale = [0, 0, 0, 1, 1, 2]                       # classes of a scale's 6 prototypes: class 3 has none
+    P = S * len(per_scale)
+    ident = torch.zeros(P, K)
+    for s_ in range(S):
+        for i, c in enumerate(per_scale):
+            ident[s_ * len(per_scale) + i, c] = 1
+    ranges = O.default_scale_ranges(P, S)
+    lay = BankLayout(P, K, S, Cs, tuple(ranges[s_] for s_ in range(S)))
+    plan = lay.plan()
+    pp = C_.byref(plan)
+    keys, J, table = class_gather_table(lay, ident, dev)
+    assert J == 3 * S
+    g = torch.Generator().manual_seed(S * 100 + H)
+    HW = H * W
+    x = torch.rand(B, S * Cs, HW, generator=g).bfloat16()
+    bank = torch.rand(P, Cs, generator=g).bfloat16().float()
+    head = torch.randn(K, P, generator=g) * 0.1
+    labels = torch.randint(-1, K + 1, (B, HW), generator=g, dtype=torch.int32)       # -1 and K: no class
+    packs = _Packs(plan, bank.to(dev), head.to(dev), False)
+    cd = torch.full((B, J, HW), float("nan"), device=dev)
+    logits = torch.empty(B * HW, K, device=dev)
+    _lib.check(lib.spx_dist_fwd_cls(pp, _lib.ptr(x.to(dev)), 0, B, HW, _lib.ptr(packs.bank), _lib.ptr(packs.p2), _lib.ptr(packs.head),
+                                    _lib.ptr(labels.to(dev)), _lib.ptr(keys), J, _lib.ptr(cd), None, _lib.ptr(logits), 1e-4, 0,
+                                    _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    _, d_ref, _ = O.forward_from_conv_features(x.float().reshape(B, S * Cs, H, W), bank.reshape(P, Cs, 1, 1), ranges, S, head)
+    ref = O.gather_class_distances(d_ref, labels.long(), ident)                       # [B, HW, J], zeros where nothing maps
+    got = cd.cpu().permute(0, 2, 1)
+    assert not torch.isnan(got).any(), "a slot was left unwritten"
+    mapped = torch.zeros_like(ref, dtype=torch.bool)
+    tab = O.class_slot_table(ident)
+    for c in range(K):
+        mapped[(labels == c)] = (tab[c] >= 0)
+    assert (got[~mapped] == 0).all()
+    err = (got - ref).abs()
+    assert (err <= 1e-4 * (1 + ref)).all(), f"class distance err {err.max().item()}"

@@ -34,4 +34,4 @@ for _ in range(2): step()
 torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
     step(); torch.cuda.synchronize()
-print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=8, max_name_column_width=60))
+print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=30, max_name_column_width=60))
