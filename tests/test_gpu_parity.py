@@ -1523,3 +1523,37 @@ def test_gathered_forward_writes_every_slot_of_uninitialised_planes(S, H, W):
     assert (got[~mapped] == 0).all()
     err = (got - ref).abs()
     assert (err <= 1e-4 * (1 + ref)).all(), f"class distance err {err.max().item()}"
+
+
+@pytest.mark.parametrize("P,S,Cs,U,K2,B,H,W", [(160, 1, 64, 160, 32, 1, 37, 41), (96, 2, 32, 150, 31, 2, 20, 33)])
+def test_group_tail_with_cross_entropy_at_the_widest_heads(P, S, Cs, U, K2, B, H, W):
+    """The grouping tail kernel with the fused cross entropy at its limits (160 units, 32 classes: 73 KiB of LDS for W_g^T, the
+    group activations of 64 pixels and the logits): logits and loss against an fp32 torch restatement of
+    model_multiscale_group.py:303-308 + loss.py:9-48 on the same bf16-representable inputs; every gradient finite."""
+    from scaleprotoseg_amd.functional import BankLayout, proto_head_forward
+
+    dev = _dev()
+    torch.manual_seed(P + U)
+    x = torch.sigmoid(torch.randn(B, S * Cs, H, W, device=dev)).bfloat16().requires_grad_(True)
+    bank = torch.rand(P, Cs, 1, 1, device=dev).bfloat16().float().requires_grad_(True)
+    wd = (torch.rand(U, P, device=dev) * 0.02).requires_grad_(True)
+    wg = (torch.randn(K2, U, device=dev) * 0.1).requires_grad_(True)
+    per = P // S
+    lay = BankLayout(P, U, S, Cs, tuple((s * per, (s + 1) * per) for s in range(S)))
+    lab = torch.randint(-1, K2, (B, H * W), device=dev, dtype=torch.int32)
+    out = proto_head_forward(x, bank, wd, lay, want_distances=True, group_tail=wg, ce_labels=lab)
+    logits, fce = out[0], out[3]
+    xf, d = x.detach().float(), []
+    for s in range(S):
+        xs = xf[:, s * Cs:(s + 1) * Cs].reshape(B, Cs, -1)
+        p = bank.detach()[s * per:(s + 1) * per].reshape(per, Cs)
+        d.append(((xs * xs).sum(1, keepdim=True) - 2 * torch.einsum("pc,bcm->bpm", p, xs) + (p * p).sum(1)[None, :, None]).clamp_min(0))
+    d = torch.cat(d, 1)
+    act = torch.log((d + 1) / (d + 1e-4)).permute(0, 2, 1).reshape(B * H * W, P)
+    ref = torch.exp(act @ wd.detach().t()) @ wg.detach().t()
+    assert (logits - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
+    valid = lab.reshape(-1) >= 0
+    ce_ref = torch.nn.functional.cross_entropy(ref[valid], lab.reshape(-1)[valid].long())
+    assert abs(float(fce.loss.detach()) - float(ce_ref)) <= 1e-5 * max(1.0, abs(float(ce_ref)))
+    fce.loss.backward()
+    assert all(torch.isfinite(t.grad).all().item() for t in (x, bank, wd, wg))
