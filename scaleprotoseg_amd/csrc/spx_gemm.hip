@@ -204,19 +204,20 @@ __global__ __launch_bounds__(256) void spx_gemm_kernel(const SpxGemmArgs a) {
 // v_mfma_f32_32x32x2_f32 over the same k - 2.7x the fp32 pipe's rate with the same fp32 accumulation, the dropped terms
 // below the summation-order noise (tests/test_gpu_gemm.py holds both kernels to the same 2e-6 |A|.|B| bound).
 // Workgroup = 4 waves = 128 x 128 of C (wave: 64 x 64 = 2 x 2 MFMA tiles), k in chunks of 32 (a k-contiguous operand is then
-// fetched in whole 128-B row pieces) through ONE LDS buffer of three bf16 planes per operand (60 KiB: two workgroups per CU):
-//   k-contiguous operand:   [plane][row][32 k] with 80-B rows   - a fragment (row = lane & 31, k = 8 (lane >> 5) + j) is one
-//                           ds_read_b128 (20-dword row stride: the 16 lanes of a read group fall on 16 distinct 16-B slots);
+// fetched in whole 128-B row pieces) through ONE LDS buffer of three bf16 planes per operand (48-60 KiB: three or two workgroups per CU):
+//   k-contiguous operand:   [plane][row][32 k], 64-B rows, the row's four 16-B slots XOR-swizzled by (row >> 2) & 3 - a fragment
+//                           (row = lane & 31, k = 8 (lane >> 5) + j) is one ds_read_b128 and the 16 lanes of a read group fall on 16
+//                           distinct slots without padding: 48 KiB for two such operands, THREE workgroups per CU;
 //   row-contiguous operand: [plane][k][128 rows] with 320-B rows - a thread's 8 consecutive rows are one 16-B write, and
 //                           the fragment comes back through two ds_read_b64_tr_b16 (k becomes the register index; the
 //                           80-dword row stride keeps the four k rows and two column halves of a 32-lane group on distinct banks).
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 #define SPX_G3_TI 128
 #define SPX_G3_TK 32
-#define SPX_G3_KS 80                      // k-contiguous image: row stride in bytes (32 k + 16 B)
+#define SPX_G3_KS 64                      // k-contiguous image: row stride in bytes (32 k, unpadded: 16-B slots XOR-swizzled by (row >> 2) & 3)
 #define SPX_G3_RS 320                     // row-contiguous image: k-row stride in bytes (128 rows + 64 B)
-#define SPX_G3_PLANE 10240                // 128 * 80 = 32 * 320
-#define SPX_G3_OPER (3 * SPX_G3_PLANE)
+template <bool KCONT> __host__ __device__ constexpr int spx_g3_plane() { return KCONT ? 128 * SPX_G3_KS : 32 * SPX_G3_RS; }
+template <bool KCONT> __host__ __device__ constexpr int spx_g3_oper() { return 3 * spx_g3_plane<KCONT>(); }
 
 __device__ __forceinline__ void split3_bf16x8(const float (&r)[8], bf16x8& h, bf16x8& m, bf16x8& l) {
 #pragma unroll
@@ -282,10 +283,11 @@ struct SpxGemm3Operand {
             bf16x8 h, m, l;
             split3_bf16x8(r, h, m, l);
             // KCONT: 8 k of one row;  else: 8 rows of one k - 16 contiguous bytes of the image either way
-            char* const dst = img + (KCONT ? (row + 64 * p) * SPX_G3_KS + kk * 2 : (kk + 16 * p) * SPX_G3_RS + row * 2);
+            const int rw = row + 64 * p;
+            char* const dst = img + (KCONT ? rw * SPX_G3_KS + (((kk >> 3) ^ ((rw >> 2) & 3)) << 4) : (kk + 16 * p) * SPX_G3_RS + row * 2);
             *(bf16x8*)dst = h;
-            *(bf16x8*)(dst + SPX_G3_PLANE) = m;
-            *(bf16x8*)(dst + 2 * SPX_G3_PLANE) = l;
+            *(bf16x8*)(dst + spx_g3_plane<KCONT>()) = m;
+            *(bf16x8*)(dst + 2 * spx_g3_plane<KCONT>()) = l;
         }
     }
 };
@@ -293,7 +295,10 @@ struct SpxGemm3Operand {
 // fragment of k-step ks (16 k) of the 32 rows starting at r0 of one plane image
 template <bool KCONT>
 __device__ __forceinline__ bf16x8 g3_frag(const char* __restrict__ plane, int r0, int ks, int lane) {
-    if (KCONT) return *(const bf16x8*)(plane + (r0 + (lane & 31)) * SPX_G3_KS + 32 * ks + 16 * (lane >> 5));
+    if (KCONT) {
+        const int rw = r0 + (lane & 31);
+        return *(const bf16x8*)(plane + rw * SPX_G3_KS + (((2 * ks + (lane >> 5)) ^ ((rw >> 2) & 3)) << 4));
+    }
     const int g = lane >> 4, i = lane & 15, q = i >> 2, pq = i & 3;
     const char* const p0 = plane + (16 * ks + 8 * (g >> 1) + q) * SPX_G3_RS + (r0 + 16 * (g & 1) + 4 * pq) * 2;
     const s16x4 lo = lds_tr_read(p0), hi = lds_tr_read(p0 + 4 * SPX_G3_RS);
@@ -304,7 +309,7 @@ __device__ __forceinline__ bf16x8 g3_frag(const char* __restrict__ plane, int r0
 }
 
 template <bool AK, bool BK>
-__global__ __launch_bounds__(256, 2) void spx_gemm3_kernel(const SpxGemmArgs a) {
+__global__ __launch_bounds__(256, (AK && BK) ? 3 : 2) void spx_gemm3_kernel(const SpxGemmArgs a) {
     constexpr int TI = SPX_G3_TI, TK = SPX_G3_TK;
     extern __shared__ __attribute__((aligned(16))) char g3_lds[];        // [A | B][plane image]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -331,7 +336,7 @@ __global__ __launch_bounds__(256, 2) void spx_gemm3_kernel(const SpxGemmArgs a) 
     sa.init(tid, a.ras, a.kas);
     sb.init(tid, a.rbs, a.kbs);
     char* const ia = g3_lds;
-    char* const ib = g3_lds + SPX_G3_OPER;
+    char* const ib = g3_lds + spx_g3_oper<AK>();
     // One LDS buffer, one register set: chunk c + 1 is in flight in registers while chunk c feeds the matrix pipe; the two
     // workgroups of a CU fill each other's commit phases.  (A second register set - two chunks of lead - measured no faster.)
     sa.load(a.A, a.ras, a.kas, i0, a.M, a.K, kbeg, kend);
@@ -350,8 +355,8 @@ __global__ __launch_bounds__(256, 2) void spx_gemm3_kernel(const SpxGemmArgs a) 
             for (int u = 0; u < 2; ++u)
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl) {
-                    fa[u][pl] = g3_frag<AK>(ia + pl * SPX_G3_PLANE, (wi * 2 + u) * 32, ks, lane);
-                    fb[u][pl] = g3_frag<BK>(ib + pl * SPX_G3_PLANE, (wj * 2 + u) * 32, ks, lane);
+                    fa[u][pl] = g3_frag<AK>(ia + pl * spx_g3_plane<AK>(), (wi * 2 + u) * 32, ks, lane);
+                    fb[u][pl] = g3_frag<BK>(ib + pl * spx_g3_plane<BK>(), (wj * 2 + u) * 32, ks, lane);
                 }
             // smallest terms first into the accumulator
 #pragma unroll
@@ -417,18 +422,22 @@ static SpxGemmPlan spx_gemm_plan(int M, int N, int K, int flags) {
     // order by a second kernel) until that many workgroups exist, keeping >= 512 k per slab.
     const long long t64 = (long long)((M + 63) / 64) * ((N + 63) / 64);
     // The bf16x3 kernel (128-tiles) unless its tiles would be mostly padding (N = 150: 1.7x) or there is next to no work.
-    // Splits, from the sweep over the ADE / COCO head shapes (tools/probes/gemm3_sweep.py, profiles/EXPERIMENTS.md): slabs of
-    // ~700 k (a workgroup's fixed cost is worth ~6 chunks of 32), at least ~400 workgroups, and never between one and one and a
-    // half rounds of the 512 workgroup slots (536 workgroups took as long as 268: the last 24 run alone).
+    // Splits, from the sweeps over the ADE / COCO head shapes (tools/probes/gemm3_sweep.py, profiles/EXPERIMENTS.md): slabs of
+    // ~420 k for contractions over prototypes (k-contiguous operands: three workgroups per CU) and ~700 k for contractions over
+    // pixels, at most ~2000 workgroups, at least ~400, and for the pixel contractions never between one and one and a half rounds
+    // of the 512 workgroup slots (536 workgroups took as long as 268: the last 24 run alone).
     const long long t128 = (long long)((M + 127) / 128) * ((N + 127) / 128);
     const double waste = (double)(t128 * 128 * 128) / ((double)M * (double)N);
     if (waste <= 1.5 && t128 >= 8 && K >= 64) {
         int sp = 1;
         if (!(flags & 4)) {
-            sp = (K + 350) / 700;
+            const int slab = K > 4096 ? 700 : 420;        // pixel contractions (few tiles, long k) / prototype contractions
+            sp = (K + slab / 2) / slab;
             sp = sp < 1 ? 1 : (sp > 16 ? 16 : sp);
+            while (sp > 1 && t128 * sp > 2000) --sp;
             while (sp < 16 && t128 * sp < 400 && K / (sp + 1) >= 128) ++sp;
-            while (sp < 16 && t128 * sp > 512 && t128 * sp < 800 && K / (sp + 1) >= 128) ++sp;
+            if (K > 4096)
+                while (sp < 16 && t128 * sp > 512 && t128 * sp < 800 && K / (sp + 1) >= 128) ++sp;
         }
         int kp = ((K + sp - 1) / sp + SPX_G_TK - 1) / SPX_G_TK * SPX_G_TK;
         return SpxGemmPlan{3, (K + kp - 1) / kp, kp};
@@ -467,11 +476,10 @@ static void spx_launch_gemm3(const SpxGemmArgs& a_, bool ak, bool bk, hipStream_
     a.ntiles = a.ni * a.nj * a.splits;
     a.linear_map = g_gemm_force_splits < 0;
     const dim3 grid((unsigned)(((a.ntiles + 7) / 8) * 8));
-    constexpr size_t lds = 2 * SPX_G3_OPER;
-    if (ak && bk) hipLaunchKernelGGL((spx_gemm3_kernel<true, true>), grid, dim3(256), lds, s, a);
-    else if (ak) hipLaunchKernelGGL((spx_gemm3_kernel<true, false>), grid, dim3(256), lds, s, a);
-    else if (bk) hipLaunchKernelGGL((spx_gemm3_kernel<false, true>), grid, dim3(256), lds, s, a);
-    else hipLaunchKernelGGL((spx_gemm3_kernel<false, false>), grid, dim3(256), lds, s, a);
+    if (ak && bk) hipLaunchKernelGGL((spx_gemm3_kernel<true, true>), grid, dim3(256), spx_g3_oper<true>() + spx_g3_oper<true>(), s, a);
+    else if (ak) hipLaunchKernelGGL((spx_gemm3_kernel<true, false>), grid, dim3(256), spx_g3_oper<true>() + spx_g3_oper<false>(), s, a);
+    else if (bk) hipLaunchKernelGGL((spx_gemm3_kernel<false, true>), grid, dim3(256), spx_g3_oper<false>() + spx_g3_oper<true>(), s, a);
+    else hipLaunchKernelGGL((spx_gemm3_kernel<false, false>), grid, dim3(256), spx_g3_oper<false>() + spx_g3_oper<false>(), s, a);
 }
 
 hipError_t spx_launch_gemm(const float* A, long long ras, long long kas, const float* B, long long rbs, long long kbs,
