@@ -204,18 +204,18 @@ __global__ __launch_bounds__(256) void spx_gemm_kernel(const SpxGemmArgs a) {
 // v_mfma_f32_32x32x2_f32 over the same k - 2.7x the fp32 pipe's rate with the same fp32 accumulation, the dropped terms
 // below the summation-order noise (tests/test_gpu_gemm.py holds both kernels to the same 2e-6 |A|.|B| bound).
 // Workgroup = 4 waves = 128 x 128 of C (wave: 64 x 64 = 2 x 2 MFMA tiles), k in chunks of 32 (a k-contiguous operand is then
-// fetched in whole 128-B row pieces) through ONE LDS buffer of three bf16 planes per operand (48-60 KiB: three or two workgroups per CU):
+// fetched in whole 128-B row pieces) through ONE LDS buffer of three bf16 planes per operand (48 KiB: three workgroups per CU):
 //   k-contiguous operand:   [plane][row][32 k], 64-B rows, the row's four 16-B slots XOR-swizzled by (row >> 2) & 3 - a fragment
 //                           (row = lane & 31, k = 8 (lane >> 5) + j) is one ds_read_b128 and the 16 lanes of a read group fall on 16
 //                           distinct slots without padding: 48 KiB for two such operands, THREE workgroups per CU;
-//   row-contiguous operand: [plane][k][128 rows] with 320-B rows - a thread's 8 consecutive rows are one 16-B write, and
-//                           the fragment comes back through two ds_read_b64_tr_b16 (k becomes the register index; the
-//                           80-dword row stride keeps the four k rows and two column halves of a 32-lane group on distinct banks).
+//   row-contiguous operand: [plane][k][128 rows], 256-B rows, 8-B slots XOR-swizzled by 8 (k & 3) - a thread's 8 consecutive
+//                           rows are one 16-B write, and the fragment comes back through two ds_read_b64_tr_b16 (k becomes the
+//                           register index; the swizzle keeps the four k rows x eight slots of a 32-lane half on distinct banks).
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 #define SPX_G3_TI 128
 #define SPX_G3_TK 32
 #define SPX_G3_KS 64                      // k-contiguous image: row stride in bytes (32 k, unpadded: 16-B slots XOR-swizzled by (row >> 2) & 3)
-#define SPX_G3_RS 320                     // row-contiguous image: k-row stride in bytes (128 rows + 64 B)
+#define SPX_G3_RS 256                     // row-contiguous image: k-row stride in bytes (128 rows, unpadded: 8-B slots XOR-swizzled by 8 (k & 3))
 template <bool KCONT> __host__ __device__ constexpr int spx_g3_plane() { return KCONT ? 128 * SPX_G3_KS : 32 * SPX_G3_RS; }
 template <bool KCONT> __host__ __device__ constexpr int spx_g3_oper() { return 3 * spx_g3_plane<KCONT>(); }
 
@@ -284,7 +284,8 @@ struct SpxGemm3Operand {
             split3_bf16x8(r, h, m, l);
             // KCONT: 8 k of one row;  else: 8 rows of one k - 16 contiguous bytes of the image either way
             const int rw = row + 64 * p;
-            char* const dst = img + (KCONT ? rw * SPX_G3_KS + (((kk >> 3) ^ ((rw >> 2) & 3)) << 4) : (kk + 16 * p) * SPX_G3_RS + row * 2);
+            const int kr = kk + 16 * p;
+            char* const dst = img + (KCONT ? rw * SPX_G3_KS + (((kk >> 3) ^ ((rw >> 2) & 3)) << 4) : kr * SPX_G3_RS + (((row >> 2) ^ (8 * (kr & 3))) << 3));
             *(bf16x8*)dst = h;
             *(bf16x8*)(dst + spx_g3_plane<KCONT>()) = m;
             *(bf16x8*)(dst + 2 * spx_g3_plane<KCONT>()) = l;
@@ -300,7 +301,9 @@ __device__ __forceinline__ bf16x8 g3_frag(const char* __restrict__ plane, int r0
         return *(const bf16x8*)(plane + rw * SPX_G3_KS + (((2 * ks + (lane >> 5)) ^ ((rw >> 2) & 3)) << 4));
     }
     const int g = lane >> 4, i = lane & 15, q = i >> 2, pq = i & 3;
-    const char* const p0 = plane + (16 * ks + 8 * (g >> 1) + q) * SPX_G3_RS + (r0 + 16 * (g & 1) + 4 * pq) * 2;
+    // 8-B slot (r0 + 16 (g & 1)) / 4 + pq of k row 16 ks + 8 (g >> 1) + q, swizzled by the row's k & 3 = q (r0 is a multiple of 32:
+    // the eight slots of a 32-lane half keep bits 3-4 for the swizzle, so its 4 k rows x 8 slots fall on 32 distinct bank pairs)
+    const char* const p0 = plane + (16 * ks + 8 * (g >> 1) + q) * SPX_G3_RS + ((((r0 >> 2) + 4 * (g & 1) + pq) ^ (8 * q)) << 3);
     const s16x4 lo = lds_tr_read(p0), hi = lds_tr_read(p0 + 4 * SPX_G3_RS);
     s16x8 v;
 #pragma unroll
@@ -309,7 +312,7 @@ __device__ __forceinline__ bf16x8 g3_frag(const char* __restrict__ plane, int r0
 }
 
 template <bool AK, bool BK>
-__global__ __launch_bounds__(256, (AK && BK) ? 3 : 2) void spx_gemm3_kernel(const SpxGemmArgs a) {
+__global__ __launch_bounds__(256, 3) void spx_gemm3_kernel(const SpxGemmArgs a) {
     constexpr int TI = SPX_G3_TI, TK = SPX_G3_TK;
     extern __shared__ __attribute__((aligned(16))) char g3_lds[];        // [A | B][plane image]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
