@@ -15,6 +15,7 @@
 
 #define SPX_KLD_TABLE_LDS (60 * 1024)      // LDS budget of the per-class tables of the pair and gradient passes (class blocks beyond it)
 
+#define SPX_KLD_MIN_WGS 512      // tile rows shrink (64 -> 32 -> 16) until the reduction passes launch at least this many workgroups
 #define SPX_KLD_THREADS 256
 #define SPX_KLD_PX_PER_WG 2048
 #define SPX_KLD_MAXJ 16
@@ -583,11 +584,13 @@ hipError_t spx_launch_kld(int pass, const float* vals, const int32_t* labels, in
     dim3 grid((unsigned)((HW + SPX_KLD_PX_PER_WG - 1) / SPX_KLD_PX_PER_WG), (unsigned)B);
     dim3 blk(SPX_KLD_THREADS);
     // rows of a workgroup's tile: 64 (16 steps per wave) on large maps; on small ones (training crops) 32 or 16, so that there
-    // are enough workgroups to fill the chip and a wave's chain of dependent steps is short (each step exposes a load round trip)
+    // are enough workgroups to fill the chip.  (Two workgroups per CU are enough since the passes fetch a step ahead: at 2 Mpx
+    // 64-row tiles = 512 workgroups run the max / sum-exp / pair passes in 27 / 22 / 39 us, 32-row tiles = 1024 in 39 / 25 / 52 -
+    // half the class-run publishes per pixel.)
     int trows = SPX_KLD_TILE;
     if (W > 0 && pass != 3) {
         const int tiles_x = (W + SPX_KLD_TILE - 1) / SPX_KLD_TILE, H = HW / W;
-        while (trows > 16 && (long long)B * tiles_x * ((H + trows - 1) / trows) < 1024) trows >>= 1;
+        while (trows > 16 && (long long)B * tiles_x * ((H + trows - 1) / trows) < SPX_KLD_MIN_WGS) trows >>= 1;
         grid.x = (unsigned)(tiles_x * ((H + trows - 1) / trows));
     }
     if (pass == 0)
