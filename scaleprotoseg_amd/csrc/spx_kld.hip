@@ -586,7 +586,7 @@ hipError_t spx_launch_kld(int pass, const float* vals, const int32_t* labels, in
     // rows of a workgroup's tile: 64 (16 steps per wave) on large maps; on small ones (training crops) 32 or 16, so that there
     // are enough workgroups to fill the chip.  (Two workgroups per CU are enough since the passes fetch a step ahead: at 2 Mpx
     // 64-row tiles = 512 workgroups run the max / sum-exp / pair passes in 27 / 22 / 39 us, 32-row tiles = 1024 in 39 / 25 / 52 -
-    // half the class-run publishes per pixel.)
+    // half the class-run publishes per pixel; 128-row tiles = 256 workgroups in 35 / 38 / 59.)
     int trows = SPX_KLD_TILE;
     if (W > 0 && pass != 3) {
         const int tiles_x = (W + SPX_KLD_TILE - 1) / SPX_KLD_TILE, H = HW / W;
@@ -617,6 +617,7 @@ hipError_t spx_launch_kld(int pass, const float* vals, const int32_t* labels, in
         float* o = (float*)out;
         // pixels per workgroup: 2048 on large maps; small maps (training crops) get enough workgroups to fill the chip - a thread
         // then takes one pixel instead of walking eight in sequence behind the table set-up (80 -> ~20 us at 10 x 65 x 65)
+        // (2 Mpx, same box: 512 / 1024 / 2048 / 4096 / 8192 pixels per workgroup = 65 / 51 / 45 / 55 / 82 us)
         int ppw = SPX_KLD_PX_PER_WG;
         while (ppw > SPX_KLD_THREADS && (long long)B * ((HW + ppw - 1) / ppw) < 512) ppw >>= 1;
         grid.x = (unsigned)((HW + ppw - 1) / ppw);
