@@ -1,5 +1,5 @@
 """Probe: the kernels of ONE eager step through the drop-in modules at crop size (torch profiler table).
-usage: module_step_kernels.py [group|proto|adegroup|adeproto] [ce]"""
+usage: module_step_kernels.py [group|proto|adegroup|adeproto|cocoproto|cocogroup] [ce]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch, torch.nn as nn
@@ -25,6 +25,12 @@ if kind == "group":
 elif kind == "adegroup":
     B, K = 2, 150
     net = GroupNet(BB(256), 64, (1800, 64, 1, 1), [], 150, num_groups=3, **mk).to(dev)
+elif kind == "cocoproto":
+    B, K = 2, 182
+    net = spx.PPNetMultiScale(BB(256), 64, (2184, 64, 1, 1), [], 182, **mk).to(dev)
+elif kind == "cocogroup":
+    B, K = 2, 182
+    net = GroupNet(BB(256), 64, (2184, 64, 1, 1), [], 182, num_groups=3, **mk).to(dev)
 elif kind == "adeproto":
     B, K = 2, 150
     net = spx.PPNetMultiScale(BB(256), 64, (1800, 64, 1, 1), [], 150, **mk).to(dev)
