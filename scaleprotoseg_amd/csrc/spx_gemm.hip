@@ -402,8 +402,15 @@ __global__ __launch_bounds__(256, 3) void spx_gemm3_kernel(const SpxGemmArgs a) 
 __global__ __launch_bounds__(256) void spx_gemm_reduce_kernel(const float* __restrict__ ws, int splits, long long MN, int N, float* __restrict__ C, long long ldc) {
     const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
     if (g >= MN) return;
+    // four slabs in flight per round (a rolled sum pays one memory round trip per slab); slab order is kept: a fixed order
     float s = 0.0f;
-    for (int k = 0; k < splits; ++k) s += ws[(size_t)k * MN + g];
+    int k = 0;
+    for (; k + 4 <= splits; k += 4) {
+        const float v0 = ws[(size_t)k * MN + g], v1 = ws[(size_t)(k + 1) * MN + g];
+        const float v2 = ws[(size_t)(k + 2) * MN + g], v3 = ws[(size_t)(k + 3) * MN + g];
+        s = (((s + v0) + v1) + v2) + v3;
+    }
+    for (; k < splits; ++k) s += ws[(size_t)k * MN + g];
     C[(g / N) * ldc + (g % N)] = s;
 }
 
